@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (read-only at /root/reference).
+
+Test infrastructure; runs only in the build container (the reference never travels).  It imports
+the reference through the stub harness documented in SURVEY.md section 8c / Appendix A: third-party
+packages that are not installed (cv2, torchvision, ultralytics, timm, mmcv, ...) and `utils.plots`
+(whose import would try a font download) are pre-seeded in sys.modules as inert stubs, the
+reference's local `Conv` is installed where `models/common.py:9163` re-imports it from, and nothing
+that touches the network is ever called.  Only library functions are executed.
+
+Every fixture holds *inputs and expected outputs* (data); weights are regenerated from names by
+`oracle.somi_ref.testing.fill_state`, so no reference state_dict or source is stored.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python oracle/gen_golden.py
+"""
+import logging
+import os
+import sys
+from unittest.mock import MagicMock
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.dont_write_bytecode = True
+
+
+class _Stub(MagicMock):
+    __all__ = []
+
+
+for _n in ['cv2', 'torchvision', 'torchvision.transforms', 'torchvision.ops', 'seaborn', 'thop', 'utils.plots', 'DCNv3',
+           'ultralytics', 'ultralytics.nn', 'ultralytics.nn.modules', 'ultralytics.nn.modules.utils',
+           'ultralytics.nn.modules.conv', 'ultralytics.utils', 'ultralytics.utils.tal', 'timm', 'timm.models',
+           'timm.models.efficientnet_blocks', 'timm.models.layers', 'timm.models.layers.norm', 'monai',
+           'monai.networks', 'monai.networks.blocks', 'mmcv', 'mmcv.cnn', 'mmcv.ops',
+           'mmcv.ops.modulated_deform_conv', 'mmengine', 'mmengine.model']:
+    sys.modules[_n] = _Stub()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+logging.disable(logging.CRITICAL)
+torch.set_num_threads(8)
+
+_src = open(f'{REF}/models/common.py').read().split('\n')
+_ns = {'nn': nn, 'torch': torch}
+exec('\n'.join(_src[42:70]), _ns)                       # the reference's local autopad + Conv (common.py:43-70)
+sys.modules['ultralytics.nn.modules.conv'].Conv = _ns['Conv']
+sys.path.insert(0, REF)
+import models.common as RC  # noqa: E402
+import models.yolo as RY  # noqa: E402
+
+RY.Segment = type('Segment', (nn.Module,), {})
+from utils.loss import ComputeLoss as RefComputeLoss  # noqa: E402
+from utils.metrics import bbox_iou as ref_bbox_iou, box_iou as ref_box_iou  # noqa: E402
+from utils.torch_utils import fuse_conv_and_bn as ref_fuse  # noqa: E402
+import utils.general as RG  # noqa: E402
+import utils.RepulsionLoss as RR  # noqa: E402
+
+sys.path.insert(0, f'{REF}/models/ops_dcnv3')
+from functions.dcnv3_func import dcnv3_core_pytorch  # noqa: E402
+
+sys.path.insert(0, ROOT)
+from oracle.somi_ref.testing import fill_state, synthetic_batch, somi_cfg, SOMI_ANCHORS, HYP_VISDRONE  # noqa: E402
+from oracle.somi_ref.nms import greedy_nms  # noqa: E402
+
+# the NMS core is third-party (torchvision): install the restated greedy NMS so the reference's
+# surrounding filtering / multi-label logic can run (SURVEY Appendix A note 2)
+sys.modules['torchvision'].ops.nms = lambda b, s, t: greedy_nms(b, s, t)
+RG.torchvision = sys.modules['torchvision']
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        flat[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **flat)
+    print(f'{name}: {sum(a.nbytes for a in flat.values()) / 1e3:.1f} kB')
+
+
+# ------------------------------------------------------------------------------------------------ DCNv3
+def dcn_case(tag, N, H, W, G, Gc, k, s, p, d, osc, seed, grads=True, dt=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+    K = k * k
+    x = (torch.rand(N, H, W, G * Gc, generator=g) * 0.01).to(dt)        # test.py:35-39 value ranges
+    off = (torch.rand(N, Ho, Wo, G * K * 2, generator=g) * 10).to(dt)
+    m = torch.rand(N, Ho, Wo, G, K, generator=g) + 1e-5
+    m = (m / m.sum(-1, keepdim=True)).reshape(N, Ho, Wo, G * K).to(dt)
+    x.requires_grad_(grads), off.requires_grad_(grads), m.requires_grad_(grads)
+    out = dcnv3_core_pytorch(x, off, m, k, k, s, s, p, p, d, d, G, Gc, osc)
+    rec = dict(input=x, offset=off, mask=m, output=out,
+               params=np.array([N, H, W, G, Gc, k, s, p, d], dtype=np.int64), offset_scale=np.float64(osc))
+    if grads:
+        go = torch.rand(out.shape, generator=g).to(dt)
+        gi, goff, gm = torch.autograd.grad(out, (x, off, m), go)
+        rec.update(grad_output=go, grad_input=gi, grad_offset=goff, grad_mask=gm)
+    save(f'dcnv3_{tag}', **rec)
+
+
+def gen_dcnv3():
+    # the reference test's fixture (models/ops_dcnv3/test.py:19-30): fp64 and fp32
+    dcn_case('testpy_f64', 2, 8, 8, 4, 16, 3, 1, 1, 1, 2.0, 3)
+    dcn_case('testpy_f32', 2, 8, 8, 4, 16, 3, 1, 1, 1, 2.0, 3, dt=torch.float32)
+    # backward channel sweep of test.py:257-260 (N=2, M=2); 1025 omitted from the fixture for size
+    for D in (1, 16, 30, 32, 64, 71):
+        dcn_case(f'bwd_D{D}', 2, 8, 8, 2, D, 3, 1, 1, 1, 2.0, 3 + D)
+    # geometry coverage the host launcher allows (dcnv3_cuda.cu:40-45)
+    dcn_case('s2_p1', 1, 9, 11, 2, 8, 3, 2, 1, 1, 1.0, 11)
+    dcn_case('d2_p2', 1, 10, 7, 3, 4, 3, 1, 2, 2, 1.5, 12)
+    dcn_case('k5_p2', 2, 7, 7, 1, 8, 5, 1, 2, 1, 0.5, 13)
+    dcn_case('p0', 1, 6, 6, 2, 4, 3, 1, 0, 1, 1.0, 14)
+
+
+# ------------------------------------------------------------------------------------------------ blocks
+def run_block(tag, mod, xs, train_too=True, seed=0):
+    fill_state(mod, seed)
+    RY.initialize_weights(mod)                                  # BN eps 1e-3 / momentum 0.03 as in Model.__init__
+    rec = {}
+    for i, x in enumerate(xs if isinstance(xs, (list, tuple)) else [xs]):
+        rec[f'in{i}'] = x
+    mod.eval()
+    with torch.no_grad():
+        y = mod(xs.clone() if isinstance(xs, torch.Tensor) else [t.clone() for t in xs])
+    rec['out_eval'] = y
+    if train_too:
+        mod.train()
+        with torch.no_grad():
+            y = mod(xs.clone() if isinstance(xs, torch.Tensor) else [t.clone() for t in xs])
+        rec['out_train'] = y
+    save(f'block_{tag}', **rec)
+
+
+def gen_blocks():
+    g = torch.Generator().manual_seed(100)
+    r = lambda *s: torch.randn(*s, generator=g)
+    run_block('conv3x3_s1', RC.Conv(16, 24, 3, 1), r(2, 16, 12, 10))
+    run_block('conv3x3_s2', RC.Conv(3, 16, 3, 2), r(2, 3, 13, 17))
+    run_block('conv1x1', RC.Conv(40, 8, 1, 1), r(2, 40, 6, 6))
+    run_block('c2fcbam_sc', RC.C2fCBAM(32, 32, 2, True), r(2, 32, 12, 12))
+    run_block('c2fcbam_nosc', RC.C2fCBAM(48, 32, 1, False), r(2, 48, 9, 7))
+    run_block('cbam_bneck', RC.CBAMBottleneck(32, 32, True, 1, k=(3, 3), e=1.0, ratio=16, kernel_size=7), r(2, 32, 10, 10))
+    run_block('odconv_s2', RC.ODConv_3rd(16, 32, 3, 2, 4), r(3, 16, 12, 12))
+    run_block('odconv_b1', RC.ODConv_3rd(16, 32, 3, 2, 4), r(1, 16, 12, 12), train_too=False)
+    run_block('sppf', RC.SPPF(32, 32, 5), r(2, 32, 9, 9))
+    run_block('bifpn2', RC.BiFPN(2), [r(2, 8, 6, 6), r(2, 8, 6, 6)], train_too=False)
+    run_block('bifpn3', RC.BiFPN(3), [r(2, 8, 6, 6), r(2, 8, 6, 6), r(2, 8, 6, 6)], train_too=False)
+    run_block('seam', RC.SEAM(32, 32, 1, 16), r(2, 32, 10, 10))
+    run_block('decouple', RY.Decouple(64, 10, 4), r(2, 64, 8, 8))
+    # fuse_conv_and_bn (utils/torch_utils.py:202-222)
+    c = RC.Conv(8, 12, 3, 1)
+    fill_state(c, 5)
+    c.bn.eps = 1e-3
+    f = ref_fuse(c.conv, c.bn)
+    save('fuse_conv_bn', weight=f.weight, bias=f.bias)
+
+
+# ------------------------------------------------------------------------------------------------ model
+def build_ref_model(width, depth, anchors):
+    cfg = somi_cfg(width, depth, anchors=anchors)
+    cfg['backbone'] = [[f, n, {'Conv': 'Conv'}.get(m, m), a] for f, n, m, a in cfg['backbone']]
+    m = RY.Model(cfg)
+    fill_state(m, 1)
+    return m
+
+
+def gen_model():
+    g = torch.Generator().manual_seed(200)
+    for tag, width, depth, anchors, B, S in (('w025_anch4', 0.25, 0.33, 4, 2, 64),
+                                             ('w025_visdrone', 0.25, 0.33, SOMI_ANCHORS, 2, 96),
+                                             ('full', 1.0, 1.0, SOMI_ANCHORS, 1, 64)):
+        m = build_ref_model(width, depth, anchors)
+        x = torch.rand(B, 3, S, S, generator=g)
+        m.eval()
+        with torch.no_grad():
+            z, raw = m(x.clone())
+        rec = dict(x=x, z=z, stride=m.stride, anchors=m.model[-1].anchors,
+                   nparams=np.int64(sum(p.numel() for p in m.parameters())))
+        for i, t in enumerate(raw):
+            rec[f'raw{i}'] = t
+        if B > 1:
+            m.train()
+            with torch.no_grad():
+                tr = m(x.clone())
+            for i, t in enumerate(tr):
+                rec[f'train{i}'] = t
+        # fused (Model.fuse) eval output
+        m.eval()
+        m.fuse()
+        with torch.no_grad():
+            zf, _ = m(x.clone())
+        rec['z_fused'] = zf
+        save(f'model_{tag}', **rec)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+def gen_loss():
+    m = build_ref_model(0.25, 0.33, SOMI_ANCHORS)
+    m.hyp = dict(HYP_VISDRONE)
+    crit = RefComputeLoss(m)
+    det = m.model[-1]
+    for tag, B, S, seed, nt_mode in (('a', 2, 64, 0, 'normal'), ('b', 3, 128, 1, 'normal'), ('empty', 2, 64, 2, 'empty'),
+                                     ('edge', 2, 64, 3, 'edge')):
+        g = torch.Generator().manual_seed(300 + seed)
+        p = [torch.randn(B, det.na, S // int(s), S // int(s), det.no, generator=g).requires_grad_(True) for s in m.stride]
+        _, targets = synthetic_batch(B, S, seed=seed)
+        if nt_mode == 'empty':
+            targets = torch.zeros(0, 6)
+        elif nt_mode == 'edge':
+            targets = targets[:12].clone()
+            targets[:6, 2:4] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [0.999, 0.001], [0.5, 0.5], [0.25, 0.75], [0.5, 0.0]])
+            targets[6:, 4:6] = torch.tensor([[0.5, 0.5], [0.004, 0.004], [0.3, 0.01], [0.01, 0.3], [0.05, 0.05], [0.1, 0.2]])
+            targets[3:5, 2:6] = targets[3:4, 2:6]                  # duplicate box -> same cell twice
+        loss, items = crit(p, targets)
+        grads = torch.autograd.grad(loss, p, allow_unused=True)
+        tcls, tbox, indices, anch = crit.build_targets(p, targets)
+        rec = dict(targets=targets, loss=loss, items=items, anchors=det.anchors, stride=m.stride)
+        for i in range(len(p)):
+            rec[f'p{i}'] = p[i]
+            rec[f'g{i}'] = grads[i] if grads[i] is not None else torch.zeros_like(p[i])
+            rec[f'tcls{i}'], rec[f'tbox{i}'], rec[f'anch{i}'] = tcls[i], tbox[i], anch[i]
+            rec[f'idx{i}'] = torch.stack(indices[i], 0) if indices[i][0].numel() else torch.zeros(4, 0, dtype=torch.long)
+        save(f'loss_{tag}', **rec)
+    # bbox_iou CIoU (utils/metrics.py:476-518)
+    g = torch.Generator().manual_seed(350)
+    b1 = torch.rand(64, 4, generator=g) * torch.tensor([20, 20, 8, 8.]) + torch.tensor([0, 0, 0.05, 0.05])
+    b2 = torch.rand(64, 4, generator=g) * torch.tensor([20, 20, 8, 8.]) + torch.tensor([0, 0, 0.05, 0.05])
+    b2[:8] = b1[:8]
+    save('ciou', box1=b1, box2=b2, ciou=ref_bbox_iou(b1.T, b2, x1y1x2y2=False, CIoU=True))
+    # repulsion loss (utils/RepulsionLoss.py:47-95); its hard-coded .cuda() hops are made identity on CPU
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    g = torch.Generator().manual_seed(360)
+    ctr = torch.rand(2, 40, 2, generator=g) * 50
+    wh = torch.rand(2, 40, 2, generator=g) * 20 + 2
+    pb = torch.cat((ctr - wh / 2, ctr + wh / 2), -1)
+    gt_pool = torch.cat((ctr[:, :6] - 8, ctr[:, :6] + 8), -1)
+    gb = gt_pool[:, torch.randint(0, 6, (40,), generator=g)]
+    fg = torch.rand(2, 40, generator=g) > 0.4
+    rgt, rbox = RR.repulsion_loss(pb, gb, fg, sigma_repgt=0.9, sigma_repbox=0)
+    save('repulsion', pbox=pb, gtbox=gb, fg=fg, rep_gt=rgt, rep_box=rbox)
+
+
+# ------------------------------------------------------------------------------------------------ nms
+def gen_nms():
+    m = build_ref_model(0.25, 0.33, SOMI_ANCHORS)
+    m.eval()
+    g = torch.Generator().manual_seed(400)
+    x = torch.rand(2, 3, 96, 96, generator=g)
+    with torch.no_grad():
+        z, _ = m(x)
+    # spread objectness so that several thresholds select different subsets
+    z = z.clone()
+    z[..., 4] = torch.rand(z.shape[:2], generator=g) ** 3
+    z[..., 5:] = torch.rand(z[..., 5:].shape, generator=g)
+    z[..., :2] = torch.rand(z[..., :2].shape, generator=g) * 96
+    z[..., 2:4] = torch.rand(z[..., 2:4].shape, generator=g) * 30 + 2
+    z[0, 10:14, :4] = z[0, 10, :4]                                   # exact duplicates -> ties
+    z[0, 10:14, 4:] = z[0, 10, 4:]
+    cases = dict(default=dict(conf_thres=0.25, iou_thres=0.45),
+                 val=dict(conf_thres=0.4, iou_thres=0.2, multi_label=True),
+                 bench=dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+                 agnostic=dict(conf_thres=0.3, iou_thres=0.5, agnostic=True),
+                 classes=dict(conf_thres=0.2, iou_thres=0.45, classes=[1, 3, 7]),
+                 maxdet=dict(conf_thres=0.05, iou_thres=0.9, multi_label=True, max_det=20),
+                 none=dict(conf_thres=0.9999, iou_thres=0.45))
+    rec = dict(pred=z)
+    for tag, kw in cases.items():
+        out = RG.non_max_suppression(z.clone(), **kw)
+        for b, o in enumerate(out):
+            rec[f'{tag}_{b}'] = o
+    save('nms', **rec)
+    b1 = z[0, :50, :4].clone(); b1[:, 2:] += b1[:, :2]
+    b2 = z[1, :40, :4].clone(); b2[:, 2:] += b2[:, :2]
+    save('box_iou', box1=b1, box2=b2, iou=ref_box_iou(b1, b2))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'loss', 'nms']
+    for w in which:
+        globals()[f'gen_{w}']()

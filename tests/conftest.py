@@ -1,0 +1,29 @@
+"""pytest configuration: registers the `gpu` marker and puts the repo on sys.path.
+
+`-m "not gpu"`: oracle-vs-golden, host logic, C-ABI symbol checks (runs on CPU).
+`-m gpu`: parity tests proper - the HIP path (through the C-ABI) against the oracle / golden vectors.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'yolo-somi_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import numpy as np
+
+    def load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+    return load
