@@ -1,0 +1,227 @@
+/* somi_hip.h - C ABI of libsomi_hip.so, the MI355X (gfx950) hot path of YOLO-SOMI.
+ *
+ * Drop-in boundary.  The reference's only native boundary is the pybind
+ * module `DCNv3` (models/ops_dcnv3/src/vision.cpp:14-17, src/dcnv3.h:20-59); everything else on
+ * the path is reached through Python call signatures (models/yolo.py, utils/loss.py,
+ * utils/general.py).  This header declares one plain-C entry point per device operation on
+ * that path; the Python host layer in yolo-somi_amd/somi_amd/ mirrors the reference's
+ * Python signatures on top of it (see INTEGRATION.md for the reference-side binding).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; the library never
+ *    allocates, frees, copies or synchronises: outputs and workspaces are caller-owned;
+ *  - tensors are fp32, activations are NHWC with an explicit channel stride (`*_cs`, in floats)
+ *    and channel offset (`*_coff`) so that channel slices / concatenations need no copy;
+ *    vectorised paths need `*_cs % 4 == 0`, `*_coff % 4 == 0` and 16-byte aligned bases;
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns;
+ *  - return value: 0 on success, a negative SOMI_E* code on a rejected argument (nothing was
+ *    launched), or a positive hipError_t from the launch.  somi_last_error() gives the text.
+ *    Argument errors mirror the reference's AT_ASSERTM checks (dcnv3_cuda.cu:29-53).
+ */
+#ifndef SOMI_HIP_H
+#define SOMI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOMI_ABI_VERSION 1
+
+#define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
+#define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
+#define SOMI_EWORKSPACE (-3) /* workspace too small */
+
+typedef void *somi_stream_t;
+
+int somi_abi_version(void);
+const char *somi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Activations used in fused epilogues.
+ */
+enum somi_act { SOMI_ACT_NONE = 0, SOMI_ACT_SILU = 1, SOMI_ACT_GELU = 2, SOMI_ACT_RELU = 3, SOMI_ACT_SIGMOID = 4 };
+
+/* ------------------------------------------------------------------------------------------
+ * Dense convolution as NHWC implicit GEMM on MFMA with a fused epilogue.
+ * Replaces: nn.Conv2d + BatchNorm2d(eval, folded) + SiLU inside `Conv.forward`
+ * (models/common.py:64-70, utils/torch_utils.py:202-222), the grouped conv of ODConv2d_3rd
+ * (models/common.py:4602-4605, per-sample weights), SEAM's 1x1 (+GELU+BN, models/common.py:8463-8465),
+ * Decouple's b3/c3 1x1 (+bias, models/yolo.py:1057,1063) and nn.Linear projections of DCNv3
+ * (models/ops_dcnv3/modules/dcnv3.py:324,330-331,377) which are 1x1 convs in NHWC.
+ *
+ *   y[b,ho,wo,n] = post( act( sum_{r,q,c} x'[b, ho*s-p+r*d, wo*s-p+q*d, c] * w[wset][n][(r*kw+q)*Cin+c] + bias[wset][n] ) )
+ *   post(v) = v*post_scale[n] + post_shift[n]  (if given), then + residual[b,ho,wo,n] (if given)
+ *   x' = x * a_chan_scale[b][c] * a_pix_scale[b][h][w]   (each factor optional; CBAM fused on the operand load)
+ *   wset = b if per_sample_w else 0.
+ */
+typedef struct somi_conv_desc {
+    const float *x;
+    const float *w;
+    const float *bias;        /* [n_wsets][Cout] or NULL */
+    const float *post_scale;  /* [Cout] or NULL */
+    const float *post_shift;  /* [Cout] or NULL (required iff post_scale) */
+    const float *residual;    /* NHWC (B,Ho,Wo,*) or NULL */
+    const float *a_chan_scale;/* [B][Cin] or NULL */
+    const float *a_pix_scale; /* [B][H][W] or NULL */
+    float *y;
+    int32_t B, H, W, Cin, x_cs, x_coff;
+    int32_t Ho, Wo, Cout, y_cs, y_coff;
+    int32_t kh, kw, stride, pad, dil;
+    int32_t res_cs, res_coff;
+    int32_t act;              /* enum somi_act */
+    int32_t per_sample_w;
+} somi_conv_desc;
+
+int somi_conv2d_nhwc_f32(const somi_conv_desc *d, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DCNv3 operator.  Replaces `dcnv3_forward` / `dcnv3_backward` of the reference extension
+ * (models/ops_dcnv3/src/dcnv3.h:20-59, src/cuda/dcnv3_cuda.cu:21-174, kernels
+ * src/cuda/dcnv3_im2col_cuda.cuh:216-275 fwd and :278-839 bwd).
+ * input (N,H,W,G*Gc); offset (N,Ho,Wo,G*K*2) x,y interleaved, points ordered kernel_w-outer /
+ * kernel_h-inner; mask (N,Ho,Wo,G*K); output (N,Ho,Wo,G*Gc).  All contiguous.
+ * Backward: grad_input must be ZEROED by the caller (the reference allocates it with at::zeros,
+ * dcnv3_cuda.cu:126-133); grad_offset / grad_mask are fully overwritten.
+ * im2col_step is validated like the reference (batch % min(batch, im2col_step) == 0) and otherwise
+ * unused: the whole batch is one launch.
+ */
+int somi_dcnv3_forward_f32(const float *input, const float *offset, const float *mask, float *output,
+                           int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h,
+                           int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
+                           float offset_scale, int im2col_step, somi_stream_t stream);
+
+int somi_dcnv3_backward_f32(const float *input, const float *offset, const float *mask, const float *grad_output,
+                            float *grad_input, float *grad_offset, float *grad_mask,
+                            int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h,
+                            int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
+                            float offset_scale, int im2col_step, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bandwidth-bound layer kernels of Model._forward_once (models/yolo.py:1269-1290).
+ */
+
+/* uint8 NCHW image batch -> fp32 NHWC with 4 channels (4th = 0), scaled by 1/255
+ * (train.py:249 `imgs.float()/255`, val.py:150-152).  Also accepts fp32 NCHW input via the _f32 form. */
+int somi_image_u8_to_nhwc4(const uint8_t *img, float *y, int B, int C, int H, int W, somi_stream_t stream);
+int somi_image_f32_to_nhwc4(const float *img, float *y, int B, int C, int H, int W, float scale, somi_stream_t stream);
+
+/* Depthwise 3x3, stride 1, pad 1, + bias, then act, then per-channel affine, then optional residual.
+ * Replaces SEAM's `Conv2d(groups=c) -> GELU -> BatchNorm2d` stages (+Residual) (models/common.py:8454-8466, 7183-7189).
+ * w is [3][3][C] (tap-major), C % 4 == 0. */
+int somi_dwconv3x3_nhwc_f32(const float *x, const float *w, const float *bias, const float *post_scale,
+                            const float *post_shift, const float *residual, float *y, int B, int H, int W, int C,
+                            int act, somi_stream_t stream);
+
+/* SPPF pooling: from x = slice [x_coff, x_coff+C) of a (B,H,W,cs) tensor write the three chained 5x5/s1/p2
+ * max-pools (== 5x5, 9x9, 13x13 windows) to the slices at y_coff + {1,2,3}*C of the same tensor
+ * (models/common.py:1856-1861).  In-place on one concat buffer: the pooled slices never alias the source slice. */
+int somi_sppf_pool_nhwc_f32(float *buf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream);
+
+/* BiFPN fusion (models/common.py:3695-3704) with the preceding nn.Upsample(2,'nearest') folded in:
+ * y = sum_i wn[i] * src_i, where source i is read at (h>>up[i], w>>up[i]).  wn = w / (sum swish(w) + 1e-4) is
+ * computed on the host.  n_in in {2,3}; all sources C channels, contiguous NHWC. */
+int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const float *wn_host, int n_in, float *y,
+                        int B, int H, int W, int C, somi_stream_t stream);
+
+/* Global average + max pool over H*W of a channel slice: out_avg[b][c], out_max[b][c]
+ * (ChannelAttentionModule models/common.py:355-357; also GAP for ODConv :4558 and SEAM :8483).
+ * partial workspace: 2*B*nchunk*C floats with nchunk = somi_pool_nchunk(H*W). out_max may be NULL. */
+int somi_pool_nchunk(int HW);
+int somi_global_pool_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, float *out_avg,
+                              float *out_max, float *workspace, somi_stream_t stream);
+
+/* Tiny per-sample MLP heads (host picks the recipe):
+ *  mode 0 (CBAM channel attention, models/common.py:355-358):
+ *        out[b] = sigmoid( W2 relu(W1 avg[b] + b1) + b2 + W2 relu(W1 max[b] + b1) + b2 )
+ *  mode 1 (SEAM, models/common.py:8484-8487): out[b] = exp( sigmoid( W2 relu(W1 avg[b]) ) )   (no biases)
+ * W1 [mid][C], W2 [C][mid]. */
+int somi_attn_mlp_f32(int mode, const float *avg, const float *mx, const float *W1, const float *b1, const float *W2,
+                      const float *b2, float *out, int B, int C, int mid, somi_stream_t stream);
+
+/* Per-pixel channel statistics of x*ca: stats[b,h,w,0] = mean_c(x*ca), stats[...,1] = max_c(x*ca)
+ * (SpatialAttentionModule models/common.py:400-402 applied to `channel_attention(x)*x`, :686-688). */
+int somi_chan_stats_nhwc_f32(const float *x, int x_cs, int x_coff, const float *ca, float *stats, int B, int HW, int C,
+                             somi_stream_t stream);
+
+/* k x k conv 2->1 channels + bias + sigmoid on the stats map -> sa[b,h,w] (models/common.py:396,403). w is [k][k][2]. */
+int somi_spatial_attn_f32(const float *stats, const float *w, float bias, float *sa, int B, int H, int W, int k,
+                          somi_stream_t stream);
+
+/* y = x * s[b][c] (SEAM output x*exp(fc), models/common.py:8489-8490; also materialised CBAM scaling). In place allowed. */
+int somi_scale_channels_nhwc_f32(const float *x, const float *s, const float *pix, float *y, int B, int HW, int C,
+                                 somi_stream_t stream);
+
+/* ODConv attention + per-sample weight synthesis (models/common.py:4557-4590):
+ *  z = relu(bn(fc(gap)))  [bn folded into fc_w/fc_b by the host; skipped when B==1 as the reference does]
+ *  a_f = sigmoid(Wf z + bf) [Cout], a_s = sigmoid(Ws z + bs) [kk], a_c = sigmoid(Wc z + bc) [Cin], a_w = softmax(Ww z + bw) [K]
+ *  wout[b][n][(t)*Cin_pad + c] = a_f[n] a_s[t] a_c[c] sum_K a_w[K] Wk[K][n][t][c]   (zero in padded c)
+ *  bout[b][n] = sum_K a_w[K] bias[K][n]
+ * then conv BN (eval) is folded: wout *= bn_scale[n]; bout = bout*bn_scale[n] + bn_shift[n].
+ * Wk is [K][Cout][kk][Cin_pad]. attn workspace: B*(hid + Cout + kk + Cin + K) floats. */
+int somi_odconv_weights_f32(const float *gap, const float *fc_w, const float *fc_b, const float *Wf, const float *bf,
+                            const float *Ws, const float *bs, const float *Wc, const float *bc, const float *Ww,
+                            const float *bw, const float *Wk, const float *biask, const float *bn_scale,
+                            const float *bn_shift, float *wout, float *bout, float *workspace, int B, int Cin,
+                            int Cin_pad, int Cout, int kk, int K, int hid, somi_stream_t stream);
+
+/* Detection decode (DecoupledDetect.forward eval branch, models/yolo.py:943-961 + Decouple interleave :1073):
+ * box (B,ny,nx,box_cs>=na*5) and cls (B,ny,nx,cls_cs>=na*nc) head outputs ->
+ *   raw (B,na,ny,nx,no)            [x[i] of the reference, always written if non-NULL]
+ *   z   (B,total,no) rows [row_off, row_off+na*ny*nx): sigmoid, xy=(s*2-0.5+grid)*stride, wh=(s*2)^2*anchor_px. */
+int somi_detect_decode_f32(const float *box, int box_cs, const float *cls, int cls_cs, const float *anchors_px_host,
+                           float stride, float *raw, float *z, int B, int ny, int nx, int na, int nc, int total,
+                           int row_off, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
+ * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.
+ * Selection is bit-exact with the oracle: candidates in prediction order (row-major over (box, class) for
+ * multi_label), stable sort by descending score, greedy suppression with IoU > iou_thres, class offset 4096.
+ * classes_mask: bit c set = keep class c (0xFFFFFFFF.. = no filter).
+ * workspace bytes: somi_nms_workspace_bytes(B, n, nc, multi_label).
+ */
+size_t somi_nms_workspace_bytes(int B, int n, int nc, int multi_label);
+int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_thres, float iou_thres, int multi_label,
+                 int agnostic, uint64_t classes_mask, int max_det, float *det, int32_t *count, void *workspace,
+                 size_t workspace_bytes, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss: ComputeLoss.__call__ + build_targets (utils/loss.py:142-262) with CIoU (utils/metrics.py:476-518).
+ * p[l] (B,na,ny_l,nx_l,no) for l < nl<=4; targets (nt,6) [img,cls,x,y,w,h]; anchors (nl,na,2) in grid units.
+ * out[0..3] = total*bs, lbox, lobj, lcls (already multiplied by the hyp gains, like loss_items).
+ * grad[l] (optional, may be NULL): d(out[0])/d p[l], fully overwritten.
+ * workspace bytes: somi_loss_workspace_bytes(B, na, nl, ny[], nx[], nt).
+ */
+typedef struct somi_loss_desc {
+    const float *p[4];
+    float *grad[4];
+    int32_t ny[4], nx[4];
+    int32_t nl, na, nc, B, nt;
+    const float *targets;
+    const float *anchors;
+    float balance[4];
+    float box_gain, obj_gain, cls_gain, cls_pw, obj_pw, anchor_t, cp, cn, gr;
+} somi_loss_desc;
+
+size_t somi_loss_workspace_bytes(const somi_loss_desc *d);
+int somi_yolo_loss_f32(const somi_loss_desc *d, float *out4, void *workspace, size_t workspace_bytes,
+                       somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weighted boxes fusion (wbf.py:68 -> ensemble_boxes.weighted_boxes_fusion, conf_type 'avg').
+ * boxes (n,4) xyxy in [0,1], scores (n), labels (n) int32, model (n) int32, already concatenated over models
+ * in model order; out_* sized n; out_count 1 int32.  One launch per image; sequential per label by design.
+ */
+size_t somi_wbf_workspace_bytes(int n);
+int somi_wbf_f32(const float *boxes, const float *scores, const int32_t *labels, const int32_t *model, int n,
+                 int n_models, const float *weights_host, float iou_thr, float skip_box_thr, float *out_boxes,
+                 float *out_scores, int32_t *out_labels, int32_t *out_count, void *workspace, size_t workspace_bytes,
+                 somi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOMI_HIP_H */

@@ -1,0 +1,95 @@
+"""DCNv3 HIP kernels (through the C ABI and the host mirror of the reference extension) against
+(1) the golden vectors produced by the reference's dcnv3_core_pytorch and (2) the CPU oracle at larger sizes.
+Bars: the reference's own test uses rtol 1e-2 / atol 1e-3 in fp32 (models/ops_dcnv3/test.py:85,134-148);
+BASELINE.json asks 1e-3 relative - that is what is asserted here."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def rel_close(got, want, rel=1e-3, what=''):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-30
+    assert err <= rel * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+GOLD = ['testpy_f32', 'testpy_f64', 'bwd_D1', 'bwd_D16', 'bwd_D30', 'bwd_D32', 'bwd_D64', 'bwd_D71', 's2_p1', 'd2_p2',
+        'k5_p2', 'p0']
+
+
+@pytest.mark.parametrize('tag', GOLD)
+def test_dcnv3_against_reference_vectors(golden, tag):
+    from somi_amd.dcnv3 import dcnv3_forward, dcnv3_backward
+    g = golden('dcnv3_' + tag)
+    N, H, W, G, Gc, k, s, p, d = (int(v) for v in g['params'])
+    osc = float(g['offset_scale'])
+    dev = torch.device('cuda:0')
+    x, off, m = (T(g[n]).float().contiguous().to(dev) for n in ('input', 'offset', 'mask'))
+    out = dcnv3_forward(x, off, m, k, k, s, s, p, p, d, d, G, Gc, osc, 256)
+    rel_close(out, T(g['output']), what='forward')
+    go = T(g['grad_output']).float().contiguous().to(dev)
+    gi, goff, gm = dcnv3_backward(x, off, m, k, k, s, s, p, p, d, d, G, Gc, osc, go, 256)
+    rel_close(gi, T(g['grad_input']), what='grad_input')
+    rel_close(goff, T(g['grad_offset']), what='grad_offset')
+    rel_close(gm, T(g['grad_mask']), what='grad_mask')
+
+
+@pytest.mark.parametrize('N,H,W,G,Gc,k,s,p,d', [(2, 8, 8, 2, 1025, 3, 1, 1, 1),      # the D=1025 case of test.py:257
+                                                (2, 40, 40, 8, 32, 3, 1, 1, 1),       # SOMI-like C=256 G=8
+                                                (3, 21, 17, 4, 24, 3, 2, 1, 1),       # lanes/group = 6 (not a power of 2)
+                                                (1, 16, 16, 16, 4, 3, 1, 1, 2)])
+def test_dcnv3_against_oracle(N, H, W, G, Gc, k, s, p, d):
+    from oracle.somi_ref import dcnv3 as O
+    from somi_amd.dcnv3 import DCNv3Function
+    g = torch.Generator().manual_seed(N * 100 + Gc)
+    Ho, Wo = O.dcnv3_out_size(H, k, s, p, d), O.dcnv3_out_size(W, k, s, p, d)
+    K = k * k
+    x = torch.randn(N, H, W, G * Gc, generator=g)
+    off = (torch.rand(N, Ho, Wo, G * K * 2, generator=g) - 0.5) * 6
+    m = torch.softmax(torch.randn(N, Ho, Wo, G, K, generator=g), -1).reshape(N, Ho, Wo, G * K)
+    go = torch.randn(N, Ho, Wo, G * Gc, generator=g)
+    want = O.dcnv3_core(x, off, m, k, k, s, s, p, p, d, d, G, Gc, 1.3)
+    wgi, wgo, wgm = O.dcnv3_backward(x, off, m, k, k, s, s, p, p, d, d, G, Gc, 1.3, go, 256)
+    dev = torch.device('cuda:0')
+    xd, od, md = (t.to(dev).requires_grad_(True) for t in (x, off, m))
+    out = DCNv3Function.apply(xd, od, md, k, k, s, s, p, p, d, d, G, Gc, 1.3, 256)
+    rel_close(out, want, what='forward')
+    out.backward(go.to(dev))
+    rel_close(xd.grad, wgi, what='grad_input')
+    rel_close(od.grad, wgo, what='grad_offset')
+    rel_close(md.grad, wgm, what='grad_mask')
+
+
+def test_dcnv3_argument_errors():
+    """Error behaviour of the reference host launcher (dcnv3_cuda.cu:29-53) surfaces as RuntimeError."""
+    from somi_amd.dcnv3 import dcnv3_forward
+    dev = torch.device('cuda:0')
+    x = torch.zeros(3, 8, 8, 16, device=dev)
+    off = torch.zeros(3, 8, 8, 4 * 9 * 2, device=dev)
+    m = torch.zeros(3, 8, 8, 4 * 9, device=dev)
+    with pytest.raises(RuntimeError, match='must divide im2col_step'):
+        dcnv3_forward(x, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 4, 4, 1.0, 2)
+    with pytest.raises(RuntimeError, match='wont match'):
+        dcnv3_forward(x, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 4, 8, 1.0, 256)
+    with pytest.raises(RuntimeError, match='contiguous'):
+        dcnv3_forward(x.transpose(1, 2), off, m, 3, 3, 1, 1, 1, 1, 1, 1, 4, 4, 1.0, 256)
+    with pytest.raises(RuntimeError, match='CUDA tensor'):
+        dcnv3_forward(x.cpu(), off, m, 3, 3, 1, 1, 1, 1, 1, 1, 4, 4, 1.0, 256)
+
+
+def test_dcnv3_module_matches_oracle():
+    from oracle.somi_ref.dcnv3 import DCNv3 as ODCN
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd.dcnv3 import DCNv3
+    ref = fill_state(ODCN(64, 3, group=4, offset_scale=2.0, center_feature_scale=True), 3).eval()
+    mod = DCNv3(64, 3, group=4, offset_scale=2.0, center_feature_scale=True)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.cuda().eval()
+    x = torch.randn(2, 12, 10, 64, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        rel_close(mod(x.cuda()), ref(x), what='DCNv3 module')

@@ -1,0 +1,209 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain torch fp32 on the CPU.
+Tolerance: 1e-3 relative (BASELINE.json north_star); in practice ~1e-5 because the MFMA path is exact fp32."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def rel_close(got, want, rel=1e-3, what=''):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-12
+    assert err <= rel * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+ACTS = {'none': lambda v: v, 'silu': F.silu, 'gelu': F.gelu, 'relu': F.relu, 'sigmoid': torch.sigmoid}
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, act, extras
+    (2, 16, 16, 64, 128, 3, 1, 'silu', {}),
+    (2, 17, 13, 32, 177, 3, 1, 'silu', {}),                 # ragged M and N: 128-wide tile with an N tail
+    (1, 9, 9, 4, 64, 3, 2, 'silu', {}),                     # first-layer shape: Cin 3 padded to 4, K = 36
+    (2, 12, 12, 100, 20, 1, 1, 'none', {}),                 # 1x1, Cout 20 -> 128x32 tile
+    (2, 12, 12, 256, 40, 1, 1, 'none', {}),                 # 128x64 tile
+    (3, 20, 20, 128, 256, 3, 2, 'silu', {}),
+    (2, 40, 40, 128, 128, 3, 1, 'silu', {'residual': True}),
+    (2, 14, 14, 96, 64, 1, 1, 'gelu', {'post': True}),
+    (2, 10, 10, 64, 96, 3, 1, 'silu', {'slices': True}),
+    (2, 10, 10, 64, 64, 3, 1, 'silu', {'modulate': True}),
+    (3, 12, 12, 32, 48, 3, 2, 'silu', {'per_sample': True}),
+    (64, 20, 20, 64, 256, 1, 1, 'silu', {}),                # many rows -> 128x128 tiles across images
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f'{c[3]}-{c[4]}-k{c[5]}s{c[6]}-{"".join(c[8]) or "plain"}')
+def test_conv_igemm(case):
+    from somi_amd import ops
+    from somi_amd.pack import pack_conv_weight
+    B, H, W, Cin, Cout, k, s, act, ex = case
+    g = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout + k + s)
+    d = dev()
+    p = k // 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    if ex.get('per_sample'):
+        w = torch.randn(B, Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        bias = torch.randn(B, Cout, generator=g)
+        want = torch.stack([F.conv2d(x[b:b + 1], w[b], bias[b], s, p)[0] for b in range(B)])
+    else:
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        xin = x
+        if ex.get('modulate'):
+            ca = torch.rand(B, Cin, generator=g) + 0.5
+            sa = torch.rand(B, H, W, generator=g) + 0.5
+            xin = x * ca[:, :, None, None] * sa[:, None]
+        want = F.conv2d(xin, w, bias, s, p)
+    want = ACTS[act](want)
+    kw = {}
+    if ex.get('post'):
+        ps, pt = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+        want = want * ps[None, :, None, None] + pt[None, :, None, None]
+        kw.update(post_scale=ps.to(d), post_shift=pt.to(d))
+    if ex.get('residual'):
+        res = torch.randn(want.shape, generator=g)
+        want = want + res
+        kw.update(residual=nhwc(res).to(d))
+    if ex.get('modulate'):
+        kw.update(a_chan_scale=ca.to(d), a_pix_scale=sa.to(d))
+    xd = nhwc(x).to(d)
+    if ex.get('slices'):                                    # read channels [32,32+Cin) of a wider tensor, write at offset 16
+        wide = torch.randn(B, H, W, Cin + 64, generator=g)
+        wide[..., 32:32 + Cin] = nhwc(x)
+        out = torch.full((B, want.shape[2], want.shape[3], Cout + 48), 7.0, device=d)
+        ops.conv2d_nhwc(wide.to(d), pack_conv_weight(w).to(d), bias.to(d), kh=k, kw=k, stride=s, pad=p, act=act, cin=Cin,
+                        x_coff=32, out=out, cout=Cout, y_coff=16)
+        torch.cuda.synchronize()
+        assert (out[..., :16] == 7.0).all() and (out[..., 16 + Cout:] == 7.0).all()
+        got = out[..., 16:16 + Cout]
+    else:
+        got = ops.conv2d_nhwc(xd, pack_conv_weight(w).to(d), bias.to(d), kh=k, kw=k, stride=s, pad=p, act=act,
+                              per_sample_w=bool(ex.get('per_sample')), **kw)
+    torch.cuda.synchronize()
+    rel_close(got, nhwc(want), what='conv')
+
+
+def test_conv_rejects_bad_arguments():
+    from somi_amd import ops
+    d = dev()
+    x = torch.zeros(1, 4, 4, 6, device=d)                  # Cin 6 is not a multiple of 4
+    w = torch.zeros(8, 9 * 6, device=d)
+    with pytest.raises(RuntimeError, match='multiples of 4'):
+        ops.conv2d_nhwc(x, w, kh=3, kw=3, pad=1)
+    with pytest.raises(RuntimeError, match='GPU tensors'):
+        ops.conv2d_nhwc(torch.zeros(1, 4, 4, 8), torch.zeros(8, 72), kh=3, kw=3, pad=1)
+
+
+def test_image_ingest():
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(1)
+    img = torch.randint(0, 256, (3, 3, 20, 24), generator=g, dtype=torch.uint8)
+    got = ops.image_to_nhwc4(img.to(d))
+    want = torch.zeros(3, 20, 24, 4)
+    want[..., :3] = nhwc(img.float() / 255)               # train.py:249
+    assert torch.equal(got.cpu(), want)
+    f = torch.rand(2, 3, 8, 8, generator=g)
+    got = ops.image_to_nhwc4(f.to(d), scale=1.0)
+    assert torch.equal(got.cpu()[..., :3], nhwc(f)) and (got.cpu()[..., 3] == 0).all()
+
+
+def test_dwconv_sppf_bifpn():
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(2)
+    B, C, H, W = 2, 32, 11, 9
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g)
+    b = torch.randn(C, generator=g)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    want = F.gelu(F.conv2d(x, w, b, 1, 1, groups=C)) * ps[None, :, None, None] + pt[None, :, None, None] + x
+    wp = w[:, 0].permute(1, 2, 0).reshape(9, C).contiguous()
+    got = ops.dwconv3x3(nhwc(x).to(d), wp.to(d), b.to(d), ps.to(d), pt.to(d), residual=nhwc(x).to(d), act='gelu')
+    rel_close(got, nhwc(want), what='dwconv')
+    # SPPF pooling into the concat buffer
+    buf = torch.zeros(B, H, W, 4 * C)
+    buf[..., :C] = nhwc(x)
+    out = ops.sppf_pool_(buf.to(d), C)
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    assert torch.equal(out.cpu(), nhwc(torch.cat([x, y1, y2, y3], 1)))
+    # BiFPN with a folded nearest upsample
+    a = torch.randn(B, C, 4, 6, generator=g)
+    c2 = torch.randn(B, C, 8, 12, generator=g)
+    c3 = torch.randn(B, C, 8, 12, generator=g)
+    wn = [0.3, 0.5, 0.7]
+    want = wn[0] * F.interpolate(a, scale_factor=2, mode='nearest') + wn[1] * c2 + wn[2] * c3
+    got = ops.bifpn([nhwc(a).to(d), nhwc(c2).to(d), nhwc(c3).to(d)], [1, 0, 0], wn)
+    rel_close(got, nhwc(want), rel=1e-6, what='bifpn')
+
+
+def test_attention_pieces():
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, mid = 3, 64, 37, 23, 4
+    x = torch.randn(B, C, H, W, generator=g)
+    wide = torch.randn(B, H, W, C + 32, generator=g)
+    wide[..., 16:16 + C] = nhwc(x)
+    avg, mx = ops.global_pool(wide.to(d), c=C, x_coff=16)
+    rel_close(avg, x.mean((2, 3)), rel=1e-5, what='gap')
+    assert torch.equal(mx.cpu(), x.amax((2, 3)))
+    W1, b1 = torch.randn(mid, C, generator=g) * 0.2, torch.randn(mid, generator=g) * 0.1
+    W2, b2 = torch.randn(C, mid, generator=g) * 0.2, torch.randn(C, generator=g) * 0.1
+    mlp = lambda v: F.linear(F.relu(F.linear(v, W1, b1)), W2, b2)   # noqa: E731
+    want_ca = torch.sigmoid(mlp(x.mean((2, 3))) + mlp(x.amax((2, 3))))
+    ca = ops.attn_mlp(0, avg, mx, W1.to(d), b1.to(d), W2.to(d), b2.to(d))
+    rel_close(ca, want_ca, rel=1e-5, what='channel attention')
+    want_seam = torch.exp(torch.sigmoid(F.linear(F.relu(F.linear(x.mean((2, 3)), W1)), W2)))
+    rel_close(ops.attn_mlp(1, avg, None, W1.to(d), None, W2.to(d), None), want_seam, rel=1e-5, what='seam mlp')
+    xs = x * want_ca[:, :, None, None]
+    stats = ops.chan_stats(wide.to(d), ca, c=C, x_coff=16)
+    want_stats = torch.stack([xs.mean(1), xs.amax(1)], -1)
+    rel_close(stats, want_stats, rel=1e-5, what='chan stats')
+    w7, b7 = torch.randn(1, 2, 7, 7, generator=g) * 0.1, 0.05
+    want_sa = torch.sigmoid(F.conv2d(torch.cat([xs.mean(1, keepdim=True), xs.amax(1, keepdim=True)], 1), w7,
+                                     torch.tensor([b7]), padding=3))[:, 0]
+    sa = ops.spatial_attn(stats, w7[0].permute(1, 2, 0).contiguous().to(d), b7, 7)
+    rel_close(sa, want_sa, rel=1e-5, what='spatial attention')
+    got = ops.scale_channels(nhwc(x).to(d), ca, sa)
+    rel_close(got, nhwc(xs * want_sa[:, None]), rel=1e-5, what='scale')
+
+
+def test_detect_decode():
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(4)
+    B, ny, nx, na, nc = 2, 6, 5, 4, 10
+    box = torch.randn(B, ny, nx, na * 5, generator=g)
+    cls = torch.randn(B, ny, nx, na * nc, generator=g)
+    anchors_px = [4., 6., 12., 8., 7., 14., 20., 12.]
+    stride = 8.0
+    total, row_off = na * ny * nx + 7, 3
+    raw = torch.empty(B, na, ny, nx, nc + 5, device=d)
+    z = torch.zeros(B, total, nc + 5, device=d)
+    ops.detect_decode(box.to(d), cls.to(d), anchors_px, stride, na, nc, raw=raw, z=z, total=total, row_off=row_off)
+    t = torch.cat((box.view(B, ny, nx, na, 5), cls.view(B, ny, nx, na, nc)), -1).permute(0, 3, 1, 2, 4)   # B,na,ny,nx,no
+    assert torch.equal(raw.cpu(), t.contiguous())
+    y = t.sigmoid()
+    yv, xv = torch.meshgrid(torch.arange(ny).float(), torch.arange(nx).float(), indexing='ij')
+    grid = torch.stack((xv, yv), 2) - 0.5
+    xy = (y[..., :2] * 2 + grid) * stride
+    wh = (y[..., 2:4] * 2) ** 2 * torch.tensor(anchors_px).view(1, na, 1, 1, 2)
+    want = torch.cat((xy, wh, y[..., 4:]), -1).reshape(B, -1, nc + 5)
+    rel_close(z[:, row_off:row_off + na * ny * nx], want, rel=1e-5, what='decode')
+    assert (z[:, :row_off] == 0).all()

@@ -1,0 +1,564 @@
+// Bandwidth-bound layer kernels of the SOMI forward (everything that is not a dense conv):
+// image ingest, depthwise 3x3, SPPF pooling, BiFPN fusion (+nearest upsample), global pooling,
+// CBAM / SEAM attention heads, ODConv per-sample weight synthesis, detection decode.
+// All NHWC fp32, 16 B per lane along channels, grid-stride over (pixel, channel-quad) items.
+#include "common.h"
+
+namespace somi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int ew_grid(long items, int block = 256) {
+    long g = (items + block - 1) / block;
+    const long cap = 256L * 8;   // 8 workgroups per CU, grid-stride beyond that
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------------ image ingest
+template <typename T, bool DIV>   // DIV: v / scale (bit-exact `imgs.float()/255`, train.py:249); else v * scale
+__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const T *__restrict__ img, float *__restrict__ y, int B,
+                                                             int C, int H, int W, float scale) {
+    const long npix = (long)B * H * W;
+    const long HW = (long)H * W;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const long b = p / HW, hw = p % HW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const float t = (float)img[(b * C + c) * HW + hw];
+            v[c] = DIV ? t / scale : t * scale;
+        }
+        *reinterpret_cast<f32x4 *>(y + p * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise 3x3
+// one lane = one pixel x 4 channels; weights [9][C]; neighbours come through L1/L2 (3x3 reuse inside a workgroup row)
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, const float *__restrict__ ps,
+                                                        const float *__restrict__ pt, const float *__restrict__ res,
+                                                        float *__restrict__ y, int B, int H, int W, int C, int act) {
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        f32x4 acc = bias ? *reinterpret_cast<const f32x4 *>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = hv + r - 1;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int wi = wv + q - 1;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + ((b * H + hi) * W + wi) * C + c);
+                const f32x4 wq = *reinterpret_cast<const f32x4 *>(w + (r * 3 + q) * C + c);
+                acc += xv * wq;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = apply_act_rt(acc[e], act);
+        if (ps) acc = acc * *reinterpret_cast<const f32x4 *>(ps + c) + *reinterpret_cast<const f32x4 *>(pt + c);
+        if (res) acc += *reinterpret_cast<const f32x4 *>(res + pix * C + c);
+        *reinterpret_cast<f32x4 *>(y + pix * C + c) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SPPF pooling
+// chained 5x5/s1/p2 max-pools == max over 5x5, 9x9, 13x13 windows clipped to the image (-inf padding)
+__global__ __launch_bounds__(256) void sppf_pool_kernel(float *__restrict__ buf, int B, int H, int W, int C, int cs,
+                                                        int x_coff) {
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        const float ninf = -__builtin_huge_valf();
+        f32x4 m5 = {ninf, ninf, ninf, ninf}, m9 = m5, m13 = m5;
+        for (int dh = -6; dh <= 6; ++dh) {
+            const int hi = hv + dh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            const int ah = dh < 0 ? -dh : dh;
+            for (int dw = -6; dw <= 6; ++dw) {
+                const int wi = wv + dw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const int aw = dw < 0 ? -dw : dw;
+                const int rad = ah > aw ? ah : aw;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + ((b * H + hi) * W + wi) * cs + x_coff + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m13[e] = fmaxf(m13[e], v[e]);
+                    if (rad <= 4) m9[e] = fmaxf(m9[e], v[e]);
+                    if (rad <= 2) m5[e] = fmaxf(m5[e], v[e]);
+                }
+            }
+        }
+        float *o = buf + pix * cs + x_coff + c;
+        *reinterpret_cast<f32x4 *>(o + C) = m5;
+        *reinterpret_cast<f32x4 *>(o + 2 * C) = m9;
+        *reinterpret_cast<f32x4 *>(o + 3 * C) = m13;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BiFPN (+upsample)
+struct BifpnArgs {
+    const float *src[3];
+    int up[3];
+    float wn[3];
+    int n_in;
+};
+__global__ __launch_bounds__(256) void bifpn_kernel(BifpnArgs a, float *__restrict__ y, int B, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        // stack-then-sum of the reference == left-to-right fp32 sum starting from 0
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i >= a.n_in) break;
+            const int u = a.up[i];
+            const long sp = (b * (H >> u) + (hv >> u)) * (W >> u) + (wv >> u);
+            acc += a.wn[i] * *reinterpret_cast<const f32x4 *>(a.src[i] + sp * C + c);
+        }
+        *reinterpret_cast<f32x4 *>(y + pix * C + c) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ global pooling
+// stage 1: grid (nchunk, B): each workgroup reduces a chunk of pixels for all channels (lane = channel quad,
+// coalesced rows); stage 2 folds the chunks.  Deterministic (no atomics).
+constexpr int POOL_CHUNK = 256;   // pixels per chunk
+__global__ __launch_bounds__(256) void global_pool_stage1(const float *__restrict__ x, int x_cs, int x_coff, int HW, int C,
+                                                          float *__restrict__ part_sum, float *__restrict__ part_max,
+                                                          int nchunk) {
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int C4 = C >> 2;
+    const int p0 = chunk * POOL_CHUNK, p1 = min(p0 + POOL_CHUNK, HW);
+    // threads: cq = tid % C4g lanes over channel quads, rows strided by 256 / C4g
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;                     // >= 1
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        const float ninf = -__builtin_huge_valf();
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {ninf, ninf, ninf, ninf};
+        if (rr < rows_par) {
+            for (int p = p0 + rr; p < p1; p += rows_par) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)b * HW + p) * x_cs + x_coff + (cq0 + cq) * 4);
+                s += v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        __shared__ f32x4 ls[256], lm[256];
+        ls[threadIdx.x] = s;
+        lm[threadIdx.x] = m;
+        __syncthreads();
+        if (threadIdx.x < ncq) {
+            for (int r2 = 1; r2 < rows_par; ++r2) {
+                s += ls[r2 * ncq + cq];
+                const f32x4 o = lm[r2 * ncq + cq];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], o[e]);
+            }
+            const long o = ((long)b * nchunk + chunk) * C + (cq0 + cq) * 4;
+            *reinterpret_cast<f32x4 *>(part_sum + o) = s;
+            *reinterpret_cast<f32x4 *>(part_max + o) = m;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void global_pool_stage2(const float *__restrict__ part_sum, const float *__restrict__ part_max,
+                                                          int nchunk, int C, int B, float inv_hw, float *__restrict__ out_avg,
+                                                          float *__restrict__ out_max) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float s = 0.f, m = -__builtin_huge_valf();
+    for (int k = 0; k < nchunk; ++k) {
+        s += part_sum[((long)b * nchunk + k) * C + c];
+        m = fmaxf(m, part_max[((long)b * nchunk + k) * C + c]);
+    }
+    out_avg[i] = s * inv_hw;
+    if (out_max) out_max[i] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ attention MLPs
+// one workgroup per sample; C <= 1024, mid <= 64
+__global__ __launch_bounds__(256) void attn_mlp_kernel(int mode, const float *__restrict__ avg, const float *__restrict__ mx,
+                                                       const float *__restrict__ W1, const float *__restrict__ b1,
+                                                       const float *__restrict__ W2, const float *__restrict__ b2,
+                                                       float *__restrict__ out, int C, int mid) {
+    __shared__ float h_avg[64], h_max[64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *va = avg + (long)b * C;
+    const float *vm = mx ? mx + (long)b * C : nullptr;
+    for (int j = wave; j < mid; j += 4) {          // one wave per hidden unit: dot over C
+        float sa = 0.f, sm = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float w = W1[(long)j * C + c];
+            sa += w * va[c];
+            if (vm) sm += w * vm[c];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            sa += __shfl_down(sa, o);
+            sm += __shfl_down(sm, o);
+        }
+        if (lane == 0) {
+            const float bb = b1 ? b1[j] : 0.f;
+            h_avg[j] = fmaxf(sa + bb, 0.f);
+            h_max[j] = fmaxf(sm + bb, 0.f);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float oa = b2 ? b2[c] : 0.f, om = oa;
+        for (int j = 0; j < mid; ++j) {
+            const float w = W2[(long)c * mid + j];
+            oa += w * h_avg[j];
+            om += w * h_max[j];
+        }
+        float r;
+        if (mode == 0) r = 1.0f / (1.0f + expf(-(oa + om)));
+        else r = expf(1.0f / (1.0f + expf(-oa)));
+        out[(long)b * C + c] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ CBAM spatial stats
+// one wave per pixel: lanes stride the channels (coalesced), wave-reduce mean and max of x*ca
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float *__restrict__ x, int x_cs, int x_coff,
+                                                         const float *__restrict__ ca, float *__restrict__ stats, int B,
+                                                         int HW, int C) {
+    const int lane = threadIdx.x & 63;
+    const long wave_id = (blockIdx.x * 256L + threadIdx.x) >> 6, nwave = (long)gridDim.x * 4;
+    const long npix = (long)B * HW;
+    const float inv_c = 1.0f / (float)C;
+    for (long p = wave_id; p < npix; p += nwave) {
+        const long b = p / HW;
+        const float *xr = x + p * x_cs + x_coff;
+        const float *cr = ca + b * C;
+        float s = 0.f, m = -__builtin_huge_valf();
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c) * *reinterpret_cast<const f32x4 *>(cr + c);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            m = fmaxf(fmaxf(fmaxf(m, v[0]), fmaxf(v[1], v[2])), v[3]);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            m = fmaxf(m, __shfl_xor(m, o));
+        }
+        if (lane == 0) {
+            stats[p * 2] = s * inv_c;
+            stats[p * 2 + 1] = m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void spatial_attn_kernel(const float *__restrict__ stats, const float *__restrict__ w,
+                                                           float bias, float *__restrict__ sa, int B, int H, int W, int k) {
+    const long npix = (long)B * H * W;
+    const int pad = k >> 1;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const int wv = (int)(p % W), hv = (int)((p / W) % H);
+        const long b = p / ((long)W * H);
+        float acc = bias;
+        for (int r = 0; r < k; ++r) {
+            const int hi = hv + r - pad;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wi = wv + q - pad;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float2 st = *reinterpret_cast<const float2 *>(stats + ((b * H + hi) * W + wi) * 2);
+                acc += st.x * w[(r * k + q) * 2] + st.y * w[(r * k + q) * 2 + 1];
+            }
+        }
+        sa[p] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float *__restrict__ x, const float *__restrict__ s,
+                                                             const float *__restrict__ pix, float *__restrict__ y, int B,
+                                                             int HW, int C) {
+    const int C4 = C >> 2;
+    const long items = (long)B * HW * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long p = it / C4, b = p / HW;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * C + c);
+        if (s) v *= *reinterpret_cast<const f32x4 *>(s + b * C + c);
+        if (pix) v *= pix[p];
+        *reinterpret_cast<f32x4 *>(y + p * C + c) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ODConv
+// stage A: one workgroup per sample computes z and the four attention vectors into the workspace
+__global__ __launch_bounds__(256) void odconv_attn_kernel(const float *__restrict__ gap, const float *__restrict__ fc_w,
+                                                          const float *__restrict__ fc_b, const float *__restrict__ Wf,
+                                                          const float *__restrict__ bf, const float *__restrict__ Ws,
+                                                          const float *__restrict__ bs, const float *__restrict__ Wc,
+                                                          const float *__restrict__ bc, const float *__restrict__ Ww,
+                                                          const float *__restrict__ bw, float *__restrict__ ws, int Cin,
+                                                          int Cout, int kk, int K, int hid) {
+    __shared__ float z[64];
+    __shared__ float lw[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *g = gap + (long)b * Cin;
+    for (int j = wave; j < hid; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < Cin; c += 64) s += fc_w[(long)j * Cin + c] * g[c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) z[j] = fmaxf(s + (fc_b ? fc_b[j] : 0.f), 0.f);
+    }
+    __syncthreads();
+    float *o = ws + (long)b * (Cout + kk + Cin + K);
+    auto head = [&](const float *Wm, const float *bm, int n, float *dst, bool sig) {
+        for (int i = tid; i < n; i += 256) {
+            float s = bm[i];
+            for (int j = 0; j < hid; ++j) s += Wm[(long)i * hid + j] * z[j];
+            dst[i] = sig ? 1.0f / (1.0f + expf(-s)) : s;
+        }
+    };
+    head(Wf, bf, Cout, o, true);
+    head(Ws, bs, kk, o + Cout, true);
+    head(Wc, bc, Cin, o + Cout + kk, true);
+    if (tid < K) {
+        float s = bw[tid];
+        for (int j = 0; j < hid; ++j) s += Ww[(long)tid * hid + j] * z[j];
+        lw[tid] = s;
+    }
+    __syncthreads();
+    if (tid < K) {                       // softmax over K (K <= 16)
+        float mx = lw[0];
+        for (int i = 1; i < K; ++i) mx = fmaxf(mx, lw[i]);
+        float den = 0.f;
+        for (int i = 0; i < K; ++i) den += expf(lw[i] - mx);
+        o[Cout + kk + Cin + tid] = expf(lw[tid] - mx) / den;
+    }
+}
+// stage B: wout[b][n][t][c]; one thread = 4 consecutive c; BN of the following layer folded in
+__global__ __launch_bounds__(256) void odconv_synth_kernel(const float *__restrict__ ws, const float *__restrict__ Wk,
+                                                           const float *__restrict__ biask, const float *__restrict__ bn_s,
+                                                           const float *__restrict__ bn_t, float *__restrict__ wout,
+                                                           float *__restrict__ bout, int B, int Cin, int Cin_pad, int Cout,
+                                                           int kk, int K) {
+    const int C4 = Cin_pad >> 2;
+    const long per_b = (long)Cout * kk * C4;
+    const long items = (long)B * per_b;
+    const long set = (long)Cout * kk * Cin_pad;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const long b = it / per_b, rem = it % per_b;
+        const int c = (int)(rem % C4) * 4;
+        const int t = (int)((rem / C4) % kk);
+        const int n = (int)(rem / ((long)C4 * kk));
+        const float *at = ws + b * (Cout + kk + Cin + K);
+        const float *aw = at + Cout + kk + Cin;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the reference sums attn*W over K with the full product attn = a_f*a_s*a_c*a_w per term (common.py:4570-4580)
+        const float fs = at[n] * at[Cout + t];
+        f32x4 ac = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ac[e] = (c + e < Cin) ? at[Cout + kk + c + e] : 0.f;
+        for (int q = 0; q < K; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wk + q * set + ((long)n * kk + t) * Cin_pad + c);
+            acc += ((fs * ac) * aw[q]) * wv;
+        }
+        const float sc = bn_s ? bn_s[n] : 1.f;
+        *reinterpret_cast<f32x4 *>(wout + b * set + ((long)n * kk + t) * Cin_pad + c) = acc * sc;
+        if (t == 0 && c == 0) {
+            float bv = 0.f;
+            if (biask)
+                for (int q = 0; q < K; ++q) bv += aw[q] * biask[q * Cout + n];
+            bout[b * Cout + n] = bn_s ? bv * sc + bn_t[n] : bv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ detect decode
+struct DecodeArgs {
+    float anchor_px[16];   // na*2, anchors * stride
+};
+__global__ __launch_bounds__(256) void detect_decode_kernel(const float *__restrict__ box, int box_cs,
+                                                            const float *__restrict__ cls, int cls_cs, DecodeArgs da,
+                                                            float stride, float *__restrict__ raw, float *__restrict__ z, int B,
+                                                            int ny, int nx, int na, int nc, int total, int row_off) {
+    const int no = nc + 5;
+    const long items = (long)B * na * ny * nx * no;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int o = (int)(it % no);
+        long r = it / no;
+        const int xg = (int)(r % nx);
+        r /= nx;
+        const int yg = (int)(r % ny);
+        r /= ny;
+        const int an = (int)(r % na);
+        const long b = r / na;
+        const long pix = (b * ny + yg) * nx + xg;
+        const float v = o < 5 ? box[pix * box_cs + an * 5 + o] : cls[pix * cls_cs + an * nc + (o - 5)];
+        if (raw) raw[it] = v;
+        if (z) {
+            const float s = 1.0f / (1.0f + expf(-v));
+            float out = s;
+            if (o == 0) out = (s * 2.0f + ((float)xg - 0.5f)) * stride;
+            else if (o == 1) out = (s * 2.0f + ((float)yg - 0.5f)) * stride;
+            else if (o == 2) out = (s * 2.0f) * (s * 2.0f) * da.anchor_px[an * 2];
+            else if (o == 3) out = (s * 2.0f) * (s * 2.0f) * da.anchor_px[an * 2 + 1];
+            const long row = row_off + ((long)an * ny + yg) * nx + xg;
+            z[(b * total + row) * no + o] = out;
+        }
+    }
+}
+
+}  // namespace somi
+
+using namespace somi;
+
+extern "C" int somi_image_u8_to_nhwc4(const uint8_t *img, float *y, int B, int C, int H, int W, somi_stream_t stream) {
+    SOMI_REQUIRE(img && y && B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4, SOMI_EINVAL, "image ingest: bad arguments");
+    SOMI_REQUIRE(aligned16(y), SOMI_EINVAL, "image ingest: output must be 16 B aligned");
+    hipLaunchKernelGGL((image_to_nhwc4_kernel<uint8_t, true>), dim3(ew_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       img, y, B, C, H, W, 255.0f);
+    return launch_status("somi_image_u8_to_nhwc4");
+}
+
+extern "C" int somi_image_f32_to_nhwc4(const float *img, float *y, int B, int C, int H, int W, float scale,
+                                       somi_stream_t stream) {
+    SOMI_REQUIRE(img && y && B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4, SOMI_EINVAL, "image ingest: bad arguments");
+    SOMI_REQUIRE(aligned16(y), SOMI_EINVAL, "image ingest: output must be 16 B aligned");
+    hipLaunchKernelGGL((image_to_nhwc4_kernel<float, false>), dim3(ew_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       img, y, B, C, H, W, scale);
+    return launch_status("somi_image_f32_to_nhwc4");
+}
+
+extern "C" int somi_dwconv3x3_nhwc_f32(const float *x, const float *w, const float *bias, const float *post_scale,
+                                       const float *post_shift, const float *residual, float *y, int B, int H, int W, int C,
+                                       int act, somi_stream_t stream) {
+    SOMI_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, SOMI_EINVAL, "dwconv: bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(y), SOMI_EINVAL, "dwconv: C %% 4 and 16 B alignment");
+    SOMI_REQUIRE(!post_scale == !post_shift, SOMI_EINVAL, "dwconv: post_scale and post_shift go together");
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, post_scale, post_shift, residual, y, B, H, W, C, act);
+    return launch_status("somi_dwconv3x3_nhwc_f32");
+}
+
+extern "C" int somi_sppf_pool_nhwc_f32(float *buf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream) {
+    SOMI_REQUIRE(buf && B > 0 && H > 0 && W > 0 && C > 0, SOMI_EINVAL, "sppf: bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && cs % 4 == 0 && x_coff % 4 == 0 && x_coff + 4 * C <= cs && aligned16(buf), SOMI_EINVAL,
+                 "sppf: needs C,cs,x_coff %% 4 == 0 and room for 4*C channels");
+    hipLaunchKernelGGL(sppf_pool_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, buf, B,
+                       H, W, C, cs, x_coff);
+    return launch_status("somi_sppf_pool_nhwc_f32");
+}
+
+extern "C" int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const float *wn_host, int n_in, float *y,
+                                   int B, int H, int W, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(src_host && up_host && wn_host && y && (n_in == 2 || n_in == 3), SOMI_EINVAL, "bifpn: bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && aligned16(y), SOMI_EINVAL, "bifpn: C %% 4 and alignment");
+    BifpnArgs a;
+    for (int i = 0; i < 3; ++i) {
+        a.src[i] = i < n_in ? src_host[i] : nullptr;
+        a.up[i] = i < n_in ? up_host[i] : 0;
+        a.wn[i] = i < n_in ? wn_host[i] : 0.f;
+        if (i < n_in) {
+            SOMI_REQUIRE(a.src[i] && aligned16(a.src[i]) && (a.up[i] == 0 || a.up[i] == 1), SOMI_EINVAL, "bifpn: bad source %d", i);
+            SOMI_REQUIRE(a.up[i] == 0 || (H % 2 == 0 && W % 2 == 0), SOMI_EINVAL, "bifpn: upsampled source needs even H, W");
+        }
+    }
+    a.n_in = n_in;
+    hipLaunchKernelGGL(bifpn_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, y, B, H, W, C);
+    return launch_status("somi_bifpn_nhwc_f32");
+}
+
+extern "C" int somi_pool_nchunk(int HW) { return (HW + POOL_CHUNK - 1) / POOL_CHUNK; }
+
+extern "C" int somi_global_pool_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, float *out_avg,
+                                         float *out_max, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(x && out_avg && workspace && B > 0 && HW > 0 && C > 0, SOMI_EINVAL, "global pool: bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && x_cs % 4 == 0 && x_coff % 4 == 0 && x_coff + C <= x_cs && aligned16(x) && aligned16(workspace),
+                 SOMI_EINVAL, "global pool: C,x_cs,x_coff %% 4 and alignment");
+    const int nchunk = somi_pool_nchunk(HW);
+    float *ps = workspace, *pm = workspace + (size_t)B * nchunk * C;
+    hipLaunchKernelGGL(global_pool_stage1, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, HW, C, ps, pm, nchunk);
+    hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, ps, pm, nchunk, C, B,
+                       1.0f / (float)HW, out_avg, out_max);
+    return launch_status("somi_global_pool_nhwc_f32");
+}
+
+extern "C" int somi_attn_mlp_f32(int mode, const float *avg, const float *mx, const float *W1, const float *b1,
+                                 const float *W2, const float *b2, float *out, int B, int C, int mid, somi_stream_t stream) {
+    SOMI_REQUIRE(avg && W1 && W2 && out && B > 0 && C > 0 && mid > 0 && mid <= 64, SOMI_EINVAL, "attn mlp: bad arguments (mid <= 64)");
+    SOMI_REQUIRE(mode == 0 || mode == 1, SOMI_EINVAL, "attn mlp: mode must be 0 or 1");
+    SOMI_REQUIRE(mode == 1 || mx, SOMI_EINVAL, "attn mlp: mode 0 needs the max-pooled vector");
+    hipLaunchKernelGGL(attn_mlp_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mode, avg, mode == 0 ? mx : nullptr, W1, b1,
+                       W2, b2, out, C, mid);
+    return launch_status("somi_attn_mlp_f32");
+}
+
+extern "C" int somi_chan_stats_nhwc_f32(const float *x, int x_cs, int x_coff, const float *ca, float *stats, int B, int HW,
+                                        int C, somi_stream_t stream) {
+    SOMI_REQUIRE(x && ca && stats && B > 0 && HW > 0 && C > 0, SOMI_EINVAL, "chan stats: bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && x_cs % 4 == 0 && x_coff % 4 == 0 && aligned16(x) && aligned16(ca), SOMI_EINVAL,
+                 "chan stats: C,x_cs,x_coff %% 4 and alignment");
+    hipLaunchKernelGGL(chan_stats_kernel, dim3(ew_grid((long)B * HW * 64)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, ca,
+                       stats, B, HW, C);
+    return launch_status("somi_chan_stats_nhwc_f32");
+}
+
+extern "C" int somi_spatial_attn_f32(const float *stats, const float *w, float bias, float *sa, int B, int H, int W, int k,
+                                     somi_stream_t stream) {
+    SOMI_REQUIRE(stats && w && sa && B > 0 && H > 0 && W > 0 && (k == 3 || k == 5 || k == 7), SOMI_EINVAL,
+                 "spatial attn: bad arguments (k in 3,5,7)");
+    hipLaunchKernelGGL(spatial_attn_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, stats, w, bias, sa, B,
+                       H, W, k);
+    return launch_status("somi_spatial_attn_f32");
+}
+
+extern "C" int somi_scale_channels_nhwc_f32(const float *x, const float *s, const float *pix, float *y, int B, int HW, int C,
+                                            somi_stream_t stream) {
+    SOMI_REQUIRE(x && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && aligned16(x) && aligned16(y), SOMI_EINVAL,
+                 "scale channels: bad arguments");
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(ew_grid((long)B * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, s, pix, y,
+                       B, HW, C);
+    return launch_status("somi_scale_channels_nhwc_f32");
+}
+
+extern "C" int somi_odconv_weights_f32(const float *gap, const float *fc_w, const float *fc_b, const float *Wf, const float *bf,
+                                       const float *Ws, const float *bs, const float *Wc, const float *bc, const float *Ww,
+                                       const float *bw, const float *Wk, const float *biask, const float *bn_scale,
+                                       const float *bn_shift, float *wout, float *bout, float *workspace, int B, int Cin,
+                                       int Cin_pad, int Cout, int kk, int K, int hid, somi_stream_t stream) {
+    SOMI_REQUIRE(gap && fc_w && Wf && bf && Ws && bs && Wc && bc && Ww && bw && Wk && wout && bout && workspace, SOMI_EINVAL,
+                 "odconv: null tensor");
+    SOMI_REQUIRE(B > 0 && Cin > 0 && Cin_pad >= Cin && Cin_pad % 4 == 0 && Cout > 0 && kk > 0 && K > 0 && K <= 16 && hid > 0 && hid <= 64,
+                 SOMI_EINVAL, "odconv: bad sizes (K <= 16, hid <= 64, Cin_pad %% 4 == 0)");
+    SOMI_REQUIRE(!bn_scale == !bn_shift, SOMI_EINVAL, "odconv: bn_scale and bn_shift go together");
+    SOMI_REQUIRE(aligned16(Wk) && aligned16(wout), SOMI_EINVAL, "odconv: Wk / wout must be 16 B aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(odconv_attn_kernel, dim3(B), dim3(256), 0, s, gap, fc_w, fc_b, Wf, bf, Ws, bs, Wc, bc, Ww, bw, workspace, Cin,
+                       Cout, kk, K, hid);
+    hipLaunchKernelGGL(odconv_synth_kernel, dim3(ew_grid((long)B * Cout * kk * (Cin_pad / 4))), dim3(256), 0, s, workspace, Wk, biask,
+                       bn_scale, bn_shift, wout, bout, B, Cin, Cin_pad, Cout, kk, K);
+    return launch_status("somi_odconv_weights_f32");
+}
+
+extern "C" int somi_detect_decode_f32(const float *box, int box_cs, const float *cls, int cls_cs, const float *anchors_px_host,
+                                      float stride, float *raw, float *z, int B, int ny, int nx, int na, int nc, int total,
+                                      int row_off, somi_stream_t stream) {
+    SOMI_REQUIRE(box && cls && anchors_px_host && (raw || z), SOMI_EINVAL, "detect decode: null tensor");
+    SOMI_REQUIRE(B > 0 && ny > 0 && nx > 0 && na > 0 && na <= 8 && nc > 0 && box_cs >= na * 5 && cls_cs >= na * nc, SOMI_EINVAL,
+                 "detect decode: bad sizes (na <= 8)");
+    SOMI_REQUIRE(!z || (row_off >= 0 && row_off + na * ny * nx <= total), SOMI_EINVAL, "detect decode: rows out of range");
+    DecodeArgs da;
+    for (int i = 0; i < 16; ++i) da.anchor_px[i] = i < na * 2 ? anchors_px_host[i] : 0.f;
+    hipLaunchKernelGGL(detect_decode_kernel, dim3(ew_grid((long)B * na * ny * nx * (nc + 5))), dim3(256), 0, (hipStream_t)stream, box,
+                       box_cs, cls, cls_cs, da, stride, raw, z, B, ny, nx, na, nc, total, row_off);
+    return launch_status("somi_detect_decode_f32");
+}

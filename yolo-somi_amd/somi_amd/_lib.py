@@ -1,0 +1,88 @@
+"""ctypes binding of libsomi_hip.so (the C ABI declared in include/somi_hip.h).
+
+The library is the product; this module only loads it, declares argument types and turns return
+codes into exceptions.  There is no fallback: if the shared library is missing or an entry point
+fails, a RuntimeError is raised (a reference-side `AT_ASSERTM` surfaces as RuntimeError too,
+models/ops_dcnv3/src/cuda/dcnv3_cuda.cu:29-53).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')
+
+c_f32p = C.c_void_p      # device pointers travel as integers
+c_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """struct somi_conv_desc (include/somi_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ('x', 'w', 'bias', 'post_scale', 'post_shift', 'residual', 'a_chan_scale',
+                                          'a_pix_scale', 'y')] + \
+               [(n, C.c_int32) for n in ('B', 'H', 'W', 'Cin', 'x_cs', 'x_coff', 'Ho', 'Wo', 'Cout', 'y_cs', 'y_coff',
+                                         'kh', 'kw', 'stride', 'pad', 'dil', 'res_cs', 'res_coff', 'act', 'per_sample_w')]
+
+
+class LossDesc(C.Structure):
+    """struct somi_loss_desc (include/somi_hip.h)."""
+    _fields_ = [('p', C.c_void_p * 4), ('grad', C.c_void_p * 4), ('ny', C.c_int32 * 4), ('nx', C.c_int32 * 4),
+                ('nl', C.c_int32), ('na', C.c_int32), ('nc', C.c_int32), ('B', C.c_int32), ('nt', C.c_int32),
+                ('targets', C.c_void_p), ('anchors', C.c_void_p), ('balance', C.c_float * 4),
+                ('box_gain', C.c_float), ('obj_gain', C.c_float), ('cls_gain', C.c_float), ('cls_pw', C.c_float),
+                ('obj_pw', C.c_float), ('anchor_t', C.c_float), ('cp', C.c_float), ('cn', C.c_float), ('gr', C.c_float)]
+
+
+I, F, P, S, Z, U64 = C.c_int, C.c_float, C.c_void_p, c_stream, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes); every symbol include/somi_hip.h declares
+SIGNATURES = {
+    'somi_abi_version': (I, []),
+    'somi_last_error': (C.c_char_p, []),
+    'somi_conv2d_nhwc_f32': (I, [C.POINTER(ConvDesc), S]),
+    'somi_dcnv3_forward_f32': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
+    'somi_dcnv3_backward_f32': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, S]),
+    'somi_image_u8_to_nhwc4': (I, [P, P, I, I, I, I, S]),
+    'somi_image_f32_to_nhwc4': (I, [P, P, I, I, I, I, F, S]),
+    'somi_dwconv3x3_nhwc_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, I, S]),
+    'somi_sppf_pool_nhwc_f32': (I, [P, I, I, I, I, I, I, S]),
+    'somi_bifpn_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float), I, P, I, I, I, I, S]),
+    'somi_pool_nchunk': (I, [I]),
+    'somi_global_pool_nhwc_f32': (I, [P, I, I, I, I, I, P, P, P, S]),
+    'somi_attn_mlp_f32': (I, [I, P, P, P, P, P, P, P, I, I, I, S]),
+    'somi_chan_stats_nhwc_f32': (I, [P, I, I, P, P, I, I, I, S]),
+    'somi_spatial_attn_f32': (I, [P, P, F, P, I, I, I, I, S]),
+    'somi_scale_channels_nhwc_f32': (I, [P, P, P, P, I, I, I, S]),
+    'somi_odconv_weights_f32': (I, [P] * 18 + [I] * 7 + [S]),
+    'somi_detect_decode_f32': (I, [P, I, P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
+    'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
+    'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
+    'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),
+    'somi_yolo_loss_f32': (I, [C.POINTER(LossDesc), P, P, Z, S]),
+    'somi_wbf_workspace_bytes': (Z, [I]),
+    'somi_wbf_f32': (I, [P, P, P, P, I, I, C.POINTER(C.c_float), F, F, P, P, P, P, P, Z, S]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                               f'(or `make -C yolo-somi_amd/csrc`). There is no CPU fallback.')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        if L.somi_abi_version() != 1:
+            raise RuntimeError('libsomi_hip.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().somi_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what or "somi"} failed (code {rc}): {msg}')

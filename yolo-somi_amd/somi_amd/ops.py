@@ -1,0 +1,177 @@
+"""Torch-tensor wrappers over the C ABI (device pointers + current HIP stream).
+
+PyTorch is plumbing here: it owns the HBM allocations and the stream; all arithmetic happens in
+libsomi_hip.so.  Tensors must live on the GPU; anything else raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4}
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('somi_amd ops need GPU tensors (no CPU fallback)')
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name='tensor'):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f'{name} tensor has to be contiguous float32')
+    return t
+
+
+def conv_out_size(size, k, s, p, d=1):
+    return (size + 2 * p - (d * (k - 1) + 1)) // s + 1
+
+
+def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', cin=None, x_coff=0, out=None,
+                cout=None, y_coff=0, post_scale=None, post_shift=None, residual=None, res_coff=0, a_chan_scale=None,
+                a_pix_scale=None, per_sample_w=False):
+    """x (B,H,W,x_cs) NHWC; w packed [n_sets][Cout][kh*kw*Cin]; returns / fills out (B,Ho,Wo,y_cs)."""
+    B, H, W, x_cs = x.shape
+    cin = x_cs - x_coff if cin is None else cin
+    cout = w.shape[-2] if cout is None else cout
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, cout, device=x.device, dtype=torch.float32)
+    d = ConvDesc()
+    d.x, d.w, d.bias, d.y = _ptr(_f32c(x, 'input')), _ptr(_f32c(w, 'weight')), _ptr(bias), _ptr(_f32c(out, 'output'))
+    d.post_scale, d.post_shift, d.residual = _ptr(post_scale), _ptr(post_shift), _ptr(residual)
+    d.a_chan_scale, d.a_pix_scale = _ptr(a_chan_scale), _ptr(a_pix_scale)
+    d.B, d.H, d.W, d.Cin, d.x_cs, d.x_coff = B, H, W, cin, x_cs, x_coff
+    d.Ho, d.Wo, d.Cout, d.y_cs, d.y_coff = Ho, Wo, cout, out.shape[3], y_coff
+    d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
+    d.res_cs, d.res_coff = (residual.shape[3] if residual is not None else 0), res_coff
+    d.act, d.per_sample_w = ACT[act], int(per_sample_w)
+    if w.numel() != (B if per_sample_w else 1) * cout * kh * kw * cin:
+        raise RuntimeError(f'weight has {w.numel()} elements, expected {(B if per_sample_w else 1) * cout * kh * kw * cin}')
+    check(_lib.lib().somi_conv2d_nhwc_f32(C.byref(d), _stream()), 'conv2d_nhwc')
+    return out
+
+
+def dcnv3_forward_raw(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels, offset_scale,
+                      im2col_step):
+    N, H, W, _ = input.shape
+    Ho, Wo = conv_out_size(H, kh, sh, ph, dh), conv_out_size(W, kw, sw, pw, dw)
+    out = torch.empty(N, Ho, Wo, group * group_channels, device=input.device, dtype=torch.float32)
+    check(_lib.lib().somi_dcnv3_forward_f32(_ptr(input), _ptr(offset), _ptr(mask), _ptr(out), N, H, W, group,
+                                            group_channels, kh, kw, sh, sw, ph, pw, dh, dw, float(offset_scale),
+                                            int(im2col_step), _stream()), 'dcnv3_forward')
+    return out
+
+
+def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels,
+                       offset_scale, im2col_step):
+    N, H, W, _ = input.shape
+    gi = torch.zeros_like(input)
+    go = torch.empty_like(offset)
+    gm = torch.empty_like(mask)
+    check(_lib.lib().somi_dcnv3_backward_f32(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go),
+                                             _ptr(gm), N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw,
+                                             float(offset_scale), int(im2col_step), _stream()), 'dcnv3_backward')
+    return gi, go, gm
+
+
+def image_to_nhwc4(img, scale=1.0 / 255.0):
+    """(B,C<=4,H,W) uint8 or float32 NCHW -> (B,H,W,4) float32 (train.py:249 `/255`)."""
+    B, Cc, H, W = img.shape
+    if not img.is_contiguous():
+        raise RuntimeError('image batch has to be contiguous NCHW')
+    y = torch.empty(B, H, W, 4, device=img.device, dtype=torch.float32)
+    L = _lib.lib()
+    if img.dtype == torch.uint8:
+        if abs(scale - 1.0 / 255.0) > 1e-12:
+            raise RuntimeError('uint8 images are always scaled by 1/255')
+        check(L.somi_image_u8_to_nhwc4(_ptr(img), _ptr(y), B, Cc, H, W, _stream()), 'image_u8_to_nhwc4')
+    elif img.dtype == torch.float32:
+        check(L.somi_image_f32_to_nhwc4(_ptr(img), _ptr(y), B, Cc, H, W, float(scale), _stream()), 'image_f32_to_nhwc4')
+    else:
+        raise RuntimeError('images must be uint8 or float32')
+    return y
+
+
+def dwconv3x3(x, w, bias=None, post_scale=None, post_shift=None, residual=None, act='none', out=None):
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().somi_dwconv3x3_nhwc_f32(_ptr(_f32c(x)), _ptr(w), _ptr(bias), _ptr(post_scale), _ptr(post_shift),
+                                             _ptr(residual), _ptr(out), B, H, W, Cc, ACT[act], _stream()), 'dwconv3x3')
+    return out
+
+
+def sppf_pool_(buf, c, x_coff=0):
+    B, H, W, cs = buf.shape
+    check(_lib.lib().somi_sppf_pool_nhwc_f32(_ptr(_f32c(buf)), B, H, W, c, cs, x_coff, _stream()), 'sppf_pool')
+    return buf
+
+
+def bifpn(srcs, ups, wn, out=None):
+    n = len(srcs)
+    B, H, W, Cc = srcs[0].shape
+    H, W = H << ups[0], W << ups[0]
+    out = torch.empty(B, H, W, Cc, device=srcs[0].device, dtype=torch.float32) if out is None else out
+    ptrs = (C.c_void_p * n)(*[_ptr(_f32c(s)) for s in srcs])
+    check(_lib.lib().somi_bifpn_nhwc_f32(ptrs, (C.c_int * n)(*ups), (C.c_float * n)(*[float(v) for v in wn]), n, _ptr(out),
+                                         B, H, W, Cc, _stream()), 'bifpn')
+    return out
+
+
+def global_pool(x, c=None, x_coff=0, want_max=True):
+    B, H, W, cs = x.shape
+    c = cs - x_coff if c is None else c
+    nchunk = _lib.lib().somi_pool_nchunk(H * W)
+    ws = torch.empty(2 * B * nchunk * c, device=x.device, dtype=torch.float32)
+    avg = torch.empty(B, c, device=x.device, dtype=torch.float32)
+    mx = torch.empty(B, c, device=x.device, dtype=torch.float32) if want_max else None
+    check(_lib.lib().somi_global_pool_nhwc_f32(_ptr(_f32c(x)), cs, x_coff, B, H * W, c, _ptr(avg), _ptr(mx), _ptr(ws),
+                                               _stream()), 'global_pool')
+    return avg, mx
+
+
+def attn_mlp(mode, avg, mx, W1, b1, W2, b2):
+    B, Cc = avg.shape
+    out = torch.empty_like(avg)
+    check(_lib.lib().somi_attn_mlp_f32(mode, _ptr(avg), _ptr(mx), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(out), B, Cc,
+                                       W1.shape[0], _stream()), 'attn_mlp')
+    return out
+
+
+def chan_stats(x, ca, c=None, x_coff=0):
+    B, H, W, cs = x.shape
+    c = cs - x_coff if c is None else c
+    stats = torch.empty(B, H, W, 2, device=x.device, dtype=torch.float32)
+    check(_lib.lib().somi_chan_stats_nhwc_f32(_ptr(_f32c(x)), cs, x_coff, _ptr(ca), _ptr(stats), B, H * W, c, _stream()),
+          'chan_stats')
+    return stats
+
+
+def spatial_attn(stats, w, bias, k):
+    B, H, W, _ = stats.shape
+    sa = torch.empty(B, H, W, device=stats.device, dtype=torch.float32)
+    check(_lib.lib().somi_spatial_attn_f32(_ptr(stats), _ptr(w), float(bias), _ptr(sa), B, H, W, k, _stream()), 'spatial_attn')
+    return sa
+
+
+def scale_channels(x, s=None, pix=None, out=None):
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().somi_scale_channels_nhwc_f32(_ptr(_f32c(x)), _ptr(s), _ptr(pix), _ptr(out), B, H * W, Cc, _stream()),
+          'scale_channels')
+    return out
+
+
+def detect_decode(box, cls, anchors_px, stride, na, nc, raw=None, z=None, total=0, row_off=0):
+    B, ny, nx, box_cs = box.shape
+    a = (C.c_float * (na * 2))(*[float(v) for v in anchors_px])
+    check(_lib.lib().somi_detect_decode_f32(_ptr(_f32c(box)), box_cs, _ptr(_f32c(cls)), cls.shape[3], a, float(stride),
+                                            _ptr(raw), _ptr(z), B, ny, nx, na, nc, total, row_off, _stream()), 'detect_decode')
