@@ -77,6 +77,10 @@ typedef struct somi_conv_desc {
 
 int somi_conv2d_nhwc_f32(const somi_conv_desc *d, somi_stream_t stream);
 
+/* Name of the kernel instantiation somi_conv2d_nhwc_f32 would launch for this descriptor (for profiling: matches the
+ * kernel name rocprofv3 reports), or NULL for an invalid descriptor. */
+const char *somi_conv2d_kernel_name(const somi_conv_desc *d);
+
 /* ------------------------------------------------------------------------------------------
  * DCNv3 operator.  Replaces `dcnv3_forward` / `dcnv3_backward` of the reference extension
  * (models/ops_dcnv3/src/dcnv3.h:20-59, src/cuda/dcnv3_cuda.cu:21-174, kernels

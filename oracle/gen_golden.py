@@ -183,18 +183,18 @@ def gen_model():
                    nparams=np.int64(sum(p.numel() for p in m.parameters())))
         for i, t in enumerate(raw):
             rec[f'raw{i}'] = t
-        if B > 1:
+        # fused (Model.fuse) eval output, on a copy so that the BN statistics are the ones used above
+        from copy import deepcopy
+        mf = deepcopy(m).eval().fuse()
+        with torch.no_grad():
+            zf, _ = mf(x.clone())
+        rec['z_fused'] = zf
+        if B > 1:                                   # train-mode forward last: it updates the BN running statistics
             m.train()
             with torch.no_grad():
                 tr = m(x.clone())
             for i, t in enumerate(tr):
                 rec[f'train{i}'] = t
-        # fused (Model.fuse) eval output
-        m.eval()
-        m.fuse()
-        with torch.no_grad():
-            zf, _ = m(x.clone())
-        rec['z_fused'] = zf
         save(f'model_{tag}', **rec)
 
 

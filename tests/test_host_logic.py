@@ -1,0 +1,83 @@
+"""CPU-side checks of the host layer: the C ABI exports every symbol the header declares, the product Model has
+the reference's parameter layout (checked against the oracle, which is pinned to the reference), and the product
+refuses to run without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'somi_hip.h')).read()
+    declared = set(re.findall(r'\b(somi_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'somi_stream_t'}
+    assert len(declared) >= 20
+    from somi_amd import _lib
+    assert set(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ declared
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f'{name} is declared in include/somi_hip.h but not exported'
+    assert _lib.lib().somi_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from somi_amd._lib import ConvDesc, LossDesc
+    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 20 * 4
+    assert ctypes.sizeof(LossDesc) == 4 * 8 + 4 * 8 + 4 * 4 + 4 * 4 + 5 * 4 + 4 + 2 * 8 + 4 * 4 + 9 * 4 + 4
+
+
+@pytest.mark.parametrize('width,depth,anchors', [(0.25, 0.33, 4), (1.0, 1.0, 'visdrone')])
+def test_model_parameter_layout_matches_reference(width, depth, anchors):
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import somi_cfg, SOMI_ANCHORS
+    from somi_amd.model import Model
+    anchors = SOMI_ANCHORS if anchors == 'visdrone' else anchors
+    cfg = somi_cfg(width, depth, anchors=anchors)
+    ref, mine = OModel(cfg), Model(cfg)
+    rs, ms = ref.state_dict(), mine.state_dict()
+    assert set(rs) == set(ms), sorted(set(rs) ^ set(ms))[:10]
+    for k in rs:
+        assert rs[k].shape == ms[k].shape, k
+    assert torch.equal(ref.stride, mine.stride)
+    assert torch.equal(ref.model[-1].anchors, mine.model[-1].anchors)
+    assert ref.save == mine.save
+    mine.load_state_dict(rs)
+    if width == 1.0:
+        assert sum(p.numel() for p in mine.parameters()) == 77537610
+
+
+def test_product_refuses_cpu_tensors():
+    from oracle.somi_ref.testing import somi_cfg
+    from somi_amd.model import Model
+    m = Model(somi_cfg(0.25, 0.33)).eval()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(1, 3, 64, 64))
+
+
+def test_unknown_module_is_rejected():
+    from oracle.somi_ref.testing import somi_cfg
+    from somi_amd.model import Model
+    cfg = somi_cfg(0.25, 0.33)
+    cfg['backbone'][0][2] = 'Focus'
+    with pytest.raises(NotImplementedError, match='outside the SOMI hot path'):
+        Model(cfg)
+
+
+def test_product_config_data_matches_oracle_copy():
+    """somi_amd.configs (product) and oracle.somi_ref.testing (test infrastructure) carry the same data and fill."""
+    import torch.nn as nn
+    from oracle.somi_ref import testing as O
+    from somi_amd import configs as P
+    assert O.somi_cfg(0.5, 0.67) == P.somi_cfg(0.5, 0.67)
+    assert O.SOMI_ANCHORS == P.SOMI_ANCHORS and O.HYP_VISDRONE == P.HYP_VISDRONE
+    a, b = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8)), nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8))
+    O.fill_state(a, 3), P.fill_state(b, 3)
+    for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(u, v), k
+    ia, ta = O.synthetic_batch(2, 32, seed=4)
+    ib, tb = P.synthetic_batch(2, 32, seed=4)
+    assert torch.equal(ia, ib) and torch.equal(ta, tb)

@@ -226,6 +226,14 @@ static int launch(const ConvArgs &a, hipStream_t s) {
     return launch_status("somi_conv2d_nhwc_f32");
 }
 
+// tile choice: widest N tile that Cout fills reasonably; small-M problems take the 64-row tile to fill the chip
+static int pick_tile(const somi_conv_desc &d, int M) {
+    const long blocks128 = (long)cdiv(M, 128) * cdiv(d.Cout, 128) * (d.per_sample_w ? d.B : 1);
+    if (d.Cout > 64) return (blocks128 >= 512 || M >= 128 * 256) ? 0 : 1;
+    if (d.Cout > 32) return 2;
+    return 3;
+}
+
 }  // namespace somi
 
 extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stream) {
@@ -254,12 +262,22 @@ extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stre
     a.M = d.per_sample_w ? d.Ho * d.Wo : d.B * d.Ho * d.Wo;
     a.tiles_m = a.tiles_n = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // tile choice: widest N tile that Cout fills reasonably; small M problems take the 64-row tile to fill the chip
-    const long blocks128 = (long)cdiv(a.M, 128) * cdiv(d.Cout, 128) * (d.per_sample_w ? d.B : 1);
-    if (d.Cout > 64) {
-        if (blocks128 >= 512 || a.M >= 128 * 256) return launch<128, 128, 2, 2>(a, s);
-        return launch<64, 128, 1, 4>(a, s);
+    switch (pick_tile(d, a.M)) {
+        case 0: return launch<128, 128, 2, 2>(a, s);
+        case 1: return launch<64, 128, 1, 4>(a, s);
+        case 2: return launch<128, 64, 2, 2>(a, s);
+        default: return launch<128, 32, 4, 1>(a, s);
     }
-    if (d.Cout > 32) return launch<128, 64, 2, 2>(a, s);
-    return launch<128, 32, 4, 1>(a, s);
+}
+
+extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
+    if (!dp || dp->Cout <= 0 || dp->Ho <= 0 || dp->Wo <= 0 || dp->B <= 0) return nullptr;
+    const int M = dp->per_sample_w ? dp->Ho * dp->Wo : dp->B * dp->Ho * dp->Wo;
+    const bool mod = dp->a_chan_scale || dp->a_pix_scale;
+    static const char *names[4][2] = {
+        {"conv_igemm_f32_kernel<128,128,2,2,false>", "conv_igemm_f32_kernel<128,128,2,2,true>"},
+        {"conv_igemm_f32_kernel<64,128,1,4,false>", "conv_igemm_f32_kernel<64,128,1,4,true>"},
+        {"conv_igemm_f32_kernel<128,64,2,2,false>", "conv_igemm_f32_kernel<128,64,2,2,true>"},
+        {"conv_igemm_f32_kernel<128,32,4,1,false>", "conv_igemm_f32_kernel<128,32,4,1,true>"}};
+    return names[somi::pick_tile(*dp, M)][mod ? 1 : 0];
 }

@@ -12,9 +12,3 @@ extern "C" int somi_wbf_f32(const float *, const float *, const int32_t *, const
     set_error("somi_wbf_f32: not implemented yet");
     return SOMI_ENOTIMPL;
 }
-extern "C" size_t somi_nms_workspace_bytes(int, int, int, int) { return 0; }
-extern "C" int somi_nms_f32(const float *, int, int, int, float, float, int, int, uint64_t, int, float *, int32_t *, void *, size_t,
-                            somi_stream_t) {
-    set_error("somi_nms_f32: not implemented yet");
-    return SOMI_ENOTIMPL;
-}

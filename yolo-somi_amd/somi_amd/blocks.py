@@ -1,0 +1,471 @@
+"""SOMI building blocks executing on libsomi_hip.so (NHWC fp32, MI355X).
+
+Each class keeps the reference's constructor signature and parameter names (so reference-format yaml and
+state_dicts load unchanged) but its forward launches HIP kernels through the C ABI:
+Conv+BN+SiLU is ONE implicit-GEMM launch with the BN folded into the packed weights (eval), `torch.cat` never
+happens (producers write channel slices of the consumer's buffer), nearest upsampling is folded into the BiFPN
+read and the CBAM scaling into the following conv's operand load.
+
+Activations travel as `Act` = (NHWC tensor, channel offset, logical channels).  Channel strides are multiples of 4;
+padded channels hold zeros (zero weight rows in the producer), so consumers may read them.
+Reference citations are relative to /root/reference.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .pack import pack_conv_weight, pad4, bn_fold
+
+
+class Act:
+    """A channel slice [coff, coff+c) of an NHWC tensor."""
+    __slots__ = ('t', 'coff', 'c', 'up')
+
+    def __init__(self, t, coff=0, c=None, up=0):
+        self.t, self.coff, self.c, self.up = t, coff, (t.shape[3] - coff if c is None else c), up
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def slice(self, coff, c):
+        return Act(self.t, self.coff + coff, c)
+
+
+def new_act(like, H, W, c):
+    return Act(torch.empty(like.shape[0], H, W, pad4(c), device=like.device, dtype=torch.float32), 0, c)
+
+
+def autopad(k, p=None, d=1):
+    """models/common.py:43-51."""
+    if p is not None:
+        return p
+    return (d * (k - 1) + 1) // 2 if d > 1 else k // 2
+
+
+class _Packed(nn.Module):
+    """Mixin: device-side packed parameters are rebuilt lazily after any parameter change."""
+
+    def _packed(self, dev):
+        cache = self.__dict__.get('_pk')
+        if cache is None or cache[0] != (dev, self.training):
+            with torch.no_grad():
+                cache = ((dev, self.training), self._pack(dev))
+            self.__dict__['_pk'] = cache
+        return cache[1]
+
+    def invalidate(self):
+        self.__dict__.pop('_pk', None)
+
+
+def _act_name(m):
+    if isinstance(m, nn.SiLU):
+        return 'silu'
+    if isinstance(m, nn.Identity):
+        return 'none'
+    if isinstance(m, nn.ReLU):
+        return 'relu'
+    if isinstance(m, nn.GELU):
+        return 'gelu'
+    raise NotImplementedError(f'activation {type(m).__name__} is not on the SOMI path')
+
+
+def _fold_conv_bn(conv, bn):
+    """W' = diag(gamma/sqrt(var+eps)) W, b' = beta - gamma*mean/sqrt(var+eps) (+ scaled conv bias)
+    (utils/torch_utils.py:202-222)."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None:
+        s, t = bn_fold(bn)
+        w = w * s.view(-1, 1, 1, 1)
+        b = b * s + t
+    return w, b
+
+
+def _pack_wb(w, b, dev):
+    """-> packed weight [pad4(Cout)][k*k*pad4(Cin)], bias [pad4(Cout)] on dev (pads zero)."""
+    cout = w.shape[0]
+    wp = pack_conv_weight(w, cout_pad=pad4(cout)).to(dev)
+    bp = torch.zeros(pad4(cout), device=dev)
+    bp[:cout] = b.to(dev)
+    return wp, bp
+
+
+class Conv(_Packed):
+    """conv2d(bias=False) -> BatchNorm2d -> SiLU as one fused launch (models/common.py:53-70)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        if g != 1 or d != 1:
+            raise NotImplementedError('grouped / dilated Conv is not on the SOMI path')
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    def _pack(self, dev):
+        if self.training:
+            raise NotImplementedError('training-mode BatchNorm (batch statistics) is not built yet on the HIP path')
+        return _pack_wb(*_fold_conv_bn(self.conv, getattr(self, 'bn', None)), dev)
+
+    def forward(self, x, out=None, residual=None, a_chan=None, a_pix=None):
+        wp, bp = self._packed(x.t.device)
+        k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
+        c2 = self.conv.out_channels
+        B, H, W, _ = x.shape
+        Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+        if out is None:
+            out = new_act(x.t, Ho, Wo, c2)
+            cout = pad4(c2)
+        else:
+            if c2 % 4:
+                raise NotImplementedError('writing into a channel slice needs c2 % 4 == 0')
+            cout = c2
+        ops.conv2d_nhwc(x.t, wp[:cout], bp, kh=k, kw=k, stride=s, pad=p, act=_act_name(self.act), cin=pad4(x.c),
+                        x_coff=x.coff, out=out.t, cout=cout, y_coff=out.coff,
+                        residual=None if residual is None else residual.t,
+                        res_coff=0 if residual is None else residual.coff, a_chan_scale=a_chan, a_pix_scale=a_pix,
+                        alg_cin=x.c, alg_cout=c2)
+        return Act(out.t, out.coff, c2)
+
+
+class PlainConv(_Packed):
+    """nn.Conv2d with bias, no norm / activation (Decouple.b3 / c3, models/yolo.py:1057,1063)."""
+
+    def __init__(self, conv):
+        super().__init__()
+        self.conv = conv
+
+    def _pack(self, dev):
+        return _pack_wb(*_fold_conv_bn(self.conv, None), dev)
+
+    def forward(self, x):
+        wp, bp = self._packed(x.t.device)
+        k = self.conv.kernel_size[0]
+        B, H, W, _ = x.shape
+        out = new_act(x.t, H, W, self.conv.out_channels)
+        ops.conv2d_nhwc(x.t, wp, bp, kh=k, kw=k, stride=1, pad=k // 2, act='none', cin=pad4(x.c), x_coff=x.coff,
+                        out=out.t, cout=pad4(self.conv.out_channels), alg_cin=x.c, alg_cout=self.conv.out_channels)
+        return out
+
+
+class ChannelAttentionModule(_Packed):
+    """sigmoid(MLP(GAP) + MLP(GMP)) (models/common.py:339-358) -> (B,C) scale vector."""
+
+    def __init__(self, c1, reduction=16):
+        super().__init__()
+        mid = c1 // reduction
+        self.shared_MLP = nn.Sequential(nn.Linear(c1, mid), nn.ReLU(), nn.Linear(mid, c1))
+
+    def _pack(self, dev):
+        l1, l2 = self.shared_MLP[0], self.shared_MLP[2]
+        return tuple(t.detach().float().contiguous().to(dev) for t in (l1.weight, l1.bias, l2.weight, l2.bias))
+
+    def forward(self, x):
+        W1, b1, W2, b2 = self._packed(x.t.device)
+        avg, mx = ops.global_pool(x.t, c=x.c, x_coff=x.coff)
+        return ops.attn_mlp(0, avg, mx, W1, b1, W2, b2)
+
+
+class SpatialAttentionModule(_Packed):
+    """sigmoid(conv_kxk([mean_c, max_c])) (models/common.py:392-405) -> (B,H,W) scale map of ca*x."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        assert kernel_size in (3, 5, 7)
+        self.cv1 = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2)
+
+    def _pack(self, dev):
+        w = self.cv1.weight.detach().float()[0].permute(1, 2, 0).contiguous().to(dev)     # [k][k][2]
+        return w, float(self.cv1.bias.detach()[0])
+
+    def forward(self, x, ca):
+        w, b = self._packed(x.t.device)
+        stats = ops.chan_stats(x.t, ca, c=x.c, x_coff=x.coff)
+        return ops.spatial_attn(stats, w, b, self.cv1.kernel_size[0])
+
+
+class CBAMBottleneck(nn.Module):
+    """cv1 3x3 -> channel attn -> spatial attn -> cv2 3x3 (+x) (models/common.py:671-691).
+    The two attention scalings are applied on cv2's operand load instead of materialising `out`."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=1.0, k=(3, 3), ratio=8, kernel_size=3):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=1)
+        self.add = shortcut and c1 == c2
+        self.channel_attention = ChannelAttentionModule(c_, ratio)
+        self.spatial_attention = SpatialAttentionModule(kernel_size)
+
+    def forward(self, x, out=None):
+        t = self.cv1(x)
+        ca = self.channel_attention(t)
+        sa = self.spatial_attention(t, ca)
+        return self.cv2(t, out=out, residual=x if self.add else None, a_chan=ca, a_pix=sa)
+
+
+class C2fCBAM(nn.Module):
+    """models/common.py:2671-2695; all (2+n) pieces live in one buffer, nothing is concatenated."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5, kernel_size=7):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(
+            CBAMBottleneck(self.c, self.c, shortcut, g, k=(3, 3), e=1.0, ratio=16, kernel_size=kernel_size)
+            for _ in range(n))
+
+    def forward(self, x):
+        c, n = self.c, len(self.m)
+        if c % 4:
+            raise NotImplementedError('C2fCBAM hidden width must be a multiple of 4 on the MI355X path')
+        B, H, W, _ = x.shape
+        cat = Act(torch.empty(B, H, W, (2 + n) * c, device=x.t.device, dtype=torch.float32))
+        self.cv1(x, out=cat.slice(0, 2 * c))
+        for i, blk in enumerate(self.m):
+            blk(cat.slice((1 + i) * c, c), out=cat.slice((2 + i) * c, c))
+        return self.cv2(cat)
+
+
+class SPPF(nn.Module):
+    """models/common.py:1846-1861: the three chained max-pools are one kernel writing the concat slices."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        if k != 5:
+            raise NotImplementedError('SPPF kernel size 5 only')
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+
+    def forward(self, x):
+        c_ = self.cv1.conv.out_channels
+        B, H, W, _ = x.shape
+        cat = Act(torch.empty(B, H, W, 4 * c_, device=x.t.device, dtype=torch.float32))
+        self.cv1(x, out=cat.slice(0, c_))
+        ops.sppf_pool_(cat.t, c_, 0)
+        return self.cv2(cat)
+
+
+class Swish(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(x)
+
+
+class BiFPN(nn.Module):
+    """w_i / (sum_j swish(w_j) + 1e-4) weighted sum (models/common.py:3688-3704); inputs may be virtual 2x-upsampled."""
+
+    def __init__(self, length):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(length, dtype=torch.float32), requires_grad=True)
+        self.swish = Swish()
+        self.epsilon = 0.0001
+
+    def forward(self, xs):
+        w = self.weight.detach().float().cpu()
+        wn = (w / (self.swish(w).sum(dim=0) + self.epsilon)).tolist()
+        for a in xs:
+            if a.coff != 0 or a.t.shape[3] != xs[0].t.shape[3]:
+                raise NotImplementedError('BiFPN inputs must be whole tensors of equal width')
+        out = ops.bifpn([a.t for a in xs], [a.up for a in xs], wn)
+        return Act(out, 0, xs[0].c)
+
+
+class Upsample(nn.Module):
+    """nn.Upsample(None, 2, 'nearest') (YOLO-SOMI.yaml:37,42,47): a view flag; the consumer (BiFPN) reads at (h>>1, w>>1)."""
+
+    def __init__(self, size=None, scale_factor=None, mode='nearest'):
+        super().__init__()
+        if size is not None or scale_factor != 2 or mode != 'nearest':
+            raise NotImplementedError('only 2x nearest upsampling is on the SOMI path')
+
+    def forward(self, x):
+        return Act(x.t, x.coff, x.c, up=x.up + 1)
+
+
+class ODConv2d_3rd(_Packed):
+    """Parameter layout of models/common.py:4495-4536; executed by ODConv_3rd below."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 K=4, r=1 / 16):
+        super().__init__()
+        if groups != 1 or dilation != 1:
+            raise NotImplementedError('grouped / dilated ODConv is not on the SOMI path')
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.kernel_size, self.stride, self.padding = (kernel_size, kernel_size), stride, padding
+        self.weight = nn.Parameter(torch.empty(K, out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(K, out_channels)) if bias else None
+        hidden = max(int(in_channels * r), 16)
+        self.reduction = nn.Linear(in_channels, hidden)          # unused in the reference too (:4521)
+        self.fc = nn.Conv2d(in_channels, hidden, 1, bias=False)
+        self.bn = nn.BatchNorm2d(hidden)
+        self.fc_f = nn.Linear(hidden, out_channels)
+        self.fc_s = nn.Linear(hidden, kernel_size * kernel_size)
+        self.fc_c = nn.Linear(hidden, in_channels)
+        self.fc_w = nn.Linear(hidden, K)
+        fan_out = kernel_size * kernel_size * out_channels
+        with torch.no_grad():
+            for i in range(K):
+                self.weight[i].normal_(0, math.sqrt(2.0 / fan_out))
+
+
+class ODConv_3rd(_Packed):
+    """ODConv2d_3rd -> BN -> SiLU (models/common.py:4638-4653): GAP kernel -> attention + per-sample weight synthesis
+    (with the outer BN folded in) -> per-sample implicit-GEMM conv with SiLU epilogue."""
+
+    def __init__(self, c1, c2, k=1, s=1, kerNums=4, g=1, p=None, act=True):
+        super().__init__()
+        self.conv = ODConv2d_3rd(c1, c2, k, s, autopad(k, p), groups=g, K=kerNums)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    def _pack(self, dev):
+        if self.training:
+            raise NotImplementedError('training-mode BatchNorm (batch statistics) is not built yet on the HIP path')
+        cv = self.conv
+        f = lambda t: t.detach().float().contiguous().to(dev)   # noqa: E731
+        s_in, t_in = bn_fold(cv.bn)
+        fcw = cv.fc.weight.detach().float().flatten(1)
+        pk = dict(fc_w=f(fcw), fc_w_bn=f(fcw * s_in[:, None]), fc_b_bn=f(t_in),
+                  Wf=f(cv.fc_f.weight), bf=f(cv.fc_f.bias), Ws=f(cv.fc_s.weight), bs=f(cv.fc_s.bias),
+                  Wc=f(cv.fc_c.weight), bc=f(cv.fc_c.bias), Ww=f(cv.fc_w.weight), bw=f(cv.fc_w.bias),
+                  Wk=pack_conv_weight(cv.weight.detach().float()).to(dev),           # [K][Cout][kk*Cin_pad]
+                  biask=None if cv.bias is None else f(cv.bias))
+        s_out, t_out = bn_fold(self.bn)
+        pk['bn_s'], pk['bn_t'] = f(s_out), f(t_out)
+        return pk
+
+    def forward(self, x):
+        pk = self._packed(x.t.device)
+        cv = self.conv
+        B, H, W, _ = x.shape
+        k, s, p = cv.kernel_size[0], cv.stride, cv.padding
+        cin, cin_pad, cout = cv.in_channels, pad4(cv.in_channels), cv.out_channels
+        if x.c != cin:
+            raise ValueError(f'Expected input{[B, x.c, H, W]} to have {cin} channels, but got {x.c} channels instead')
+        if cout % 4 or cin % 4:
+            raise NotImplementedError('ODConv channels must be multiples of 4 on the MI355X path')
+        gap, _ = ops.global_pool(x.t, c=cin, x_coff=x.coff, want_max=False)
+        bn_attn = B > 1                                        # the reference skips the squeeze BN for one sample (:4562)
+        wout = torch.empty(B, cout, k * k * cin_pad, device=x.t.device, dtype=torch.float32)
+        bout = torch.empty(B, cout, device=x.t.device, dtype=torch.float32)
+        ops.odconv_weights(gap, pk['fc_w_bn'] if bn_attn else pk['fc_w'], pk['fc_b_bn'] if bn_attn else None, pk, wout,
+                           bout, cin, cin_pad, cout, k * k, cv.K)
+        Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+        out = new_act(x.t, Ho, Wo, cout)
+        ops.conv2d_nhwc(x.t, wout, bout, kh=k, kw=k, stride=s, pad=p, act=_act_name(self.act), cin=cin_pad,
+                        x_coff=x.coff, out=out.t, cout=cout, per_sample_w=True)
+        return out
+
+
+class Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class SEAM(_Packed):
+    """models/common.py:8448-8505: dw3x3+GELU+BN -> Residual(dw3x3+GELU+BN) -> 1x1+GELU+BN -> GAP -> MLP -> x*exp(.)."""
+
+    def __init__(self, c1, c2, n, reduction=16):
+        super().__init__()
+        if c1 != c2:
+            c2 = c1
+        if n != 1:
+            raise NotImplementedError('SEAM with n != 1 is not on the SOMI path')
+        stage = nn.Sequential(
+            Residual(nn.Sequential(nn.Conv2d(c2, c2, 3, 1, 1, groups=c2), nn.GELU(), nn.BatchNorm2d(c2))),
+            nn.Conv2d(c2, c2, 1, 1, 0, groups=1), nn.GELU(), nn.BatchNorm2d(c2))
+        self.DCovN = nn.Sequential(nn.Conv2d(c1, c2, 3, 1, 1, groups=c1), nn.GELU(), nn.BatchNorm2d(c2), stage)
+        self.fc = nn.Sequential(nn.Linear(c2, c2 // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(c2 // reduction, c2, bias=False), nn.Sigmoid())
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight, gain=1)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _pack(self, dev):
+        if self.training:
+            raise NotImplementedError('training-mode BatchNorm (batch statistics) is not built yet on the HIP path')
+        f = lambda t: t.detach().float().contiguous().to(dev)   # noqa: E731
+        dw = lambda conv: f(conv.weight[:, 0].permute(1, 2, 0).reshape(9, -1))   # noqa: E731  [9][C]
+        d = self.DCovN
+        st = d[3]
+        pw = st[1]
+        return dict(dw0=dw(d[0]), b0=f(d[0].bias), bn0=tuple(map(f, bn_fold(d[2]))),
+                    dw1=dw(st[0].fn[0]), b1=f(st[0].fn[0].bias), bn1=tuple(map(f, bn_fold(st[0].fn[2]))),
+                    pw=f(pw.weight.flatten(1)), pb=f(pw.bias), bn2=tuple(map(f, bn_fold(st[3]))),
+                    W1=f(self.fc[0].weight), W2=f(self.fc[2].weight))
+
+    def forward(self, x):
+        pk = self._packed(x.t.device)
+        if x.coff != 0 or x.t.shape[3] != x.c or x.c % 4:
+            raise NotImplementedError('SEAM input must be a whole tensor with channels a multiple of 4')
+        y0 = ops.dwconv3x3(x.t, pk['dw0'], pk['b0'], *pk['bn0'], act='gelu')
+        y1 = ops.dwconv3x3(y0, pk['dw1'], pk['b1'], *pk['bn1'], residual=y0, act='gelu')
+        y2 = ops.conv2d_nhwc(y1, pk['pw'], pk['pb'], kh=1, kw=1, act='gelu', post_scale=pk['bn2'][0],
+                             post_shift=pk['bn2'][1])
+        avg, _ = ops.global_pool(y2, want_max=False)
+        s = ops.attn_mlp(1, avg, None, pk['W1'], None, pk['W2'], None)
+        return Act(ops.scale_channels(x.t, s), 0, x.c)
+
+
+class Decouple(nn.Module):
+    """Decoupled head for one level (models/yolo.py:1042-1073); the [5|nc] interleave happens in the decode kernel."""
+
+    def __init__(self, c1, nc=80, na=3):
+        super().__init__()
+        c_ = min(c1, 256)
+        self.na, self.nc = na, nc
+        self.a = Conv(c1, c_, 1)
+        c = [int(v + na * 5) for v in (c_ - na * 5) * torch.linspace(1, 0, 4)]
+        self.b1, self.b2, self.b3 = Conv(c_, c[1], 3), Conv(c[1], c[2], 3), nn.Conv2d(c[2], na * 5, 1)
+        self.c1, self.c2, self.c3 = Conv(c_, c_, 1), Conv(c_, c_, 1), nn.Conv2d(c_, na * nc, 1)
+        self.__dict__['_b3'] = PlainConv(self.b3)              # runners share the parameters, stay out of state_dict
+        self.__dict__['_c3'] = PlainConv(self.c3)
+
+    def invalidate(self):
+        self._b3.invalidate()
+        self._c3.invalidate()
+
+    def forward(self, x):
+        x = self.a(x)
+        b = self._b3(self.b2(self.b1(x)))
+        c = self._c3(self.c2(self.c1(x)))
+        return b, c
+
+
+class DecoupledDetect(nn.Module):
+    """models/yolo.py:925-980.  forward returns (z, [raw_i]) in eval like the reference; raw_i is (B,na,ny,nx,no)."""
+    stride = None
+
+    def __init__(self, nc=10, anchors=(), ch=(), inplace=False):
+        super().__init__()
+        self.nc, self.no = nc, nc + 5
+        self.nl, self.na = len(anchors), len(anchors[0]) // 2
+        self.register_buffer('anchors', torch.tensor(anchors).float().view(self.nl, -1, 2))
+        self.m = nn.ModuleList(Decouple(c, self.nc, self.na) for c in ch)
+        self.inplace = False
+
+    def forward(self, xs):
+        B = xs[0].shape[0]
+        dev = xs[0].t.device
+        total = sum(self.na * a.shape[1] * a.shape[2] for a in xs)
+        z = None if self.training else torch.empty(B, total, self.no, device=dev, dtype=torch.float32)
+        raws, row = [], 0
+        anchors = self.anchors.detach().float().cpu()
+        for i in range(self.nl):
+            b, c = self.m[i](xs[i])
+            _, ny, nx, _ = b.shape
+            raw = torch.empty(B, self.na, ny, nx, self.no, device=dev, dtype=torch.float32)
+            stride = float(self.stride[i])
+            ops.detect_decode(b.t, c.t, (anchors[i] * stride).flatten().tolist(), stride, self.na, self.nc, raw=raw,
+                              z=z, total=total, row_off=row)
+            raws.append(raw)
+            row += self.na * ny * nx
+        return raws if self.training else (z, raws)

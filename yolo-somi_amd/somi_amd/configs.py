@@ -1,0 +1,83 @@
+"""Configuration data of the SOMI path and deterministic synthetic weights (product side).
+
+`somi_cfg` is the layer table of models/modules/YOLO-SOMI.yaml as a dict (with the documented C2fEACBAM -> C2fCBAM
+substitution, SURVEY.md "five facts" #2), `SOMI_ANCHORS` the 16 anchor pairs of its line 9 comment, `HYP_VISDRONE` the
+loss-relevant keys of data/hyps/hyp.VisDrone.yaml.  `fill_state` gives every parameter a value derived from its
+state_dict name (bench.py's synthetic weights: no checkpoint can be downloaded here); `synthetic_batch` is the
+VisDrone-shaped batch of SURVEY.md section 8d.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+def fill_state(module, seed=0):
+    """In-place deterministic fill of module.state_dict(); returns the module."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if not t.dtype.is_floating_point:
+                continue                                        # num_batches_tracked etc.
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+            leaf = name.rsplit('.', 1)[-1]
+            if leaf == 'running_var':
+                v = torch.rand(t.shape, generator=g) + 0.5       # U(0.5, 1.5)
+            elif leaf == 'running_mean':
+                v = torch.randn(t.shape, generator=g) * 0.1
+            elif leaf == 'anchors':
+                continue                                        # geometry, not a weight
+            elif t.dim() == 1 and leaf == 'weight':              # BN / LN scale (BiFPN weight too)
+                v = torch.rand(t.shape, generator=g) + 0.5
+            elif t.dim() <= 1 or leaf == 'bias':
+                v = torch.randn(t.shape, generator=g) * 0.1
+            else:                                               # conv / linear / ODConv kernels
+                fan_in = t[0].numel() if t.dim() < 5 else t[0, 0].numel()
+                v = torch.randn(t.shape, generator=g) * (1.0 / math.sqrt(max(fan_in, 1)))
+            t.copy_(v.to(t.dtype))
+    return module
+
+
+def synthetic_batch(batch, size, nc=10, seed=0):
+    """uint8 images (B,3,S,S) and targets (nt,6) = [img, cls, x, y, w, h] as SURVEY.md section 8d specifies."""
+    rng = np.random.RandomState(seed)
+    imgs = torch.from_numpy(rng.randint(0, 256, (batch, 3, size, size), dtype=np.uint8))
+    rows = []
+    for b in range(batch):
+        n = int(np.clip(rng.poisson(54), 1, 300))
+        cls = rng.randint(0, nc, n).astype(np.float32)
+        xy = rng.uniform(0.02, 0.98, (n, 2)).astype(np.float32)
+        wh = np.clip(np.exp(rng.normal(math.log(0.03), 0.7, (n, 2))), 0.004, 0.5).astype(np.float32)
+        rows.append(np.concatenate([np.full((n, 1), b, np.float32), cls[:, None], xy, wh], 1))
+    return imgs, torch.from_numpy(np.concatenate(rows, 0))
+
+
+SOMI_ANCHORS = [[4, 6, 12, 8, 7, 14, 20, 12], [13, 22, 31, 18, 21, 33, 46, 23],
+                [37, 37, 31, 56, 65, 34, 55, 57], [95, 52, 60, 90, 147, 76, 103, 134]]
+"""The 16 anchor pairs listed in models/modules/YOLO-SOMI.yaml:9 (comment), 4 per level P2..P5."""
+
+HYP_VISDRONE = dict(lr0=0.0032, lrf=0.12, momentum=0.843, weight_decay=0.00036, warmup_epochs=2.0,
+                    warmup_momentum=0.5, warmup_bias_lr=0.05, box=0.07, cls=0.18, cls_pw=0.631, obj=0.15,
+                    obj_pw=0.911, iou_t=0.2, anchor_t=3, fl_gamma=0.0, alpha=0.01, beta=0.1, Rp_nms=0.1,
+                    deta=0.5, slide_ratio=0, nwdloss=0, shapeloss=0, label_smoothing=0.0)
+"""Loss-relevant keys of data/hyps/hyp.VisDrone.yaml (values are configuration data)."""
+
+
+def somi_cfg(width=1.0, depth=1.0, nc=10, anchors=4):
+    """The layer table of models/modules/YOLO-SOMI.yaml as a dict (C2fEACBAM -> C2fCBAM)."""
+    bb = [[-1, 1, 'Conv', [64, 3, 2]], [-1, 1, 'ODConv_3rd', [128, 3, 2, 4]], [-1, 3, 'C2fCBAM', [128, True]],
+          [-1, 1, 'Conv', [256, 3, 2]], [-1, 6, 'C2fCBAM', [256, True]], [-1, 1, 'Conv', [512, 3, 2]],
+          [-1, 6, 'C2fCBAM', [512, True]], [-1, 1, 'Conv', [1024, 3, 2]], [-1, 3, 'C2fCBAM', [1024, True]],
+          [-1, 1, 'SPPF', [1024, 5]]]
+    up = [-1, 1, 'nn.Upsample', [None, 2, 'nearest']]
+    hd = [[2, 1, 'Conv', [256]], [4, 1, 'Conv', [256]], [6, 1, 'Conv', [256]], [9, 1, 'Conv', [256]],
+          up, [[-1, 12], 1, 'BiFPN', []], [-1, 1, 'SEAM', [256, 1, 16]], [-1, 3, 'C2fCBAM', [256]],
+          up, [[-1, 11], 1, 'BiFPN', []], [-1, 1, 'SEAM', [256, 1, 16]], [-1, 3, 'C2fCBAM', [256]],
+          up, [[-1, 10], 1, 'BiFPN', []], [-1, 1, 'SEAM', [256, 1, 16]], [-1, 3, 'C2fCBAM', [256]],
+          [-1, 1, 'ODConv_3rd', [256, 3, 2, 4]], [[-1, 11, 21], 1, 'BiFPN', []], [-1, 3, 'C2fCBAM', [256]],
+          [-1, 1, 'ODConv_3rd', [256, 3, 2, 4]], [[-1, 12, 17], 1, 'BiFPN', []], [-1, 3, 'C2fCBAM', [512]],
+          [-1, 1, 'ODConv_3rd', [256, 3, 2, 4]], [[-1, 13], 1, 'BiFPN', []], [-1, 3, 'C2fCBAM', [1024]],
+          [[25, 28, 31, 34], 1, 'DecoupledDetect', ['nc', 'anchors']]]
+    import copy
+    return dict(nc=nc, depth_multiple=depth, width_multiple=width, anchors=copy.deepcopy(anchors),
+                backbone=copy.deepcopy(bb), head=copy.deepcopy(hd))

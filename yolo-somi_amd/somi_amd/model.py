@@ -1,0 +1,185 @@
+"""`Model`: yaml -> SOMI layer graph -> forward on the MI355X, mirroring models/yolo.py:1164-1664.
+
+Same constructor (`Model(cfg, ch=3, nc=None, anchors=None)`), same attributes callers use (`.stride`, `.names`, `.nc`,
+`.hyp`, `.yaml`, `.model[-1].{nl,na,nc,anchors,stride}`, `.fuse()`), same outputs: eval -> `(z (B,N,no), [raw_l])`,
+raw_l = (B,na,ny,nx,no).  Input is the reference's `(B,3,H,W)` NCHW batch, either float32 already divided by 255
+(train.py:249) or uint8 (the /255 then happens in the ingest kernel).  Only module names SURVEY.md section 8a lists
+are accepted.
+"""
+import math
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+import yaml
+
+from . import blocks as B
+from . import ops
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+_CH = {'Conv': B.Conv, 'SPPF': B.SPPF, 'C2fCBAM': B.C2fCBAM, 'SEAM': B.SEAM}
+_ALIASES = {'C2fEACBAM': 'C2fCBAM'}     # undefined in the reference (SURVEY "five facts" #2); documented substitution
+
+
+def parse_model(d, ch):
+    """models/yolo.py:1453-1664 for the SOMI module set."""
+    anchors, nc, gd, gw = d['anchors'], d['nc'], d['depth_multiple'], d['width_multiple']
+    na = (len(anchors[0]) // 2) if isinstance(anchors, list) else anchors
+    no = na * (nc + 5)
+    layers, save, c2 = [], [], ch[-1]
+    consts = {'None': None, 'nc': nc, 'anchors': anchors, 'True': True, 'False': False}
+    for i, (f, n, name, args) in enumerate(d['backbone'] + d['head']):
+        name = _ALIASES.get(name, name)
+        args = [consts.get(a, a) if isinstance(a, str) else a for a in args]
+        n = max(round(n * gd), 1) if n > 1 else n
+        if name in _CH:
+            m = _CH[name]
+            c1, c2 = ch[f], args[0]
+            if c2 != no:
+                c2 = make_divisible(c2 * gw, 8)
+            args = [c1, c2, *args[1:]]
+            if name == 'C2fCBAM':
+                args.insert(2, n)
+                n = 1
+        elif name == 'ODConv_3rd':
+            m = B.ODConv_3rd
+            c1, c2 = ch[f], args[0]
+            if c2 != no:
+                c2 = make_divisible(c2 * gw, 8)
+            args = [c1, c2, *args[1:]]
+        elif name == 'BiFPN':
+            m = B.BiFPN
+            args = [len(f)]
+        elif name == 'nn.Upsample':
+            m = B.Upsample
+            c2 = ch[f]
+        elif name == 'DecoupledDetect':
+            m = B.DecoupledDetect
+            args.append([ch[x] for x in f])
+            if isinstance(args[1], int):
+                args[1] = [list(range(args[1] * 2))] * len(f)
+        else:
+            raise NotImplementedError(f'module {name!r} is outside the SOMI hot path (SURVEY.md section 8a)')
+        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        m_.i, m_.f, m_.type = i, f, name
+        m_.np = sum(p.numel() for p in m_.parameters())
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+class Model(nn.Module):
+    def __init__(self, cfg='yolov5s.yaml', ch=3, nc=None, anchors=None):
+        super().__init__()
+        if isinstance(cfg, dict):
+            self.yaml = deepcopy(cfg)
+        else:
+            with open(cfg, errors='ignore') as fh:
+                self.yaml = yaml.safe_load(fh)
+        ch = self.yaml['ch'] = self.yaml.get('ch', ch)
+        if ch != 3:
+            raise NotImplementedError('the ingest kernel packs 3-channel images')
+        if nc and nc != self.yaml['nc']:
+            self.yaml['nc'] = nc
+        if anchors:
+            self.yaml['anchors'] = round(anchors)
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=[ch])
+        self.names = [str(i) for i in range(self.yaml['nc'])]
+        self.nc = self.yaml['nc']
+        self.inplace = self.yaml.get('inplace', False)
+        det = self.model[-1]
+        if not isinstance(det, B.DecoupledDetect):
+            raise NotImplementedError('only the DecoupledDetect head is on the SOMI path')
+        # the reference probes strides with a 256x256 zero image (models/yolo.py:1209-1216); the SOMI graph's strides
+        # follow from its stride-2 layers, computed here without a device
+        det.stride = torch.tensor(self._probe_strides())
+        self._check_anchor_order(det)
+        det.anchors /= det.stride.view(-1, 1, 1)
+        self.stride = det.stride
+        self._initialize_dh_biases()
+        for m in self.modules():                                 # utils/torch_utils.py:165-174
+            if type(m) is nn.BatchNorm2d:
+                m.eps, m.momentum = 1e-3, 0.03
+
+    # ---------------------------------------------------------------------------------------------- construction
+    def _probe_strides(self):
+        red = []                                                 # spatial reduction factor of every layer's output
+        for m in self.model:
+            src = m.f if isinstance(m.f, int) else m.f[0]
+            r = 1.0 if m.i == 0 else (red[m.i - 1] if src == -1 else red[src])
+            if isinstance(m, B.Conv):
+                r *= m.conv.stride[0]
+            elif isinstance(m, B.ODConv_3rd):
+                r *= m.conv.stride
+            elif isinstance(m, B.Upsample):
+                r /= 2
+            red.append(r)
+        return [float(red[j]) for j in self.model[-1].f]
+
+    @staticmethod
+    def _check_anchor_order(m):
+        """utils/autoanchor.py:16-22."""
+        a = m.anchors.prod(-1).view(-1)
+        if (a[-1] - a[0]).sign() != (m.stride[-1] - m.stride[0]).sign():
+            m.anchors[:] = m.anchors.flip(0)
+
+    def _initialize_dh_biases(self, cf=None):
+        """models/yolo.py:1334-1345."""
+        det = self.model[-1]
+        for mi, s in zip(det.m, det.stride):
+            b = mi.b3.bias.view(det.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            mi.b3.bias = nn.Parameter(b.view(-1), requires_grad=True)
+            mi._b3.conv = mi.b3
+            b = mi.c3.bias.data
+            b += math.log(0.6 / (det.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
+            mi.c3.bias = nn.Parameter(b, requires_grad=True)
+
+    # ---------------------------------------------------------------------------------------------- state handling
+    def invalidate(self):
+        """Drop the device-side packed weights (call after changing parameters in place)."""
+        for m in self.modules():
+            if hasattr(m, 'invalidate') and m is not self:
+                m.invalidate()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate()
+        return r
+
+    def train(self, mode=True):
+        self.invalidate()
+        return super().train(mode)
+
+    def fuse(self):
+        """models/yolo.py:1413-1428.  Conv+BN are always folded at pack time on this path, so fuse() only has to keep
+        the reference's contract (returns self, eval semantics unchanged)."""
+        return self
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def forward(self, x, augment=False, profile=False, visualize=False):
+        if augment:
+            raise NotImplementedError('TTA (_forward_augment, models/yolo.py:1253-1267) is outside the hot path')
+        return self._forward_once(x)
+
+    def _forward_once(self, x):
+        """models/yolo.py:1269-1290: walk the layers with the skip list."""
+        if not x.is_cuda:
+            raise RuntimeError('somi_amd.Model runs on the MI355X only (no CPU fallback); move the batch to cuda')
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f'expected a (B,3,H,W) batch, got {tuple(x.shape)}')
+        a = B.Act(ops.image_to_nhwc4(x.contiguous(), scale=1.0 / 255.0 if x.dtype == torch.uint8 else 1.0), 0, 3)
+        y = []
+        for m in self.model:
+            if m.f != -1:
+                a = y[m.f] if isinstance(m.f, int) else [a if j == -1 else y[j] for j in m.f]
+            a = m(a)
+            y.append(a if m.i in self.save else None)
+        return a

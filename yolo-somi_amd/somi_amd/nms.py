@@ -1,0 +1,40 @@
+"""`non_max_suppression` with the reference's signature (utils/general.py:629-630), executed by somi_nms_f32.
+
+Returns a list of (n_i, 6) [x1, y1, x2, y2, conf, cls] tensors on the prediction's device.  One device->host copy of
+the per-image counts happens at the end (the reference syncs per image inside its Python loop, and val.py:189 copies
+results to the CPU anyway).  `labels` (a-priori boxes for autolabelling) are not on the hot path.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _ptr, _stream
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=(), max_det=300):
+    assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
+    assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
+    if labels:
+        raise NotImplementedError('a-priori labels (utils/general.py:651-658) are outside the hot path')
+    if not prediction.is_cuda:
+        raise RuntimeError('somi_amd NMS runs on the MI355X only (no CPU fallback)')
+    if prediction.dtype != torch.float32 or not prediction.is_contiguous():
+        raise RuntimeError('prediction tensor has to be contiguous float32')
+    B, n, no = prediction.shape
+    nc = no - 5
+    ml = bool(multi_label) and nc > 1
+    mask = 0xFFFFFFFFFFFFFFFF
+    if classes is not None:
+        mask = 0
+        for c in classes:
+            mask |= 1 << int(c)
+    L = _lib.lib()
+    nbytes = L.somi_nms_workspace_bytes(B, n, nc, int(ml))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=prediction.device)
+    det = torch.empty(B, max_det, 6, dtype=torch.float32, device=prediction.device)
+    count = torch.empty(B, dtype=torch.int32, device=prediction.device)
+    check(L.somi_nms_f32(_ptr(prediction), B, n, nc, float(conf_thres), float(iou_thres), int(ml), int(bool(agnostic)), mask,
+                         int(max_det), _ptr(det), _ptr(count), _ptr(ws), nbytes, _stream()), 'non_max_suppression')
+    counts = count.cpu().tolist()
+    return [det[b, :counts[b]] for b in range(B)]

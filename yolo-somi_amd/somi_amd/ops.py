@@ -10,6 +10,8 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, check
 
+PROFILE = None   # bench.py sets this to a list: every conv launch appends (kernel name, algorithmic FLOPs, ev0, ev1)
+
 ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4}
 
 
@@ -37,7 +39,7 @@ def conv_out_size(size, k, s, p, d=1):
 
 def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', cin=None, x_coff=0, out=None,
                 cout=None, y_coff=0, post_scale=None, post_shift=None, residual=None, res_coff=0, a_chan_scale=None,
-                a_pix_scale=None, per_sample_w=False):
+                a_pix_scale=None, per_sample_w=False, alg_cin=None, alg_cout=None):
     """x (B,H,W,x_cs) NHWC; w packed [n_sets][Cout][kh*kw*Cin]; returns / fills out (B,Ho,Wo,y_cs)."""
     B, H, W, x_cs = x.shape
     cin = x_cs - x_coff if cin is None else cin
@@ -56,7 +58,16 @@ def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', 
     d.act, d.per_sample_w = ACT[act], int(per_sample_w)
     if w.numel() != (B if per_sample_w else 1) * cout * kh * kw * cin:
         raise RuntimeError(f'weight has {w.numel()} elements, expected {(B if per_sample_w else 1) * cout * kh * kw * cin}')
+    if PROFILE is None:
+        check(_lib.lib().somi_conv2d_nhwc_f32(C.byref(d), _stream()), 'conv2d_nhwc')
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                                               # torch's current stream == the stream the kernel runs on
     check(_lib.lib().somi_conv2d_nhwc_f32(C.byref(d), _stream()), 'conv2d_nhwc')
+    e1.record()
+    name = _lib.lib().somi_conv2d_kernel_name(C.byref(d)).decode()
+    flops = 2.0 * B * Ho * Wo * (alg_cout or cout) * (alg_cin or cin) * kh * kw
+    PROFILE.append((name, flops, e0, e1))
     return out
 
 
@@ -175,3 +186,16 @@ def detect_decode(box, cls, anchors_px, stride, na, nc, raw=None, z=None, total=
     a = (C.c_float * (na * 2))(*[float(v) for v in anchors_px])
     check(_lib.lib().somi_detect_decode_f32(_ptr(_f32c(box)), box_cs, _ptr(_f32c(cls)), cls.shape[3], a, float(stride),
                                             _ptr(raw), _ptr(z), B, ny, nx, na, nc, total, row_off, _stream()), 'detect_decode')
+
+
+def odconv_weights(gap, fc_w, fc_b, pk, wout, bout, cin, cin_pad, cout, kk, K):
+    """Attention heads + per-sample weight synthesis of ODConv (models/common.py:4557-4590), outer BN folded in."""
+    B = gap.shape[0]
+    hid = fc_w.shape[0]
+    ws = torch.empty(B * (cout + kk + cin + K), device=gap.device, dtype=torch.float32)
+    check(_lib.lib().somi_odconv_weights_f32(_ptr(gap), _ptr(fc_w), _ptr(fc_b), _ptr(pk['Wf']), _ptr(pk['bf']), _ptr(pk['Ws']),
+                                             _ptr(pk['bs']), _ptr(pk['Wc']), _ptr(pk['bc']), _ptr(pk['Ww']), _ptr(pk['bw']),
+                                             _ptr(pk['Wk']), _ptr(pk['biask']), _ptr(pk['bn_s']), _ptr(pk['bn_t']),
+                                             _ptr(wout), _ptr(bout), _ptr(ws), B, cin, cin_pad, cout, kk, K, hid, _stream()),
+          'odconv_weights')
+    return wout, bout
