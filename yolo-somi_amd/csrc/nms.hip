@@ -4,8 +4,9 @@
 //   1. count   candidates per 1024-row chunk           (obj > thr, then obj*cls > thr per class / best class)
 //   2. scan    chunk counts -> offsets                  (compaction order == prediction order: box-major, class-minor)
 //   3. emit    key = ~bits(score), val = row*nc + cls   (8 B per candidate; boxes are re-derived from `pred` when needed)
-//   4. sort    stable LSD radix sort, 4-bit digits, one workgroup per image (ties keep prediction order - the oracle's
-//              stable descending sort); only the first max_nms = 30000 sorted entries are used (:688-689)
+//   4. select  three-level radix select of the exact top max_nms = 30000 (:688-689) + order-preserving compaction
+//      sort    parallel rank sort of the <= 30000 survivors, stable (ties keep prediction order = the oracle's
+//              stable descending sort)
 //   5. greedy  512 candidates per round: test against the kept list (LDS), build the round's 512x512 suppression bit
 //              matrix, resolve it serially in one wave, append survivors; stop at max_det kept (:696-697).
 // IoU arithmetic is written with explicit round-to-nearest intrinsics (no FMA contraction) in the oracle's operation
@@ -138,73 +139,195 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
     if (threadIdx.x == 0) a.total[b] = carry;
 }
 
-// ------------------------------------------------------------------------------------------------ radix sort
-// One workgroup (1024 threads = 16 waves) per image; 8 passes of 4 bits; stable.
-__global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
-    __shared__ int hist[16];            // digit totals -> exclusive bases (running, advanced tile by tile)
-    __shared__ int wcnt[16][16];        // [wave][digit] counts of the current tile
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ------------------------------------------------------------------------------------------------ top-k select
+// Only the first max_nms = 30000 entries of the (score desc, prediction order) ranking are used (general.py:688-689).
+// A three-level radix select (12 + 12 + 8 key bits, histograms in LDS then merged with global atomics) finds the
+// exact 32-bit threshold key T of the 30000-th entry; an order-preserving compaction then keeps every entry with
+// key < T plus the first r entries with key == T.  Images with <= 30000 candidates skip all of this.
+constexpr int SEL_CHUNK = 4096;      // candidates per select workgroup (256 threads x 16)
+
+struct SelState {                    // per image, in global memory (zeroed every call)
+    int hist1[4096];
+    int hist2[4096];
+    int hist3[256];
+};
+
+// exclusive prefix search over a histogram in global memory by one workgroup of 256 threads:
+// returns the first bin whose inclusive cumulative count exceeds `need` (0-based rank), and the count before it.
+__device__ __forceinline__ void find_bin(const int *hist, int nbins, int need, int *bin_out, int *before_out, int *lds) {
+    // lds: >= 260 ints
+    const int tid = threadIdx.x;
+    const int per = nbins / 256;                   // 16 or 1
+    int s = 0;
+    for (int i = 0; i < per; ++i) s += hist[tid * per + i];
+    int tot;
+    const int pre = block_exscan_256(s, &tot, lds);
+    __shared__ int res[2];
+    if (need >= pre && need < pre + s) {           // exactly one thread
+        int run = pre;
+        for (int i = 0; i < per; ++i) {
+            const int c = hist[tid * per + i];
+            if (need < run + c) { res[0] = tid * per + i; res[1] = run; break; }
+            run += c;
+        }
+    }
+    __syncthreads();
+    *bin_out = res[0];
+    *before_out = res[1];
+    __syncthreads();
+}
+
+// level 1/2/3 histogram kernels: grid (nsel_chunks, B)
+template <int LEVEL>
+__global__ __launch_bounds__(256) void nms_select_hist_kernel(const NmsArgs a, SelState *st) {
+    __shared__ int lh[4096];
+    __shared__ int lds[264];
+    const int b = blockIdx.y;
     const int n = a.total[b];
-    if (n <= 1) return;
-    uint32_t *k0 = a.keyA + (size_t)b * a.cap, *v0 = a.valA + (size_t)b * a.cap;
-    uint32_t *k1 = a.keyB + (size_t)b * a.cap, *v1 = a.valB + (size_t)b * a.cap;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = pass * 4;
-        if (tid < 16) hist[tid] = 0;
-        __syncthreads();
-        // (a) digit histogram of the whole segment: per-wave ballot counts, one LDS atomic per wave and digit
-        for (int i0 = 0; i0 < n; i0 += 1024) {
-            const int i = i0 + tid;
-            const bool ok = i < n;
-            const int dgt = ok ? (int)((k0[i] >> shift) & 15u) : 16;
-            for (int dd = 0; dd < 16; ++dd) {
-                const unsigned long long m = __ballot(dgt == dd);
-                if (lane == 0 && m) atomicAdd(&hist[dd], __popcll(m));
-            }
+    if (n <= MAX_NMS) return;
+    const int i0 = blockIdx.x * SEL_CHUNK;
+    if (i0 >= n) return;
+    SelState &S = st[b];
+    uint32_t prefix = 0;
+    if (LEVEL >= 2) {
+        int b1, bef1;
+        find_bin(S.hist1, 4096, MAX_NMS - 1, &b1, &bef1, lds);
+        prefix = (uint32_t)b1 << 20;
+        if (LEVEL == 3) {
+            int b2, bef2;
+            find_bin(S.hist2, 4096, MAX_NMS - 1 - bef1, &b2, &bef2, lds);
+            prefix |= (uint32_t)b2 << 8;
         }
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int dd = 0; dd < 16; ++dd) { const int c = hist[dd]; hist[dd] = run; run += c; }
+    }
+    constexpr int NB = LEVEL == 3 ? 256 : 4096;
+    for (int i = threadIdx.x; i < NB; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t *keys = a.keyA + (size_t)b * a.cap;
+    const int i1 = min(i0 + SEL_CHUNK, n);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const uint32_t k = keys[i];
+        if (LEVEL == 1) atomicAdd(&lh[k >> 20], 1);
+        else if (LEVEL == 2) { if ((k >> 20) == (prefix >> 20)) atomicAdd(&lh[(k >> 8) & 0xFFFu], 1); }
+        else { if ((k >> 8) == (prefix >> 8)) atomicAdd(&lh[k & 0xFFu], 1); }
+    }
+    __syncthreads();
+    int *gh = LEVEL == 1 ? S.hist1 : (LEVEL == 2 ? S.hist2 : S.hist3);
+    for (int i = threadIdx.x; i < NB; i += 256)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// threshold key T and number of ties r to take, recomputed by whoever needs them
+__device__ __forceinline__ void select_threshold(const SelState &S, uint32_t *T, int *r, int *lds) {
+    int b1, bef1, b2, bef2, b3, bef3;
+    find_bin(S.hist1, 4096, MAX_NMS - 1, &b1, &bef1, lds);
+    find_bin(S.hist2, 4096, MAX_NMS - 1 - bef1, &b2, &bef2, lds);
+    find_bin(S.hist3, 256, MAX_NMS - 1 - bef1 - bef2, &b3, &bef3, lds);
+    *T = ((uint32_t)b1 << 20) | ((uint32_t)b2 << 8) | (uint32_t)b3;
+    *r = MAX_NMS - (bef1 + bef2 + bef3);           // entries with key == T to keep (>= 1)
+}
+
+// order-preserving compaction in three steps (count -> scan -> write) over SEL_CHUNK-sized chunks.
+// sel_cnt[b][chunk] = {#key<T, #key==T}; after the scan kernel: exclusive prefixes.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void nms_select_compact_kernel(const NmsArgs a, const SelState *st, int2 *sel_cnt,
+                                                                 int nsel_chunk) {
+    __shared__ int lds[264];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int n = a.total[b];
+    if (n <= MAX_NMS) return;
+    const int i0 = chunk * SEL_CHUNK + threadIdx.x * 16;       // 16 consecutive candidates per thread
+    uint32_t T;
+    int r;
+    select_threshold(st[b], &T, &r, lds);
+    const uint32_t *keys = a.keyA + (size_t)b * a.cap;
+    const uint32_t *vals = a.valA + (size_t)b * a.cap;
+    uint32_t k[16];
+    int lt = 0, eq = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + e;
+        k[e] = i < n ? keys[i] : 0xFFFFFFFFu;
+        lt += (i < n && k[e] < T) ? 1 : 0;
+        eq += (i < n && k[e] == T) ? 1 : 0;
+    }
+    int tot_lt, tot_eq;
+    const int pre_lt = block_exscan_256(lt, &tot_lt, lds);
+    const int pre_eq = block_exscan_256(eq, &tot_eq, lds);
+    if (!WRITE) {
+        if (threadIdx.x == 0) sel_cnt[b * nsel_chunk + chunk] = make_int2(tot_lt, tot_eq);
+        return;
+    }
+    const int2 base = sel_cnt[b * nsel_chunk + chunk];          // exclusive prefixes over chunks
+    int eq_rank = base.y + pre_eq;                               // rank among ties, in prediction order
+    // destination: entries keep their relative order: position = (#selected before me)
+    // selected-before = lt_before + min(eq_before, r)
+    int lt_rank = base.x + pre_lt;
+    uint32_t *ok_ = a.keyB + (size_t)b * a.cap, *ov = a.valB + (size_t)b * a.cap;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + e;
+        if (i >= n) break;
+        const bool is_lt = k[e] < T, is_eq = k[e] == T;
+        if (is_lt || (is_eq && eq_rank < r)) {
+            const int pos = lt_rank + min(eq_rank, r);
+            ok_[pos] = k[e];
+            ov[pos] = vals[i];
         }
+        lt_rank += is_lt ? 1 : 0;
+        eq_rank += is_eq ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_select_scan_kernel(const NmsArgs a, int2 *sel_cnt, int nsel_chunk) {
+    __shared__ int lds[8];
+    __shared__ int carry[2];
+    const int b = blockIdx.x;
+    if (a.total[b] <= MAX_NMS) return;
+    if (threadIdx.x == 0) carry[0] = carry[1] = 0;
+    __syncthreads();
+    const int used = (a.total[b] + SEL_CHUNK - 1) / SEL_CHUNK;
+    for (int c0 = 0; c0 < used; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        const int2 v = c < used ? sel_cnt[b * nsel_chunk + c] : make_int2(0, 0);
+        int tx, ty;
+        const int px = block_exscan_256(v.x, &tx, lds);
+        const int py = block_exscan_256(v.y, &ty, lds);
+        if (c < used) sel_cnt[b * nsel_chunk + c] = make_int2(carry[0] + px, carry[1] + py);
         __syncthreads();
-        // (b) stable scatter, tile by tile in order
-        for (int i0 = 0; i0 < n; i0 += 1024) {
-            const int i = i0 + tid;
-            const bool ok = i < n;
-            uint32_t key = 0, val = 0;
-            if (ok) { key = k0[i]; val = v0[i]; }
-            const int dgt = ok ? (int)((key >> shift) & 15u) : 16;
-            // lanes of this wave with my digit
-            unsigned long long peers = 0;
-            for (int dd = 0; dd < 16; ++dd) {
-                const unsigned long long m = __ballot(dgt == dd);
-                if (dgt == dd) peers = m;
-                if (lane == 0) wcnt[wave][dd] = __popcll(m);
-            }
-            __syncthreads();
-            int before = 0;                                  // same digit in earlier waves of this tile
-            if (ok) {
-                for (int w = 0; w < wave; ++w) before += wcnt[w][dgt];
-                const int pos = hist[dgt] + before + __popcll(peers & lt_mask);
-                k1[pos] = key;
-                v1[pos] = val;
-            }
-            __syncthreads();
-            if (tid < 16) {                                  // advance the running bases past this tile
-                int s = 0;
-                for (int w = 0; w < 16; ++w) s += wcnt[w][tid];
-                hist[tid] += s;
-            }
-            __syncthreads();
-        }
-        uint32_t *t = k0; k0 = k1; k1 = t;
-        t = v0; v0 = v1; v1 = t;
-        __threadfence_block();
+        if (threadIdx.x == 0) { carry[0] += tx; carry[1] += ty; }
         __syncthreads();
     }
-    // 8 passes: the sorted data is back in keyA / valA
+}
+
+// ------------------------------------------------------------------------------------------------ rank sort
+// Stable sort of the (<= 30000) selected entries by (key, position): every entry counts the entries that precede it.
+// grid (ceil(30000/256), B); the candidate keys stream through LDS in tiles of 2048.  O(n^2) compares spread over the
+// whole chip (n = 30000: 9e8 compares per image), deterministic, no atomics.  Output: sorted vals -> sortV.
+__global__ __launch_bounds__(256) void nms_rank_sort_kernel(const NmsArgs a, uint32_t *sortV) {
+    __shared__ uint32_t tile[2048];
+    const int b = blockIdx.y;
+    const int tot = a.total[b];
+    const bool sel = tot > MAX_NMS;
+    const int n = sel ? MAX_NMS : tot;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= n) return;
+    const uint32_t *keys = (sel ? a.keyB : a.keyA) + (size_t)b * a.cap;
+    const uint32_t *vals = (sel ? a.valB : a.valA) + (size_t)b * a.cap;
+    const uint32_t mine = i < n ? keys[i] : 0xFFFFFFFFu;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 2048) {
+        const int m = min(2048, n - j0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < m; t += 256) tile[t] = keys[j0 + t];
+        __syncthreads();
+        // entries before me in position with key <= mine, entries after me with key < mine
+        const int split = min(max(i - j0, 0), m);          // tile positions [0,split) precede me
+        int cnt = 0;
+        for (int t = 0; t < split; ++t) cnt += tile[t] <= mine ? 1 : 0;
+        for (int t = split; t < m; ++t) cnt += tile[t] < mine ? 1 : 0;
+        rank += cnt;
+    }
+    if (i < n) sortV[(size_t)b * MAX_NMS + rank] = vals[i];
 }
 
 // ------------------------------------------------------------------------------------------------ greedy NMS
@@ -219,7 +342,7 @@ __device__ __forceinline__ bool iou_gt(const BoxO &p, const BoxO &q, float thr) 
     return iou > thr;
 }
 
-__global__ __launch_bounds__(ROUND) void nms_greedy_kernel(const NmsArgs a) {
+__global__ __launch_bounds__(ROUND) void nms_greedy_kernel(const NmsArgs a, const uint32_t *sortV) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     BoxO *kept = reinterpret_cast<BoxO *>(smem);                         // [max_det]
     BoxO *cand = kept + a.max_det;                                       // [ROUND]
@@ -230,7 +353,7 @@ __global__ __launch_bounds__(ROUND) void nms_greedy_kernel(const NmsArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     int n = a.total[b];
     if (n > MAX_NMS) n = MAX_NMS;
-    const uint32_t *vals = a.valA + (size_t)b * a.cap;
+    const uint32_t *vals = sortV + (size_t)b * MAX_NMS;
     const float *img = a.pred + (size_t)b * a.n * a.no;
     float *det = a.det + (size_t)b * a.max_det * 6;
     if (tid == 0) nk_sh = 0;
@@ -334,7 +457,10 @@ extern "C" size_t somi_nms_workspace_bytes(int B, int n, int nc, int multi_label
     if (B <= 0 || n <= 0 || nc <= 0) return 0;
     const size_t nchunk = (size_t)(n + NMS_CHUNK - 1) / NMS_CHUNK;
     const size_t cap = (size_t)n * (size_t)((multi_label && nc > 1) ? nc : 1);
-    return align_up((size_t)B * nchunk * 4, 256) * 2 + align_up((size_t)B * 4, 256) + align_up((size_t)B * cap * 4, 256) * 4;
+    const size_t nsel_chunk = (cap + SEL_CHUNK - 1) / SEL_CHUNK;
+    return align_up((size_t)B * nchunk * 4, 256) * 2 + align_up((size_t)B * 4, 256) + align_up((size_t)B * cap * 4, 256) * 4 +
+           align_up((size_t)B * sizeof(SelState), 256) + align_up((size_t)B * nsel_chunk * sizeof(int2), 256) +
+           align_up((size_t)B * MAX_NMS * 4, 256);
 }
 
 extern "C" int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_thres, float iou_thres, int multi_label,
@@ -365,14 +491,26 @@ extern "C" int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_
     a.keyA = reinterpret_cast<uint32_t *>(w); w += s_buf;
     a.valA = reinterpret_cast<uint32_t *>(w); w += s_buf;
     a.keyB = reinterpret_cast<uint32_t *>(w); w += s_buf;
-    a.valB = reinterpret_cast<uint32_t *>(w);
+    a.valB = reinterpret_cast<uint32_t *>(w); w += s_buf;
+    const int nsel_chunk = (a.cap + SEL_CHUNK - 1) / SEL_CHUNK;
+    SelState *st = reinterpret_cast<SelState *>(w); w += align_up((size_t)B * sizeof(SelState), 256);
+    int2 *sel_cnt = reinterpret_cast<int2 *>(w); w += align_up((size_t)B * nsel_chunk * sizeof(int2), 256);
+    uint32_t *sortV = reinterpret_cast<uint32_t *>(w);
     a.det = det; a.count = count;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(nms_count_emit_kernel<false>, dim3(a.nchunk, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(nms_count_emit_kernel<true>, dim3(a.nchunk, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, s, a);
+    // top-30000 select (every kernel exits at once for images with <= 30000 candidates)
+    (void)hipMemsetAsync(st, 0, (size_t)B * sizeof(SelState), s);
+    hipLaunchKernelGGL(nms_select_hist_kernel<1>, dim3(nsel_chunk, B), dim3(256), 0, s, a, st);
+    hipLaunchKernelGGL(nms_select_hist_kernel<2>, dim3(nsel_chunk, B), dim3(256), 0, s, a, st);
+    hipLaunchKernelGGL(nms_select_hist_kernel<3>, dim3(nsel_chunk, B), dim3(256), 0, s, a, st);
+    hipLaunchKernelGGL(nms_select_compact_kernel<false>, dim3(nsel_chunk, B), dim3(256), 0, s, a, st, sel_cnt, nsel_chunk);
+    hipLaunchKernelGGL(nms_select_scan_kernel, dim3(B), dim3(256), 0, s, a, sel_cnt, nsel_chunk);
+    hipLaunchKernelGGL(nms_select_compact_kernel<true>, dim3(nsel_chunk, B), dim3(256), 0, s, a, st, sel_cnt, nsel_chunk);
+    hipLaunchKernelGGL(nms_rank_sort_kernel, dim3((MAX_NMS + 255) / 256, B), dim3(256), 0, s, a, sortV);
     const size_t lds = (size_t)(max_det + ROUND) * sizeof(BoxO) + (size_t)ROUND * (ROUND / 32) * 4 + (ROUND / 32 + 2) * 4;
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(ROUND), lds, s, a);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(ROUND), lds, s, a, sortV);
     return launch_status("somi_nms_f32");
 }
