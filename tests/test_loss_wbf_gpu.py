@@ -1,0 +1,91 @@
+"""Loss and WBF kernels on the MI355X against reference-generated vectors (loss) and the CPU oracle (WBF)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def rel_close(got, want, rel=1e-3, what=''):
+    got, want = torch.as_tensor(got).detach().cpu().double(), torch.as_tensor(want).detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-12
+    assert err <= rel * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+class _M:
+    def __init__(self, anchors, hyp, nc=10):
+        class Det:
+            pass
+        d = Det()
+        d.anchors, d.nl, d.na, d.nc = anchors, anchors.shape[0], anchors.shape[1], nc
+        self.model, self.hyp = [d], hyp
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'empty', 'edge'])
+def test_compute_loss_matches_reference_vectors(golden, tag):
+    from somi_amd.configs import HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    g = golden('loss_' + tag)
+    crit = ComputeLoss(_M(T(g['anchors']), dict(HYP_VISDRONE)))
+    p = [T(g[f'p{i}']).cuda().requires_grad_(True) for i in range(4)]
+    loss, items = crit(p, T(g['targets']).cuda())
+    rel_close(loss, g['loss'], rel=1e-4, what='loss')
+    rel_close(items, g['items'], rel=1e-4, what='loss_items')
+    loss.backward()
+    for i in range(4):
+        rel_close(p[i].grad, g[f'g{i}'], rel=1e-3, what=f'd loss / d p[{i}]')
+    with torch.no_grad():                                        # value-only path (val.py:159-160)
+        l2, it2 = crit([t.detach() for t in p], T(g['targets']).cuda())
+    rel_close(l2, g['loss'], rel=1e-4, what='loss (no grad)')
+
+
+def test_compute_loss_rejects_disabled_branches():
+    from somi_amd.configs import HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    h = dict(HYP_VISDRONE, fl_gamma=1.5)
+    with pytest.raises(NotImplementedError):
+        ComputeLoss(_M(torch.ones(4, 4, 2), h))
+
+
+def _wbf_inputs(seed, nm=2, n=120):
+    rng = np.random.RandomState(seed)
+    boxes, scores, labels = [], [], []
+    base = rng.uniform(0.05, 0.8, (40, 2)).astype(np.float32)
+    for t in range(nm):
+        k = rng.randint(n // 2, n)
+        pick = rng.randint(0, 40, k)
+        xy = base[pick] + rng.normal(0, 0.004, (k, 2)).astype(np.float32)
+        wh = rng.uniform(0.02, 0.15, (k, 2)).astype(np.float32)
+        b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        b[:3] = b[:3, [2, 3, 0, 1]]                             # reversed corners
+        b[3] = [0.2, 0.2, 0.2, 0.5]                             # zero area
+        b[4] = [-0.1, 0.9, 0.3, 1.2]                            # needs clipping
+        s = rng.uniform(0.0, 1.0, k).astype(np.float32)
+        s[5:8] = s[5]                                           # score ties
+        boxes.append(b), scores.append(s), labels.append((pick % 10).astype(np.int64))
+    return boxes, scores, labels
+
+
+@pytest.mark.parametrize('seed,nm,weights', [(0, 2, None), (1, 3, [1.0, 2.0, 1.0]), (2, 1, None)])
+def test_wbf_matches_oracle(seed, nm, weights):
+    from oracle.somi_ref.wbf import weighted_boxes_fusion as oracle
+    from somi_amd.wbf import weighted_boxes_fusion
+    b, s, l = _wbf_inputs(seed, nm)
+    wb, wsc, wl = oracle([x.tolist() for x in b], [x.tolist() for x in s], [x.tolist() for x in l], weights=weights,
+                         iou_thr=0.67, skip_box_thr=0.01)       # wbf.py:34-35
+    gb, gs, gl = weighted_boxes_fusion(b, s, l, weights=weights, iou_thr=0.67, skip_box_thr=0.01)
+    assert gb.shape == wb.shape and len(gs) == len(wsc)
+    assert np.array_equal(gl, wl)                               # same clusters, same order
+    assert np.array_equal(gb, wb.astype(np.float32))            # coordinates bit-exact after the float32 store
+    assert np.array_equal(gs, wsc.astype(np.float32))
+
+
+def test_wbf_empty():
+    from somi_amd.wbf import weighted_boxes_fusion
+    gb, gs, gl = weighted_boxes_fusion([np.zeros((0, 4))], [np.zeros(0)], [np.zeros(0)])
+    assert gb.shape == (0, 4) and gs.shape == (0,) and gl.shape == (0,)
+    gb, gs, gl = weighted_boxes_fusion([np.array([[0.1, 0.1, 0.2, 0.2]])], [np.array([0.001])], [np.array([1])], skip_box_thr=0.01)
+    assert gb.shape == (0, 4)

@@ -1,0 +1,93 @@
+"""`ComputeLoss` with the reference's interface (utils/loss.py:112-208) on top of somi_yolo_loss_f32.
+
+`ComputeLoss(model)(p, targets) -> (loss[1], loss_items[3] detached)`; p is the list of (B,na,ny,nx,no) training
+outputs, targets (nt,6) = [image, class, x, y, w, h] normalised.  The loss value and d loss / d p come out of the same
+fused launches; autograd sees one node.  hyp keys read: cls_pw, obj_pw, fl_gamma, slide_ratio, nwdloss, box, obj, cls,
+anchor_t (+label_smoothing) - the ones the reference's __init__ reads; the branches hyp.VisDrone.yaml leaves off
+(focal, slide, NWD, autobalance) raise NotImplementedError.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import LossDesc, check
+from .ops import _ptr, _stream
+
+
+def smooth_BCE(eps=0.1):
+    """utils/loss.py:14-15."""
+    return 1.0 - 0.5 * eps, 0.5 * eps
+
+
+class _AttachGrad(torch.autograd.Function):
+    """Makes the pre-computed d loss / d p an autograd edge from the loss to the prediction tensors."""
+
+    @staticmethod
+    def forward(ctx, loss, grads, *p):
+        ctx.grads = grads
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        return (None, None) + tuple(g * go for g in ctx.grads)
+
+
+class ComputeLoss:
+    def __init__(self, model, autobalance=False):
+        self.sort_obj_iou = False
+        h = model.hyp
+        if autobalance or h['fl_gamma'] > 0 or h['slide_ratio'] > 0 or h['nwdloss'] > 0:
+            raise NotImplementedError('focal / slide / NWD / autobalance are off in hyp.VisDrone.yaml and not on the HIP path')
+        det = model.model[-1]
+        self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
+        self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, 0.02])       # utils/loss.py:135
+        self.gr, self.hyp, self.autobalance = 1.0, h, autobalance
+        self.na, self.nc, self.nl, self.anchors = det.na, det.nc, det.nl, det.anchors
+        if self.nl > 4:
+            raise NotImplementedError('at most 4 detection levels')
+        self._anc = None
+
+    def _anchors(self, dev):
+        if self._anc is None or self._anc.device != dev:
+            self._anc = self.anchors.detach().float().contiguous().to(dev)
+        return self._anc
+
+    def _launch(self, p, targets, need_grad):
+        d = LossDesc()
+        grads = []
+        for i, t in enumerate(p):
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise RuntimeError('prediction tensors have to be float32 on the GPU (no CPU fallback)')
+            d.p[i] = _ptr(t)
+            g = torch.empty_like(t) if need_grad else None
+            grads.append(g)
+            d.grad[i] = _ptr(g)
+            d.ny[i], d.nx[i] = t.shape[2], t.shape[3]
+        dev = p[0].device
+        tg = targets.detach().to(dev).float().contiguous()
+        d.nl, d.na, d.nc, d.B, d.nt = len(p), self.na, self.nc, p[0].shape[0], tg.shape[0]
+        d.targets, d.anchors = (_ptr(tg) if tg.numel() else None), _ptr(self._anchors(dev))
+        for i in range(len(p)):
+            d.balance[i] = self.balance[i]
+        h = self.hyp
+        d.box_gain, d.obj_gain, d.cls_gain = float(h['box']), float(h['obj']), float(h['cls'])
+        d.cls_pw, d.obj_pw, d.anchor_t = float(h['cls_pw']), float(h['obj_pw']), float(h['anchor_t'])
+        d.cp, d.cn, d.gr = float(self.cp), float(self.cn), float(self.gr)
+        L = _lib.lib()
+        nbytes = L.somi_loss_workspace_bytes(C.byref(d))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        check(L.somi_yolo_loss_f32(C.byref(d), _ptr(out), _ptr(ws), nbytes, _stream()), 'ComputeLoss')
+        return out, grads
+
+    def __call__(self, p, targets):
+        if len(p) != self.nl:
+            raise RuntimeError(f'expected {self.nl} prediction levels, got {len(p)}')
+        need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in p)
+        pc = [t.detach().contiguous() for t in p]
+        out, grads = self._launch(pc, targets, need_grad)
+        loss = out[0:1]
+        if need_grad:
+            loss = _AttachGrad.apply(loss, grads, *p)
+        return loss, out[1:4].detach()
