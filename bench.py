@@ -124,7 +124,7 @@ def main():
     if rank == 0:
         # dominant kernel = the conv tile variant with the largest total time
         by = {}
-        for name, flops, e0, e1 in prof:
+        for name, flops, e0, e1, _ in prof:
             d = by.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops

@@ -154,6 +154,12 @@ int somi_chan_stats_nhwc_f32(const float *x, int x_cs, int x_coff, const float *
 int somi_spatial_attn_f32(const float *stats, const float *w, float bias, float *sa, int B, int H, int W, int k,
                           somi_stream_t stream);
 
+/* CBAM apply in one pass: sa = sigmoid(conv_kxk(stats) + bias); y = x * ca[b][c] * sa[b,h,w] (models/common.py:686-688:
+ * `out = channel_attention(x2) * x2; out = spatial_attention(out) * out`).  x / y are channel slices; in place allowed. */
+int somi_cbam_apply_nhwc_f32(const float *x, int x_cs, int x_coff, const float *ca, const float *stats, const float *w,
+                             float bias, float *y, int y_cs, int y_coff, int B, int H, int W, int C, int k,
+                             somi_stream_t stream);
+
 /* y = x * s[b][c] (SEAM output x*exp(fc), models/common.py:8489-8490; also materialised CBAM scaling). In place allowed. */
 int somi_scale_channels_nhwc_f32(const float *x, const float *s, const float *pix, float *y, int B, int HW, int C,
                                  somi_stream_t stream);

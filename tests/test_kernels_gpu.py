@@ -89,6 +89,12 @@ def test_conv_igemm(case):
         torch.cuda.synchronize()
         assert (out[..., :16] == 7.0).all() and (out[..., 16 + Cout:] == 7.0).all()
         got = out[..., 16:16 + Cout]
+    elif Cout % 4:                                          # ragged Cout: the output row stride must still be 16 B aligned
+        out = torch.full((B, want.shape[2], want.shape[3], (Cout + 3) // 4 * 4), 7.0, device=d)
+        ops.conv2d_nhwc(xd, pack_conv_weight(w).to(d), bias.to(d), kh=k, kw=k, stride=s, pad=p, act=act, out=out, cout=Cout, **kw)
+        torch.cuda.synchronize()
+        assert (out[..., Cout:] == 7.0).all()
+        got = out[..., :Cout]
     else:
         got = ops.conv2d_nhwc(xd, pack_conv_weight(w).to(d), bias.to(d), kh=k, kw=k, stride=s, pad=p, act=act,
                               per_sample_w=bool(ex.get('per_sample')), **kw)
@@ -182,6 +188,10 @@ def test_attention_pieces():
     rel_close(sa, want_sa, rel=1e-5, what='spatial attention')
     got = ops.scale_channels(nhwc(x).to(d), ca, sa)
     rel_close(got, nhwc(xs * want_sa[:, None]), rel=1e-5, what='scale')
+    wd = wide.to(d)                                          # fused stats->sigmoid(conv7x7)->scale, in place on a channel slice
+    ops.cbam_apply_(wd, ca, stats, w7[0].permute(1, 2, 0).contiguous().to(d), b7, 7, c=C, x_coff=16)
+    rel_close(wd[..., 16:16 + C], nhwc(xs * want_sa[:, None]), rel=1e-5, what='cbam apply')
+    assert torch.equal(wd[..., :16].cpu(), wide[..., :16]) and torch.equal(wd[..., 16 + C:].cpu(), wide[..., 16 + C:])
 
 
 def test_detect_decode():

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Per-kernel measurements on the MI355X (HIP events on the launch stream): DCNv3 forward/backward achieved HBM GB/s
+against the algorithmic bytes of SURVEY.md section 8d, and the conv-backbone (layers 0-9, 640x640, batch 64) fp32-MFMA TFLOP/s
+that BASELINE.json's north_star targets.  Prints one JSON object per line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'yolo-somi_amd')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+from somi_amd import ops  # noqa: E402
+from somi_amd.blocks import Act  # noqa: E402
+from somi_amd.configs import somi_cfg, SOMI_ANCHORS, fill_state  # noqa: E402
+from somi_amd.dcnv3 import dcnv3_forward, dcnv3_backward  # noqa: E402
+from somi_amd.model import Model  # noqa: E402
+
+HBM_PEAK = 8000.0      # GB/s spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+F32_PEAK = 157.3
+
+
+def timeit(fn, warm=3, iters=10):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def dcn(N, H, C=256, G=8, k=3, spread=2.0):
+    d = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(0)
+    K = k * k
+    x = torch.randn(N, H, H, C, device=d, generator=g)
+    off = torch.randn(N, H, H, G * K * 2, device=d, generator=g) * spread
+    m = torch.softmax(torch.randn(N, H, H, G, K, device=d, generator=g), -1).reshape(N, H, H, G * K).contiguous()
+    go = torch.randn(N, H, H, C, device=d, generator=g)
+    args = (k, k, 1, 1, 1, 1, 1, 1, G, C // G, 1.0)
+    tf = timeit(lambda: dcnv3_forward(x, off, m, *args, 256))
+    tb = timeit(lambda: dcnv3_backward(x, off, m, *args, go, 256))
+    px = N * H * H
+    bf, bb = 4 * (2 * C + 3 * G * K) * px, 4 * (4 * C + 6 * G * K) * px
+    for name, t, byt in (('dcnv3_fwd', tf, bf), ('dcnv3_bwd', tb, bb)):
+        print(json.dumps({'kernel': name, 'shape': f'N{N} {H}x{H} C{C} G{G} K{K} offsets~N(0,{spread})', 'ms': round(t * 1e3, 4),
+                          'algorithmic_GB': round(byt / 1e9, 4), 'achieved_GBps': round(byt / t / 1e9, 1),
+                          'frac_of_8TBps': round(byt / t / 1e9 / HBM_PEAK, 4)}), flush=True)
+
+
+def backbone(B=64, S=640):
+    d = torch.device('cuda')
+    model = fill_state(Model(somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS)), 1).to(d).eval()
+    imgs = torch.randint(0, 256, (B, 3, S, S), dtype=torch.uint8, device=d)
+
+    def run():
+        with torch.no_grad():
+            a = Act(ops.image_to_nhwc4(imgs), 0, 3)
+            for m in model.model[:10]:
+                a = m(a)
+        return a
+    run()
+    ops.PROFILE = prof = []
+    run()
+    torch.cuda.synchronize()
+    ops.PROFILE = None
+    flops = sum(p[1] for p in prof)
+    secs = sum(p[2].elapsed_time(p[3]) for p in prof) * 1e-3
+    t = timeit(run, warm=1, iters=3)
+    print(json.dumps({'kernel': 'conv backbone L0-9 (all conv launches)', 'shape': f'B{B} {S}x{S}', 'conv_launches': len(prof),
+                      'algorithmic_TFLOP': round(flops / 1e12, 3), 'conv_ms': round(secs * 1e3, 2),
+                      'achieved_TFLOPs': round(flops / secs / 1e12, 2), 'frac_of_f32_mfma_peak': round(flops / secs / 1e12 / F32_PEAK, 4),
+                      'backbone_wall_ms_incl_attention_kernels': round(t * 1e3, 2)}), flush=True)
+    by = {}
+    for name, fl, e0, e1, _ in prof:
+        v = by.setdefault(name, [0, 0.0, 0.0])
+        v[0] += 1; v[1] += fl; v[2] += e0.elapsed_time(e1) * 1e-3
+    for name, (c, fl, s) in sorted(by.items(), key=lambda kv: -kv[1][2]):
+        print(json.dumps({'kernel': name, 'launches': c, 'ms': round(s * 1e3, 2), 'TFLOPs': round(fl / s / 1e12, 2)}), flush=True)
+
+
+    if os.environ.get('SOMI_PER_LAUNCH'):
+        for name, fl, e0, e1, shp in prof:
+            t = e0.elapsed_time(e1) * 1e-3
+            print(json.dumps({'launch': name.split('<')[1][:-1], 'B,H,W,Cin,Cout,k,s,ps': shp, 'us': round(t * 1e6, 1),
+                              'TFLOPs': round(fl / t / 1e12, 1)}), flush=True)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['dcn', 'backbone']
+    if 'dcn' in which:
+        dcn(32, 80)
+        dcn(16, 160)
+        dcn(32, 80, spread=0.3)
+    if 'backbone' in which:
+        backbone()

@@ -1,67 +1,93 @@
 // NHWC implicit-GEMM convolution on the fp32 matrix cores of gfx950, with a fused epilogue.
 //
 // GEMM view:  M = B*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin with k = (r*kw+q)*Cin + c.
-//   A[m][k] = x[b, ho*s-p+r*d, wo*s-p+q*d, c]  (0 outside the image)  - gathered on the fly, never materialised
-//   B[k][n] = w[n][k]                                                     - weights pre-packed K-contiguous
+//   act[m][k] = x[b, ho*s-p+r*d, wo*s-p+q*d, c]  (0 outside the image) - gathered on the fly, never materialised
+//   wgt[n][k] = w[n][k]                                                  - weights pre-packed K-contiguous
 // Arithmetic: v_mfma_f32_32x32x2_f32 - exact fp32 products, fp32 accumulate (bit-for-bit an fmaf chain), so the
 // result matches the reference CPU path to fp32 rounding (MI355X_MICROARCH.md, FP32-input MFMA: 157 TFLOP/s peak).
 //
-// Workgroup = 256 threads = 4 waves (one per SIMD).  Block tile BM x BN, K-tile 32:
-//   global -> registers (16 B per lane, coalesced along c / k) -> LDS image [row][36] (32 k + 4 pad floats:
-//   16 B-aligned rows, conflict-free for both the ds_write_b128 staging store and the ds_read_b128 fragment load)
-//   -> each lane reads 4 consecutive k of one row per ds_read_b128 and feeds them to 4 consecutive MFMA k-steps.
-//   The k order inside a K-tile is permuted identically for A and B (lane half h of k-step t takes k = 8j+4h+t),
-//   which a sum over k does not care about.
-// The next K-tile's global loads are issued before the MFMAs of the current one and written to LDS after them
-// (register-staged software pipeline), 2-3 workgroups per CU cover the two barriers per K-tile.
+// Workgroup = 256 threads = 4 waves (one per SIMD), block tile BM x BN, K-tile 32, two workgroups per CU.
+//  * operand fetch: `buffer_load_dwordx4` through wave-uniform descriptors; padding taps, the M / N / K tails are mapped
+//    to an out-of-range offset so the hardware range check returns zeros - no branches, ~40 VALU per K-tile instead
+//    of ~200 with pointer arithmetic (PMC: 4.1 VALU per MFMA before, which phase-locked the two waves of a SIMD into
+//    issuing addresses together while the matrix pipe idled);
+//  * LDS image [row][36] floats (32 k + 4 pad: 16 B-aligned rows, conflict-free ds_write_b128 / ds_read_b128,
+//    SQ_LDS_BANK_CONFLICT = 0), DOUBLE buffered: tile t+1 is fetched to registers after the first quarter of tile t's
+//    MFMAs and written to the other buffer before the last quarter - one barrier per K-tile;
+//  * each lane reads 4 consecutive k of one row per ds_read_b128 and feeds them to 4 consecutive MFMA k-steps (the k
+//    order inside a K-tile is permuted identically for both operands: lane half h of k-step t takes k = 8j+4h+t);
+//  * the weights are the MFMA A operand and the activations the B operand, so the accumulator holds D[n][m] with
+//    m on the lane and 4 consecutive n per register quad: the epilogue (bias, activation, affine, residual) works on
+//    float4 and leaves as 16 B stores.
 //
 // Reference being replaced: F.conv2d + BatchNorm2d(eval) + SiLU in Conv.forward (models/common.py:64-70,
 // folded as utils/torch_utils.py:202-222), ODConv2d_3rd's grouped per-sample conv (models/common.py:4602-4605).
+#include <stdlib.h>
 #include "common.h"
 
 namespace somi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;          // K-tile (floats)
-constexpr int LDS_LD = BK + 4;  // LDS row stride in floats (144 B)
+constexpr int BK = 32;                    // K-tile (floats)
+constexpr int LDS_LD = BK + 4;            // LDS row stride in floats (144 B)
+constexpr unsigned OOB = 0xFFFFFFE0u;     // byte offset beyond every descriptor: the load returns 0
+constexpr unsigned OOB_BASE = 0xF0000000u;  // + any K offset (< 2^27) still beyond every descriptor
+constexpr unsigned MAX_BUF_BYTES = 0xE0000000u;
 
 struct ConvArgs {
     somi_conv_desc d;
     int M;        // rows per weight set: B*Ho*Wo, or Ho*Wo when per_sample_w (grid.z = B)
     int K;        // kh*kw*Cin
     int tiles_m, tiles_n;
+    unsigned x_bytes, w_bytes, chan_bytes, pix_bytes;
+    int stagger;  // s_sleep units (64 clk) for every second generation of workgroups
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ float fast_silu(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+
+// FAST: Cin % 32 == 0 (every K-tile lies inside one filter tap), kh*kw <= 32: the tap walk is wave-uniform (SALU), each
+// row's padding test is one bit of a mask built once, and a fetch costs 4 VALU per 16 B.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
-    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;     // float4 loads per thread per K-tile
+    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;     // 16 B loads per thread per K-tile (activations / weights)
+    constexpr int TILE = (BM + BN) * LDS_LD;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tiling");
 
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
-    float *As = lds, *Bs = lds + BM * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
 
     const somi_conv_desc &d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int ntile = a.tiles_m * a.tiles_n;
     const int tile = xcd_remap(blockIdx.x, ntile);
-    const int tile_m = tile / a.tiles_n, tile_n = tile % a.tiles_n;   // n fastest: neighbours share the A rows
+    const int tile_m = tile / a.tiles_n, tile_n = tile % a.tiles_n;   // n fastest: neighbours share the activation rows
     const int bz = blockIdx.z;                                        // weight set / image (per_sample_w)
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const float *__restrict__ wbase = d.w + (size_t)bz * d.Cout * a.K;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(MODULATE && d.a_chan_scale ? d.a_chan_scale : d.x), 0,
+                                                                        MODULATE && d.a_chan_scale ? a.chan_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(MODULATE && d.a_pix_scale ? d.a_pix_scale : d.x), 0,
+                                                                        MODULATE && d.a_pix_scale ? a.pix_bytes : 0, 0x00020000);
+    const bool has_chan = MODULATE && d.a_chan_scale, has_pix = MODULATE && d.a_pix_scale;
 
-    // ---- per-thread load geometry: float4 column kc (4 floats) of rows row0 + 32*i
+    // ---- per-thread fetch geometry: 16 B column kc of rows row0 + 32*i
     const int kc = (tid & 7) * 4, row0 = tid >> 3;
-    const float *a_base[A_ROWS];
-    int a_hi0[A_ROWS], a_wi0[A_ROWS];
-    const float *a_pix[A_ROWS];
-    const float *a_chan[A_ROWS];
+    int a_hi0[A_ROWS], a_wi0[A_ROWS], a_off[A_ROWS], a_pixi[A_ROWS], a_chn[A_ROWS];
     const int HoWo = d.Ho * d.Wo;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -71,58 +97,90 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
             const int ho = rem / d.Wo, wo = rem % d.Wo;
             a_hi0[i] = ho * d.stride - d.pad;
             a_wi0[i] = wo * d.stride - d.pad;
-            a_base[i] = d.x + (size_t)b * d.H * d.W * d.x_cs + d.x_coff;
-            if constexpr (MODULATE) {
-                a_pix[i] = d.a_pix_scale ? d.a_pix_scale + (size_t)b * d.H * d.W : nullptr;
-                a_chan[i] = d.a_chan_scale ? d.a_chan_scale + (size_t)b * d.Cin : nullptr;
-            }
+            a_pixi[i] = (b * d.H + a_hi0[i]) * d.W + a_wi0[i];           // pixel index of tap (0,0), may be "before" the image
+            a_off[i] = a_pixi[i] * d.x_cs + d.x_coff;
+            a_chn[i] = b * d.Cin;
         } else {
-            a_hi0[i] = -(1 << 28);   // forces the bounds test to fail -> zeros
-            a_wi0[i] = 0;
-            a_base[i] = d.x;
-            if constexpr (MODULATE) { a_pix[i] = nullptr; a_chan[i] = nullptr; }
+            a_hi0[i] = -(1 << 28);                                        // the bounds test fails for every tap -> zeros
+            a_wi0[i] = 0; a_pixi[i] = 0; a_off[i] = 0; a_chn[i] = 0;
         }
     }
-    const float *b_ptr[B_ROWS];
-    bool b_ok[B_ROWS];
+    unsigned b_off[B_ROWS];
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
         const int n = n0 + row0 + 32 * i;
-        b_ok[i] = n < d.Cout;
-        b_ptr[i] = wbase + (size_t)(b_ok[i] ? n : 0) * a.K + kc;
+        b_off[i] = n < d.Cout ? (unsigned)(((size_t)bz * d.Cout + n) * a.K + kc) * 4u : (FAST ? OOB_BASE : OOB);
     }
+    // FAST path state: per-row tap-validity masks and byte offsets with the thread's column folded in
+    unsigned a_mask[A_ROWS], a_offb[A_ROWS], a_pixb[A_ROWS], a_chnb[A_ROWS];
+    if constexpr (FAST) {
+        const int ntap = d.kh * d.kw;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            unsigned mk = 0;
+            for (int t = 0; t < ntap; ++t) {
+                const int hh = a_hi0[i] + (t / d.kw) * d.dil, ww = a_wi0[i] + (t % d.kw) * d.dil;
+                mk |= ((unsigned)hh < (unsigned)d.H && (unsigned)ww < (unsigned)d.W) ? (1u << t) : 0u;
+            }
+            a_mask[i] = mk;
+            a_offb[i] = (unsigned)(a_off[i] + kc) * 4u;
+            a_pixb[i] = (unsigned)a_pixi[i] * 4u;
+            a_chnb[i] = (unsigned)(a_chn[i] + kc) * 4u;
+        }
+    }
+    int tp_u = 0, c0_u = 0, r_u = 0, q_u = 0;                       // wave-uniform tap walk (FAST)
 
-    // k -> (tap r,q ; channel c) for this thread's float4 column, advanced incrementally per K-tile
+    // k -> (tap r,q ; channel c) for this thread's column, advanced incrementally per K-tile
     int k = kc, c = kc % d.Cin, tap = kc / d.Cin;
     int r = tap / d.kw, q = tap % d.kw;
 
     f32x4 ra[A_ROWS], rb[B_ROWS];
-    auto load_tile = [&]() {
+    auto fetch_tile = [&](int kt_next) {
+        if constexpr (FAST) {
+            const int dpix = (r_u * d.W + q_u) * d.dil;
+            const unsigned sd = (unsigned)(dpix * d.x_cs + c0_u) * 4u, bit = 1u << tp_u;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const bool ok = (a_mask[i] & bit) != 0;
+                f32x4 v = buf_load4(rx, ok ? a_offb[i] + sd : OOB);
+                if constexpr (MODULATE) {
+                    if (has_chan) v *= buf_load4(rc, ok ? a_chnb[i] + (unsigned)c0_u * 4u : OOB);
+                    if (has_pix) v *= buf_load1(rp, ok ? a_pixb[i] + (unsigned)dpix * 4u : OOB);
+                }
+                ra[i] = v;
+            }
+            const unsigned ko = (unsigned)kt_next * (BK * 4u);
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_off[i] + ko);
+            return;
+        }
         const bool kin = k < a.K;
         const int dh = r * d.dil, dw = q * d.dil;
+        const int dpix = dh * d.W + dw;
+        const int delta = dpix * d.x_cs + c;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
-            const bool ok = kin && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const size_t pix = (size_t)hi * d.W + wi;
-                v = *reinterpret_cast<const f32x4 *>(a_base[i] + pix * d.x_cs + c);
-                if constexpr (MODULATE) {
-                    if (a_chan[i]) v *= *reinterpret_cast<const f32x4 *>(a_chan[i] + c);
-                    if (a_pix[i]) v *= a_pix[i][pix];
-                }
+            const bool ok = kin && (unsigned)(a_hi0[i] + dh) < (unsigned)d.H && (unsigned)(a_wi0[i] + dw) < (unsigned)d.W;
+            f32x4 v = buf_load4(rx, ok ? (unsigned)(a_off[i] + delta) * 4u : OOB);
+            if constexpr (MODULATE) {
+                if (has_chan) v *= buf_load4(rc, ok ? (unsigned)(a_chn[i] + c) * 4u : OOB);
+                if (has_pix) v *= buf_load1(rp, ok ? (unsigned)(a_pixi[i] + dpix) * 4u : OOB);
             }
             ra[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kin && b_ok[i]) v = *reinterpret_cast<const f32x4 *>(b_ptr[i]);
-            rb[i] = v;
-        }
+        for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, (kin && b_off[i] != OOB) ? b_off[i] : OOB);
     };
     auto advance_k = [&]() {
+        if constexpr (FAST) {
+            c0_u += BK;
+            if (c0_u == d.Cin) {
+                c0_u = 0;
+                ++tp_u;
+                if (++q_u == d.kw) { q_u = 0; ++r_u; }
+            }
+            return;
+        }
         k += BK;
         c += BK;
         while (c >= d.Cin) {
@@ -130,83 +188,119 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
             if (++q == d.kw) { q = 0; ++r; }
         }
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) b_ptr[i] += BK;
+        for (int i = 0; i < B_ROWS; ++i) b_off[i] += (b_off[i] != OOB) ? BK * 4u : 0u;
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](float *buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i)
-            *reinterpret_cast<f32x4 *>(&As[(row0 + 32 * i) * LDS_LD + kc]) = ra[i];
+            *reinterpret_cast<f32x4 *>(&buf[(row0 + 32 * i) * LDS_LD + kc]) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i)
-            *reinterpret_cast<f32x4 *>(&Bs[(row0 + 32 * i) * LDS_LD + kc]) = rb[i];
+            *reinterpret_cast<f32x4 *>(&buf[(BM + row0 + 32 * i) * LDS_LD + kc]) = rb[i];
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[jn][i][e] = 0.f;
 
     const int nkt = (a.K + BK - 1) / BK;
     const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
-    const float *Aw = As + (wm * WM) * LDS_LD + frag_off;
-    const float *Bw = Bs + (wn * WN) * LDS_LD + frag_off;
+    const int aw_off = (wm * WM) * LDS_LD + frag_off;            // activation rows of this wave
+    const int bw_off = (BM + wn * WN) * LDS_LD + frag_off;       // weight rows of this wave
 
-    load_tile();
-    store_tile();
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            advance_k();
-            load_tile();           // in flight while the MFMAs below run
-        }
+    auto mma_group = [&](const float *buf, int j) {
+        f32x4 fa[TM], fb[TN];
 #pragma unroll
-        for (int j = 0; j < BK / 8; ++j) {
-            f32x4 fa[TM], fb[TN];
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(buf + aw_off + i * 32 * LDS_LD + j * 8);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Aw + i * 32 * LDS_LD + j * 8);
+        for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const f32x4 *>(buf + bw_off + i * 32 * LDS_LD + j * 8);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const f32x4 *>(Bw + i * 32 * LDS_LD + j * 8);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < TN; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[jn][t], acc[i][jn], 0, 0, 0);
-        }
-        __syncthreads();           // every wave is done reading this K-tile
+                    acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[jn][t], fa[i][t], acc[jn][i], 0, 0, 0);
+    };
+
+    // The two workgroups that share a CU start together and, contending for one matrix pipe per SIMD, stay in lockstep:
+    // both issue addresses / LDS stores while the pipe idles.  Delaying every second generation of workgroups by about
+    // half a K-tile keeps the pairs out of phase (one computes while the other fetches).
+    if (a.stagger && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(1), __builtin_amdgcn_s_sleep(1);
+    if (a.stagger && ((blockIdx.x >> 8) & 1))
+        for (int z = 0; z < a.stagger; ++z) __builtin_amdgcn_s_sleep(16);
+    fetch_tile(0);
+    store_tile(lds);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const float *cur = lds + (kt & 1) * TILE;
+        float *nxt = lds + ((kt + 1) & 1) * TILE;
+        const bool more = kt + 1 < nkt;
+        mma_group(cur, 0);
         if (more) {
-            store_tile();
-            __syncthreads();
+            advance_k();
+            fetch_tile(kt + 1);    // in flight behind the next two MFMA groups
         }
+        mma_group(cur, 1);
+        mma_group(cur, 2);
+        if (more) store_tile(nxt); // the other buffer: nobody reads it during this K-tile
+        mma_group(cur, 3);
+        __syncthreads();
     }
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31 (-> m), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (-> n).
+    // Each wave parks its D tile in its own LDS region as [m][n] (the operand buffers are free after the last barrier),
+    // then sweeps it with a compact loop: 16 lanes cover 64 consecutive n of one row -> bias / activation / affine /
+    // residual on float4 and full-line 16 B stores.
+    constexpr int SLD = WN + 4;
+    static_assert(4 * WM * SLD <= 2 * TILE, "epilogue staging does not fit the operand buffers");
+    float *stage = lds + wave * (WM * SLD);
+    const int h4 = (lane >> 5) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[jn][i][4 * g], acc[jn][i][4 * g + 1], acc[jn][i][4 * g + 2], acc[jn][i][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(&stage[(i * 32 + (lane & 31)) * SLD + jn * 32 + 8 * g + h4]) = v;
+            }
+    __syncthreads();
     const float *bias = d.bias ? d.bias + (size_t)bz * d.Cout : nullptr;
     const size_t row_base = (size_t)bz * a.M;
+    constexpr int NQ = WN / 4;                                    // float4 per staged row
+    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+    for (int idx = lane; idx < WM * NQ; idx += 64) {
+        const int ml = idx / NQ, n = nw + (idx % NQ) * 4, m = mw + ml;
+        if (m >= a.M || n >= d.Cout) continue;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&stage[ml * SLD + (idx % NQ) * 4]);
+        const size_t row = row_base + m;
+        float *yrow = d.y + row * d.y_cs + d.y_coff;
+        const float *rrow = d.residual ? d.residual + row * d.res_cs + d.res_coff : nullptr;
+        if (n + 3 < d.Cout) {
+            if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);
+            if (d.act == SOMI_ACT_SILU) {
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int n = n0 + wn * WN + jn * 32 + (lane & 31);
-        if (n >= d.Cout) continue;
-        const float bv = bias ? bias[n] : 0.f;
-        const float ps = d.post_scale ? d.post_scale[n] : 1.f;
-        const float pt = d.post_scale ? d.post_shift[n] : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+            } else if (d.act != SOMI_ACT_NONE) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m >= a.M) continue;
-                float v = acc[i][jn][e] + bv;
-                v = apply_act_rt(v, d.act);
-                v = v * ps + pt;
-                const size_t row = row_base + m;
-                if (d.residual) v += d.residual[row * d.res_cs + d.res_coff + n];
-                d.y[row * d.y_cs + d.y_coff + n] = v;
+                for (int e = 0; e < 4; ++e) v[e] = apply_act_rt(v[e], d.act);
+            }
+            if (d.post_scale)
+                v = v * *reinterpret_cast<const f32x4 *>(d.post_scale + n) + *reinterpret_cast<const f32x4 *>(d.post_shift + n);
+            if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + n);
+            *reinterpret_cast<f32x4 *>(yrow + n) = v;
+        } else {
+            for (int e = 0; e < 4 && n + e < d.Cout; ++e) {          // ragged Cout tail
+                float t = v[e] + (bias ? bias[n + e] : 0.f);
+                t = apply_act_rt(t, d.act);
+                if (d.post_scale) t = t * d.post_scale[n + e] + d.post_shift[n + e];
+                if (rrow) t += rrow[n + e];
+                yrow[n + e] = t;
             }
         }
     }
@@ -219,10 +313,15 @@ static int launch(const ConvArgs &a, hipStream_t s) {
     args.tiles_n = cdiv(a.d.Cout, BN);
     const dim3 grid(args.tiles_m * args.tiles_n, 1, a.d.per_sample_w ? a.d.B : 1);
     const bool mod = a.d.a_chan_scale || a.d.a_pix_scale;
-    if (mod)
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true>), grid, dim3(256), 0, s, args);
+    const bool fast = a.d.Cin % BK == 0 && a.d.kh * a.d.kw <= 32 && (size_t)a.K * 4 < (1u << 27);
+    if (mod && fast)
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(256), 0, s, args);
+    else if (mod)
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, false>), grid, dim3(256), 0, s, args);
+    else if (fast)
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, dim3(256), 0, s, args);
     else
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, s, args);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, dim3(256), 0, s, args);
     return launch_status("somi_conv2d_nhwc_f32");
 }
 
@@ -256,11 +355,26 @@ extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stre
     SOMI_REQUIRE((long)d.B * d.Ho * d.Wo < (1L << 31), SOMI_EINVAL, "conv: too many output pixels");
     if (d.a_chan_scale) SOMI_REQUIRE(aligned16(d.a_chan_scale), SOMI_EINVAL, "conv: a_chan_scale must be 16 B aligned");
 
+    SOMI_REQUIRE(d.y_cs % 4 == 0 && d.y_coff % 4 == 0 && aligned16(d.y), SOMI_EINVAL,
+                 "conv: y_cs (%d), y_coff (%d) must be multiples of 4 and y 16 B aligned", d.y_cs, d.y_coff);
+    SOMI_REQUIRE(!d.residual || (d.res_cs % 4 == 0 && d.res_coff % 4 == 0 && aligned16(d.residual)), SOMI_EINVAL,
+                 "conv: residual stride / offset must be multiples of 4 and 16 B aligned");
+    SOMI_REQUIRE((!d.bias || aligned16(d.bias)) && (!d.post_scale || (aligned16(d.post_scale) && aligned16(d.post_shift))),
+                 SOMI_EINVAL, "conv: bias / post_scale / post_shift must be 16 B aligned");
     ConvArgs a;
     a.d = d;
     a.K = d.kh * d.kw * d.Cin;
     a.M = d.per_sample_w ? d.Ho * d.Wo : d.B * d.Ho * d.Wo;
     a.tiles_m = a.tiles_n = 0;
+    const size_t xb = (size_t)d.B * d.H * d.W * d.x_cs * 4, wb = (size_t)(d.per_sample_w ? d.B : 1) * d.Cout * a.K * 4;
+    SOMI_REQUIRE(xb <= MAX_BUF_BYTES && wb <= MAX_BUF_BYTES, SOMI_ENOTIMPL,
+                 "conv: input (%zu B) or weights (%zu B) exceed the 4 GiB buffer-descriptor range; split the batch", xb, wb);
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
+    a.chan_bytes = (unsigned)((size_t)d.B * d.Cin * 4);
+    a.pix_bytes = (unsigned)((size_t)d.B * d.H * d.W * 4);
+    static const int stagger_env = getenv("SOMI_CONV_STAGGER") ? atoi(getenv("SOMI_CONV_STAGGER")) : 0;
+    a.stagger = stagger_env;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (pick_tile(d, a.M)) {
         case 0: return launch<128, 128, 2, 2>(a, s);
@@ -273,11 +387,11 @@ extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stre
 extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
     if (!dp || dp->Cout <= 0 || dp->Ho <= 0 || dp->Wo <= 0 || dp->B <= 0) return nullptr;
     const int M = dp->per_sample_w ? dp->Ho * dp->Wo : dp->B * dp->Ho * dp->Wo;
-    const bool mod = dp->a_chan_scale || dp->a_pix_scale;
-    static const char *names[4][2] = {
-        {"conv_igemm_f32_kernel<128,128,2,2,false>", "conv_igemm_f32_kernel<128,128,2,2,true>"},
-        {"conv_igemm_f32_kernel<64,128,1,4,false>", "conv_igemm_f32_kernel<64,128,1,4,true>"},
-        {"conv_igemm_f32_kernel<128,64,2,2,false>", "conv_igemm_f32_kernel<128,64,2,2,true>"},
-        {"conv_igemm_f32_kernel<128,32,4,1,false>", "conv_igemm_f32_kernel<128,32,4,1,true>"}};
-    return names[somi::pick_tile(*dp, M)][mod ? 1 : 0];
+    const int mod = (dp->a_chan_scale || dp->a_pix_scale) ? 1 : 0;
+    const int fast = (dp->Cin % somi::BK == 0 && dp->kh * dp->kw <= 32) ? 1 : 0;
+    static const char *tiles[4] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1"};
+    static thread_local char name[96];
+    snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::pick_tile(*dp, M)], mod ? "true" : "false",
+             fast ? "true" : "false");
+    return name;
 }

@@ -284,6 +284,48 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const float *__restri
     }
 }
 
+// CBAM apply: sa = sigmoid(conv_kxk(stats) + bias) for a tile of 64 pixels (one lane each), then y = x * ca[b][c] * sa[p]
+// for the tile's 64 x C elements (float4 per lane).  In place allowed.  Replaces materialising `spatial_attention(out) * out`
+// with `out = channel_attention(x2) * x2` (models/common.py:686-688) in two passes.
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const float *__restrict__ x, int x_cs, int x_coff, const float *__restrict__ ca,
+                                                         const float *__restrict__ stats, const float *__restrict__ w, float bias,
+                                                         float *__restrict__ y, int y_cs, int y_coff, int B, int H, int W, int C, int k) {
+    __shared__ float sa[64];
+    const long npix = (long)B * H * W;
+    const int pad = k >> 1, C4 = C >> 2;
+    for (long p0 = blockIdx.x * 64L; p0 < npix; p0 += (long)gridDim.x * 64) {
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const long p = p0 + threadIdx.x;
+            float acc = bias;
+            if (p < npix) {
+                const int wv = (int)(p % W), hv = (int)((p / W) % H);
+                const long b = p / ((long)W * H);
+                for (int r = 0; r < k; ++r) {
+                    const int hi = hv + r - pad;
+                    if ((unsigned)hi >= (unsigned)H) continue;
+                    for (int q = 0; q < k; ++q) {
+                        const int wi = wv + q - pad;
+                        if ((unsigned)wi >= (unsigned)W) continue;
+                        const float2 st = *reinterpret_cast<const float2 *>(stats + ((b * H + hi) * W + wi) * 2);
+                        acc += st.x * w[(r * k + q) * 2] + st.y * w[(r * k + q) * 2 + 1];
+                    }
+                }
+            }
+            sa[threadIdx.x] = 1.0f / (1.0f + expf(-acc));
+        }
+        __syncthreads();
+        const int np = (int)min(64L, npix - p0);
+        for (int it = threadIdx.x; it < np * C4; it += 256) {
+            const int pl = it / C4, c = (it % C4) * 4;
+            const long p = p0 + pl, b = p / ((long)W * H);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
+            v = v * *reinterpret_cast<const f32x4 *>(ca + b * C + c) * sa[pl];
+            *reinterpret_cast<f32x4 *>(y + p * y_cs + y_coff + c) = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_channels_kernel(const float *__restrict__ x, const float *__restrict__ s,
                                                              const float *__restrict__ pix, float *__restrict__ y, int B,
                                                              int HW, int C) {
@@ -519,6 +561,19 @@ extern "C" int somi_spatial_attn_f32(const float *stats, const float *w, float b
     hipLaunchKernelGGL(spatial_attn_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, stats, w, bias, sa, B,
                        H, W, k);
     return launch_status("somi_spatial_attn_f32");
+}
+
+extern "C" int somi_cbam_apply_nhwc_f32(const float *x, int x_cs, int x_coff, const float *ca, const float *stats, const float *w,
+                                        float bias, float *y, int y_cs, int y_coff, int B, int H, int W, int C, int k,
+                                        somi_stream_t stream) {
+    SOMI_REQUIRE(x && ca && stats && w && y && B > 0 && H > 0 && W > 0 && C > 0 && (k == 3 || k == 5 || k == 7), SOMI_EINVAL,
+                 "cbam apply: bad arguments (k in 3,5,7)");
+    SOMI_REQUIRE(C % 4 == 0 && x_cs % 4 == 0 && x_coff % 4 == 0 && y_cs % 4 == 0 && y_coff % 4 == 0 && aligned16(x) && aligned16(y) &&
+                     aligned16(ca), SOMI_EINVAL, "cbam apply: C, strides, offsets %% 4 and 16 B alignment");
+    const long tiles = ((long)B * H * W + 63) / 64;
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3((unsigned)(tiles > 256L * 16 ? 256L * 16 : tiles)), dim3(256), 0, (hipStream_t)stream, x,
+                       x_cs, x_coff, ca, stats, w, bias, y, y_cs, y_coff, B, H, W, C, k);
+    return launch_status("somi_cbam_apply_nhwc_f32");
 }
 
 extern "C" int somi_scale_channels_nhwc_f32(const float *x, const float *s, const float *pix, float *y, int B, int HW, int C,

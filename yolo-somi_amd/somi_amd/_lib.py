@@ -52,6 +52,7 @@ SIGNATURES = {
     'somi_attn_mlp_f32': (I, [I, P, P, P, P, P, P, P, I, I, I, S]),
     'somi_chan_stats_nhwc_f32': (I, [P, I, I, P, P, I, I, I, S]),
     'somi_spatial_attn_f32': (I, [P, P, F, P, I, I, I, I, S]),
+    'somi_cbam_apply_nhwc_f32': (I, [P, I, I, P, P, P, F, P, I, I, I, I, I, I, I, S]),
     'somi_scale_channels_nhwc_f32': (I, [P, P, P, P, I, I, I, S]),
     'somi_odconv_weights_f32': (I, [P] * 18 + [I] * 7 + [S]),
     'somi_detect_decode_f32': (I, [P, I, P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),

@@ -181,14 +181,17 @@ class SpatialAttentionModule(_Packed):
         return w, float(self.cv1.bias.detach()[0])
 
     def forward(self, x, ca):
+        """Applies both attentions to x in place: x <- x * ca * sa (one stats pass + one apply pass)."""
         w, b = self._packed(x.t.device)
         stats = ops.chan_stats(x.t, ca, c=x.c, x_coff=x.coff)
-        return ops.spatial_attn(stats, w, b, self.cv1.kernel_size[0])
+        ops.cbam_apply_(x.t, ca, stats, w, b, self.cv1.kernel_size[0], c=x.c, x_coff=x.coff)
+        return x
 
 
 class CBAMBottleneck(nn.Module):
     """cv1 3x3 -> channel attn -> spatial attn -> cv2 3x3 (+x) (models/common.py:671-691).
-    The two attention scalings are applied on cv2's operand load instead of materialising `out`."""
+    The two attention scalings are applied to cv1's output in place by one streaming kernel (the in-operand form of
+    the conv kernel measured 26 % slower than the plain one; the extra pass costs ~2 %)."""
 
     def __init__(self, c1, c2, shortcut=True, g=1, e=1.0, k=(3, 3), ratio=8, kernel_size=3):
         super().__init__()
@@ -202,8 +205,8 @@ class CBAMBottleneck(nn.Module):
     def forward(self, x, out=None):
         t = self.cv1(x)
         ca = self.channel_attention(t)
-        sa = self.spatial_attention(t, ca)
-        return self.cv2(t, out=out, residual=x if self.add else None, a_chan=ca, a_pix=sa)
+        t = self.spatial_attention(t, ca)
+        return self.cv2(t, out=out, residual=x if self.add else None)
 
 
 class C2fCBAM(nn.Module):

@@ -67,7 +67,7 @@ def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', 
     e1.record()
     name = _lib.lib().somi_conv2d_kernel_name(C.byref(d)).decode()
     flops = 2.0 * B * Ho * Wo * (alg_cout or cout) * (alg_cin or cin) * kh * kw
-    PROFILE.append((name, flops, e0, e1))
+    PROFILE.append((name, flops, e0, e1, (B, H, W, cin, cout, kh, stride, int(per_sample_w))))
     return out
 
 
@@ -171,6 +171,15 @@ def spatial_attn(stats, w, bias, k):
     sa = torch.empty(B, H, W, device=stats.device, dtype=torch.float32)
     check(_lib.lib().somi_spatial_attn_f32(_ptr(stats), _ptr(w), float(bias), _ptr(sa), B, H, W, k, _stream()), 'spatial_attn')
     return sa
+
+
+def cbam_apply_(x, ca, stats, w, bias, k, c=None, x_coff=0):
+    """In place: x[..., slice] *= ca[b,c] * sigmoid(conv_kxk(stats)+bias)  (CBAM, models/common.py:686-688)."""
+    B, H, W, cs = x.shape
+    c = cs - x_coff if c is None else c
+    check(_lib.lib().somi_cbam_apply_nhwc_f32(_ptr(_f32c(x)), cs, x_coff, _ptr(ca), _ptr(stats), _ptr(w), float(bias), _ptr(x), cs,
+                                              x_coff, B, H, W, c, k, _stream()), 'cbam_apply')
+    return x
 
 
 def scale_channels(x, s=None, pix=None, out=None):
