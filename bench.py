@@ -60,6 +60,20 @@ def cpu_baseline(size, seconds_budget=25.0):
             'sample': f'{n} x (forward + NMS) of yolov5l-SOMI at batch {B}, {size}x{size}, torch CPU fp32, {cores} threads'}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic.json, written by tools/profile_summary.py: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read
+    correction).  PMC counters cannot be read live by the benchmarked process; None if no profile is committed."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(path):
+        return None
+    key = kernel_name.replace(' ', '')
+    for k, v in json.load(open(path)).get('kernels', {}).items():
+        if key in k.replace(' ', ''):
+            return v['hbm_bytes_per_launch']
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -102,24 +116,13 @@ def main():
                 return None
             return non_max_suppression(z, 0.001, 0.6, multi_label=True)
 
+    from somi_amd.dist import timed_steps, whole_job_rate
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
     ops.PROFILE = prof = []                                     # per-launch HIP events around every conv launch
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.time() - t0
+    dt = timed_steps(step, args.steps, dist=dist, sync=torch.cuda.synchronize, device=dev)   # barrier+sync both sides, MAX over ranks
     ops.PROFILE = None
-    if dist:
-        dist.barrier()
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     if rank == 0:
         # dominant kernel = the conv tile variant with the largest total time
@@ -134,7 +137,7 @@ def main():
         achieved = flops / secs / 1e12
         out = {
             'metric': 'images/sec infer (forward+NMS) @640, VisDrone-shaped synthetic, yolov5l-SOMI',
-            'value': round(world * args.batch * args.steps / dt, 2), 'unit': 'images/s', 'n_gpus': world,
+            'value': round(whole_job_rate(args.batch, args.steps, world, dt), 2), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'yolov5l-SOMI inference step: uint8 ingest + forward + decode'
@@ -149,6 +152,7 @@ def main():
                          'all_conv_tflops': round(all_flops / all_secs / 1e12, 2),
                          'conv_share_of_step': round(all_secs / dt, 3)},
         }
+        out['roofline']['traffic'] = pmc_traffic(name)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
