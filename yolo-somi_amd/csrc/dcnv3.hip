@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const DcnArgs a) {
     const int CV = a.C / VEC;
     const long img = (long)a.H * a.W * a.C;
     const int LG = a.Gc / VEC;                                 // lanes per group
-    const bool shuffle = VEC == 4 && LG <= 64 && (LG & (LG - 1)) == 0 && (CV % 64 == 0 || 64 % CV == 0);
+    // groups are LG consecutive lanes, aligned because CV = G*LG: butterflies need LG to be a power of two <= 64
+    const bool shuffle = LG <= 64 && (LG & (LG - 1)) == 0;
     const int lane = threadIdx.x & 63;
     const int nit = np * CV;
     const int nit_pad = (nit + 255) / 256 * 256;               // keep whole waves in the loop for the shuffles
@@ -286,7 +287,10 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
     SOMI_REQUIRE((reinterpret_cast<uintptr_t>(offset) & 7u) == 0 && (reinterpret_cast<uintptr_t>(grad_offset) & 7u) == 0,
                  SOMI_EINVAL, "dcnv3: offset / grad_offset must be 8 B aligned");
     const size_t lds = (size_t)a.TP * G * a.K * (sizeof(Rec) + 3 * sizeof(float));
-    const bool vec = (Gc % 4 == 0) && aligned16(grad_output);
+    // one channel per lane: a wave's fp32 atomic covers 256 contiguous bytes of grad_input (the shape that runs at the
+    // chip-wide atomic rate, MI355X_MICROARCH.md "Global float atomics"); 4 channels per lane (16 B stride between lanes'
+    // dwords) measured 4x slower.  The float4 form is kept for group widths where it avoids the LDS-atomic fallback.
+    const bool vec = (Gc % 4 == 0) && aligned16(grad_output) && !((Gc & (Gc - 1)) == 0 && Gc <= 64);
     if (vec) hipLaunchKernelGGL(dcnv3_bwd_kernel<4>, dim3(a.ntile), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(dcnv3_bwd_kernel<1>, dim3(a.ntile), dim3(256), lds, (hipStream_t)stream, a);
     return launch_status("somi_dcnv3_backward_f32");
