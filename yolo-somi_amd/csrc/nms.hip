@@ -16,7 +16,7 @@
 
 namespace somi {
 
-constexpr int NMS_CHUNK = 1024;      // rows per count/emit workgroup (256 threads x 4 consecutive rows)
+constexpr int NMS_CHUNK = 512;       // rows per count/emit workgroup (256 threads x 2 consecutive rows)
 constexpr int MAX_NMS = 30000;       // utils/general.py:641
 constexpr float MAX_WH = 4096.f;     // utils/general.py:640
 constexpr int ROUND = 512;           // candidates per greedy round
@@ -91,17 +91,35 @@ __device__ __forceinline__ int block_exscan_256(int v, int *tot, int *lds /* >= 
     return base + inc - v;
 }
 
+// count (EMIT=false) / emit (EMIT=true) over one chunk of NMS_CHUNK prediction rows.  The chunk's rows are staged in LDS
+// with coalesced 16 B loads (a row is 4*(5+nc) bytes, so per-thread row reads straight from HBM touch every line many
+// times: PMC showed 9.1 GB fetched for 0.26 GB of predictions); emitted (key, val) pairs are compacted in LDS and leave
+// as contiguous stores.
+constexpr int EMIT_STAGE = 4096;     // (key,val) pairs staged per chunk before falling back to direct stores
 template <bool EMIT>
 __global__ __launch_bounds__(256) void nms_count_emit_kernel(const NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];     // [NMS_CHUNK][no], then the emit staging
     __shared__ int lds[4];
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int r0 = chunk * NMS_CHUNK + threadIdx.x * 4;
-    const float *img = a.pred + (size_t)b * a.n * a.no;
-    int cnt[4], mine = 0;
+    const int rbase = chunk * NMS_CHUNK;
+    const int nrow = min(NMS_CHUNK, a.n - rbase);
+    const float *src = a.pred + ((size_t)b * a.n + rbase) * a.no;
+    const int nfl = nrow * a.no;
+    if (((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) {
+        for (int i = threadIdx.x * 4; i + 3 < nfl; i += 1024)
+            *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
+        for (int i = (nfl & ~3) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    }
+    __syncthreads();
+    constexpr int RPT = NMS_CHUNK / 256;
+    const int rl0 = threadIdx.x * RPT;
+    int cnt[RPT], mine = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + i;
-        cnt[i] = r < a.n ? row_entries<false>(a, img + (size_t)r * a.no, r, nullptr, nullptr, 0) : 0;
+    for (int i = 0; i < RPT; ++i) {
+        const int rl = rl0 + i;
+        cnt[i] = rl < nrow ? row_entries<false>(a, rows + rl * a.no, rbase + rl, nullptr, nullptr, 0) : 0;
         mine += cnt[i];
     }
     int tot;
@@ -110,13 +128,30 @@ __global__ __launch_bounds__(256) void nms_count_emit_kernel(const NmsArgs a) {
         if (threadIdx.x == 0) a.chunk_cnt[b * a.nchunk + chunk] = tot;
         return;
     }
-    int dst = a.chunk_off[b * a.nchunk + chunk] + pre;
+    const int gbase = a.chunk_off[b * a.nchunk + chunk];
     uint32_t *keys = a.keyA + (size_t)b * a.cap, *vals = a.valA + (size_t)b * a.cap;
+    if (tot <= EMIT_STAGE) {
+        uint32_t *skey = reinterpret_cast<uint32_t *>(rows + NMS_CHUNK * a.no), *sval = skey + EMIT_STAGE;
+        int dst = pre;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + i;
-        if (cnt[i]) row_entries<true>(a, img + (size_t)r * a.no, r, keys, vals, dst);
-        dst += cnt[i];
+        for (int i = 0; i < RPT; ++i) {
+            const int rl = rl0 + i;
+            if (cnt[i]) row_entries<true>(a, rows + rl * a.no, rbase + rl, skey, sval, dst);
+            dst += cnt[i];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < tot; i += 256) {
+            keys[gbase + i] = skey[i];
+            vals[gbase + i] = sval[i];
+        }
+    } else {
+        int dst = gbase + pre;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int rl = rl0 + i;
+            if (cnt[i]) row_entries<true>(a, rows + rl * a.no, rbase + rl, keys, vals, dst);
+            dst += cnt[i];
+        }
     }
 }
 
@@ -498,9 +533,17 @@ extern "C" int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_
     uint32_t *sortV = reinterpret_cast<uint32_t *>(w);
     a.det = det; a.count = count;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(nms_count_emit_kernel<false>, dim3(a.nchunk, B), dim3(256), 0, s, a);
+    const size_t rows_lds = (size_t)NMS_CHUNK * a.no * 4;
+    SOMI_REQUIRE(rows_lds + (size_t)EMIT_STAGE * 8 <= 150 * 1024, SOMI_ENOTIMPL, "nms: nc = %d does not fit the LDS row staging", nc);
+    if (rows_lds + (size_t)EMIT_STAGE * 8 > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_count_emit_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)rows_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_count_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(rows_lds + (size_t)EMIT_STAGE * 8));
+    }
+    hipLaunchKernelGGL(nms_count_emit_kernel<false>, dim3(a.nchunk, B), dim3(256), rows_lds, s, a);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(nms_count_emit_kernel<true>, dim3(a.nchunk, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nms_count_emit_kernel<true>, dim3(a.nchunk, B), dim3(256), rows_lds + (size_t)EMIT_STAGE * 8, s, a);
     // top-30000 select (every kernel exits at once for images with <= 30000 candidates)
     (void)hipMemsetAsync(st, 0, (size_t)B * sizeof(SelState), s);
     hipLaunchKernelGGL(nms_select_hist_kernel<1>, dim3(nsel_chunk, B), dim3(256), 0, s, a, st);
