@@ -103,6 +103,16 @@ int somi_dcnv3_backward_f32(const float *input, const float *offset, const float
                             int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
                             float offset_scale, int im2col_step, somi_stream_t stream);
 
+/* Pieces of the DCNv3 nn.Module around the operator (models/ops_dcnv3/modules/dcnv3.py:283-291,334,370-376):
+ *  LayerNorm over C (biased variance, eps inside the sqrt) + activation on contiguous NHWC;
+ *  softmax over the K points of each (pixel, group): x, y are (n_groups, K) contiguous;
+ *  centre-feature-scale blend y = x*(1-s) + xproj*s with s = sigmoid(logit[p*logit_cs + g]). */
+int somi_layernorm_act_nhwc_f32(const float *x, const float *gamma, const float *beta, float eps, int act, float *y,
+                                long npix, int C, somi_stream_t stream);
+int somi_group_softmax_f32(const float *x, float *y, long n_groups, int K, somi_stream_t stream);
+int somi_dcnv3_cfs_blend_f32(const float *x, const float *xproj, const float *logit, int logit_cs, float *y, long npix,
+                             int G, int Gc, somi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bandwidth-bound layer kernels of Model._forward_once (models/yolo.py:1269-1290).
  */

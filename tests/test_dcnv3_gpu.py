@@ -93,3 +93,18 @@ def test_dcnv3_module_matches_oracle():
     x = torch.randn(2, 12, 10, 64, generator=torch.Generator().manual_seed(9))
     with torch.no_grad():
         rel_close(mod(x.cuda()), ref(x), what='DCNv3 module')
+
+
+def test_dcnv3_module_helpers():
+    import torch.nn.functional as F
+    from somi_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 9, 7, 64, generator=g)
+    gm, bt = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    rel_close(ops.layernorm_act(x.cuda(), gm.cuda(), bt.cuda(), 1e-6, 'gelu'), F.gelu(F.layer_norm(x, (64,), gm, bt, 1e-6)),
+              rel=1e-5, what='layernorm+gelu')
+    m = torch.randn(2, 9, 7, 4 * 9, generator=g)
+    rel_close(ops.group_softmax(m.cuda(), 9), torch.softmax(m.view(2, 9, 7, 4, 9), -1).view(2, 9, 7, 36), rel=1e-5, what='softmax')
+    a, b, lg = torch.randn(2, 9, 7, 64, generator=g), torch.randn(2, 9, 7, 64, generator=g), torch.randn(2, 9, 7, 4, generator=g)
+    s = torch.sigmoid(lg)[..., None].repeat(1, 1, 1, 1, 16).flatten(-2)
+    rel_close(ops.cfs_blend(a.cuda(), b.cuda(), lg.cuda(), 4, 16), a * (1 - s) + b * s, rel=1e-5, what='cfs blend')

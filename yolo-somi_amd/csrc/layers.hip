@@ -459,9 +459,93 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ DCNv3 module helpers
+// LayerNorm over C (eps inside the sqrt, biased variance) followed by an activation: one wave per pixel, two passes over a
+// row that stays in L1 (models/ops_dcnv3/modules/dcnv3.py:283-291: LayerNorm(eps=1e-6) -> GELU).
+__global__ __launch_bounds__(256) void layernorm_act_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps, int act,
+                                                            float *__restrict__ y, long npix, int C) {
+    const int lane = threadIdx.x & 63;
+    const long wave_id = (blockIdx.x * 256L + threadIdx.x) >> 6, nwave = (long)gridDim.x * 4;
+    for (long p = wave_id; p < npix; p += nwave) {
+        const float *xr = x + p * C;
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c) - mean;
+            q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q / (float)C + eps);
+        for (int c = lane * 4; c < C; c += 256) {
+            f32x4 v = (*reinterpret_cast<const f32x4 *>(xr + c) - mean) * rstd;
+            v = v * *reinterpret_cast<const f32x4 *>(gamma + c) + *reinterpret_cast<const f32x4 *>(beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_rt(v[e], act);
+            *reinterpret_cast<f32x4 *>(y + p * C + c) = v;
+        }
+    }
+}
+
+// softmax over the K sampling points of every (pixel, group) (modules/dcnv3.py:334); one lane per (pixel, group)
+__global__ __launch_bounds__(256) void group_softmax_kernel(const float *__restrict__ x, float *__restrict__ y, long n, int K) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float *r = x + i * K;
+        float m = r[0];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, r[k]);
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) den += expf(r[k] - m);
+        const float inv = 1.f / den;
+        for (int k = 0; k < K; ++k) y[i * K + k] = expf(r[k] - m) * inv;
+    }
+}
+
+// centre-feature-scale blend (modules/dcnv3.py:370-376): s = sigmoid(logit[p][g]); y = x*(1-s) + xproj*s
+__global__ __launch_bounds__(256) void cfs_blend_kernel(const float *__restrict__ x, const float *__restrict__ xproj,
+                                                        const float *__restrict__ logit, int logit_cs, float *__restrict__ y,
+                                                        long npix, int G, int Gc) {
+    const int C = G * Gc;
+    const long items = npix * C;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const long p = it / C;
+        const int g = (int)(it % C) / Gc;
+        const float sg = 1.0f / (1.0f + expf(-logit[p * logit_cs + g]));
+        y[it] = x[it] * (1.f - sg) + xproj[it] * sg;
+    }
+}
+
 }  // namespace somi
 
 using namespace somi;
+
+extern "C" int somi_layernorm_act_nhwc_f32(const float *x, const float *gamma, const float *beta, float eps, int act, float *y,
+                                           long npix, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(x && gamma && beta && y && npix > 0 && C > 0 && C % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) &&
+                     aligned16(beta), SOMI_EINVAL, "layernorm: bad arguments (C %% 4, 16 B alignment)");
+    hipLaunchKernelGGL(layernorm_act_kernel, dim3(ew_grid(npix * 64)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, act, y,
+                       npix, C);
+    return launch_status("somi_layernorm_act_nhwc_f32");
+}
+
+extern "C" int somi_group_softmax_f32(const float *x, float *y, long n_groups, int K, somi_stream_t stream) {
+    SOMI_REQUIRE(x && y && n_groups > 0 && K > 0, SOMI_EINVAL, "group softmax: bad arguments");
+    hipLaunchKernelGGL(group_softmax_kernel, dim3(ew_grid(n_groups)), dim3(256), 0, (hipStream_t)stream, x, y, n_groups, K);
+    return launch_status("somi_group_softmax_f32");
+}
+
+extern "C" int somi_dcnv3_cfs_blend_f32(const float *x, const float *xproj, const float *logit, int logit_cs, float *y, long npix,
+                                        int G, int Gc, somi_stream_t stream) {
+    SOMI_REQUIRE(x && xproj && logit && y && npix > 0 && G > 0 && Gc > 0 && logit_cs >= G, SOMI_EINVAL, "cfs blend: bad arguments");
+    hipLaunchKernelGGL(cfs_blend_kernel, dim3(ew_grid(npix * G * Gc)), dim3(256), 0, (hipStream_t)stream, x, xproj, logit, logit_cs, y,
+                       npix, G, Gc);
+    return launch_status("somi_dcnv3_cfs_blend_f32");
+}
 
 extern "C" int somi_image_u8_to_nhwc4(const uint8_t *img, float *y, int B, int C, int H, int W, somi_stream_t stream) {
     SOMI_REQUIRE(img && y && B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4, SOMI_EINVAL, "image ingest: bad arguments");

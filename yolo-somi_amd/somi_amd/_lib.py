@@ -42,6 +42,9 @@ SIGNATURES = {
     'somi_conv2d_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'somi_dcnv3_forward_f32': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
     'somi_dcnv3_backward_f32': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, S]),
+    'somi_layernorm_act_nhwc_f32': (I, [P, P, P, F, I, P, C.c_long, I, S]),
+    'somi_group_softmax_f32': (I, [P, P, C.c_long, I, S]),
+    'somi_dcnv3_cfs_blend_f32': (I, [P, P, P, I, P, C.c_long, I, I, S]),
     'somi_image_u8_to_nhwc4': (I, [P, P, I, I, I, I, S]),
     'somi_image_f32_to_nhwc4': (I, [P, P, I, I, I, I, F, S]),
     'somi_dwconv3x3_nhwc_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, I, S]),

@@ -78,9 +78,8 @@ class _ToChannelsLast(nn.Module):
 class DCNv3(nn.Module):
     """DCNv3 layer, NHWC in / NHWC out (modules/dcnv3.py:222-379).
 
-    Inference (`torch.no_grad`, eval) runs entirely on HIP kernels: the four Linear layers are 1x1 NHWC convs on the
-    MFMA kernel, the depthwise conv + LayerNorm + GELU and the mask softmax are torch device ops on the same stream
-    (widening target: fuse them), the deformable gather is `somi_dcnv3_forward_f32`.
+    The forward runs entirely on HIP kernels (see `forward`); autograd is wired for the deformable operator only
+    (`DCNv3Function`), the surrounding layers' backward belongs to the training path that is not built yet.
     """
 
     def __init__(self, channels=64, kernel_size=3, dw_kernel_size=None, stride=1, pad=1, dilation=1, group=4,
@@ -112,26 +111,47 @@ class DCNv3(nn.Module):
             self.center_feature_scale_proj_weight = nn.Parameter(torch.zeros(group, channels))
             self.center_feature_scale_proj_bias = nn.Parameter(torch.zeros(group))
 
-    def _linear(self, x, lin):
-        """nn.Linear on NHWC == 1x1 conv; weight (out,in) is already [Cout][K]."""
-        cin = lin.in_features
+    def _linear(self, x, weight, bias):
+        """nn.Linear on NHWC == 1x1 conv on the MFMA kernel; weight (out,in) is already [Cout][K].  Cout is padded to a
+        multiple of 4 with zero rows (the pad columns are sliced off by the caller when it matters)."""
+        cout, cin = weight.shape
         if cin % 4:
             raise RuntimeError('DCNv3 channels must be a multiple of 4 on the MI355X path')
-        return ops.conv2d_nhwc(x, lin.weight.detach().contiguous(), lin.bias.detach(), kh=1, kw=1)
+        w, b = weight.detach().float(), bias.detach().float()
+        if cout % 4:
+            pad = 4 - cout % 4
+            w = torch.cat([w, w.new_zeros(pad, cin)])
+            b = torch.cat([b, b.new_zeros(pad)])
+        return ops.conv2d_nhwc(x, w.contiguous(), b.contiguous(), kh=1, kw=1)
 
     def forward(self, input):
-        N, H, W, _ = input.shape
-        x = self._linear(input, self.input_proj)
+        """Every arithmetic step runs in libsomi_hip.so: 4 Linear layers = 1x1 MFMA convs, depthwise conv, LayerNorm+GELU,
+        mask softmax, the deformable gather and the centre-feature-scale blend."""
+        N, H, W, C = input.shape
+        if self.dw_kernel_size != 3:
+            raise NotImplementedError('depthwise kernel size 3 only on the MI355X path')
+        if not input.is_cuda or input.dtype != torch.float32:
+            raise RuntimeError('DCNv3 runs on float32 GPU tensors only (no CPU fallback)')
+        input = input.contiguous()
+        x = self._linear(input, self.input_proj.weight, self.input_proj.bias)
         x_proj = x
-        x1 = self.dw_conv(input.permute(0, 3, 1, 2)).contiguous()
-        offset = self._linear(x1, self.offset)
-        mask = self._linear(x1, self.mask).reshape(N, H, W, self.group, -1)
-        mask = F.softmax(mask, -1).reshape(N, H, W, -1).contiguous()
+        dw = self.dw_conv[0]
+        ln = self.dw_conv[1][1]
+        wdw = dw.weight.detach().float()[:, 0].permute(1, 2, 0).reshape(9, C).contiguous()
+        x1 = ops.dwconv3x3(input, wdw, dw.bias.detach().float().contiguous())
+        x1 = ops.layernorm_act(x1, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
+        K = self.kernel_size * self.kernel_size
+        offset = self._linear(x1, self.offset.weight, self.offset.bias)
+        mlog = self._linear(x1, self.mask.weight, self.mask.bias)
+        if offset.shape[-1] != self.group * K * 2:
+            offset = offset[..., :self.group * K * 2].contiguous()
+        if mlog.shape[-1] != self.group * K:
+            mlog = mlog[..., :self.group * K].contiguous()
+        mask = ops.group_softmax(mlog, K)
         x = DCNv3Function.apply(x, offset, mask, self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad,
                                 self.pad, self.dilation, self.dilation, self.group, self.group_channels,
                                 self.offset_scale, 256)
         if self.center_feature_scale:
-            cfs = torch.sigmoid(F.linear(x1, self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias))
-            cfs = cfs[..., None].repeat(1, 1, 1, 1, self.channels // self.group).flatten(-2)
-            x = x * (1 - cfs) + x_proj * cfs
-        return self._linear(x, self.output_proj)
+            logit = self._linear(x1, self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias)
+            x = ops.cfs_blend(x, x_proj, logit, self.group, self.group_channels)
+        return self._linear(x, self.output_proj.weight, self.output_proj.bias)

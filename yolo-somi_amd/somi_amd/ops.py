@@ -208,3 +208,26 @@ def odconv_weights(gap, fc_w, fc_b, pk, wout, bout, cin, cin_pad, cout, kk, K):
                                              _ptr(wout), _ptr(bout), _ptr(ws), B, cin, cin_pad, cout, kk, K, hid, _stream()),
           'odconv_weights')
     return wout, bout
+
+
+def layernorm_act(x, gamma, beta, eps, act='none'):
+    """LayerNorm over the last dim of contiguous NHWC + activation (DCNv3 module, modules/dcnv3.py:283-291)."""
+    out = torch.empty_like(x)
+    C_ = x.shape[-1]
+    check(_lib.lib().somi_layernorm_act_nhwc_f32(_ptr(_f32c(x)), _ptr(gamma), _ptr(beta), float(eps), ACT[act], _ptr(out),
+                                                 x.numel() // C_, C_, _stream()), 'layernorm_act')
+    return out
+
+
+def group_softmax(x, K):
+    """softmax over trailing groups of K (mask logits (N,H,W,G*K) -> softmax per (pixel, group), modules/dcnv3.py:334)."""
+    out = torch.empty_like(x)
+    check(_lib.lib().somi_group_softmax_f32(_ptr(_f32c(x)), _ptr(out), x.numel() // K, K, _stream()), 'group_softmax')
+    return out
+
+
+def cfs_blend(x, xproj, logit, G, Gc):
+    out = torch.empty_like(x)
+    check(_lib.lib().somi_dcnv3_cfs_blend_f32(_ptr(_f32c(x)), _ptr(_f32c(xproj)), _ptr(_f32c(logit)), logit.shape[-1], _ptr(out),
+                                              x.numel() // (G * Gc), G, Gc, _stream()), 'cfs_blend')
+    return out
