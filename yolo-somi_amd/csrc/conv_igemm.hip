@@ -328,7 +328,11 @@ static int launch(const ConvArgs &a, hipStream_t s) {
 // tile choice: widest N tile that Cout fills reasonably; small-M problems take the 64-row tile to fill the chip
 static int pick_tile(const somi_conv_desc &d, int M) {
     const long blocks128 = (long)cdiv(M, 128) * cdiv(d.Cout, 128) * (d.per_sample_w ? d.B : 1);
-    if (d.Cout > 64) return (blocks128 >= 512 || M >= 128 * 256) ? 0 : 1;
+    if (d.Cout > 64) {
+        // a 64-wide N tile when it wastes much less of the last tile (e.g. Cout 192: 3 x 64 instead of 2 x 128)
+        if (cdiv(d.Cout, 64) * 64 * 5 <= cdiv(d.Cout, 128) * 128 * 4 && M >= 128 * 256) return 2;
+        return (blocks128 >= 512 || M >= 128 * 256) ? 0 : 1;
+    }
     if (d.Cout > 32) return 2;
     return 3;
 }

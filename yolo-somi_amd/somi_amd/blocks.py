@@ -258,8 +258,9 @@ class Swish(nn.Module):
         return x * torch.sigmoid(x)
 
 
-class BiFPN(nn.Module):
-    """w_i / (sum_j swish(w_j) + 1e-4) weighted sum (models/common.py:3688-3704); inputs may be virtual 2x-upsampled."""
+class BiFPN(_Packed):
+    """w_i / (sum_j swish(w_j) + 1e-4) weighted sum (models/common.py:3688-3704); inputs may be virtual 2x-upsampled.
+    The normalised weights are host scalars computed once per parameter change (no device sync in the forward)."""
 
     def __init__(self, length):
         super().__init__()
@@ -267,9 +268,12 @@ class BiFPN(nn.Module):
         self.swish = Swish()
         self.epsilon = 0.0001
 
-    def forward(self, xs):
+    def _pack(self, dev):
         w = self.weight.detach().float().cpu()
-        wn = (w / (self.swish(w).sum(dim=0) + self.epsilon)).tolist()
+        return (w / (self.swish(w).sum(dim=0) + self.epsilon)).tolist()
+
+    def forward(self, xs):
+        wn = self._packed(xs[0].t.device)
         for a in xs:
             if a.coff != 0 or a.t.shape[3] != xs[0].t.shape[3]:
                 raise NotImplementedError('BiFPN inputs must be whole tensors of equal width')
@@ -455,13 +459,18 @@ class DecoupledDetect(nn.Module):
         self.m = nn.ModuleList(Decouple(c, self.nc, self.na) for c in ch)
         self.inplace = False
 
+    def invalidate(self):
+        self.__dict__.pop('_anchors_host', None)
+
     def forward(self, xs):
         B = xs[0].shape[0]
         dev = xs[0].t.device
         total = sum(self.na * a.shape[1] * a.shape[2] for a in xs)
         z = None if self.training else torch.empty(B, total, self.no, device=dev, dtype=torch.float32)
         raws, row = [], 0
-        anchors = self.anchors.detach().float().cpu()
+        anchors = self.__dict__.get('_anchors_host')
+        if anchors is None:                                   # cached host copy: no device sync per forward
+            anchors = self.__dict__['_anchors_host'] = self.anchors.detach().float().cpu()
         for i in range(self.nl):
             b, c = self.m[i](xs[i])
             _, ny, nx, _ = b.shape

@@ -3,6 +3,11 @@ import torch
 
 
 def pad4(c):
+    """Channel storage width: multiples of 4 always (16 B vectors); widths >= 64 that are not a multiple of 32 go up to the
+    next multiple of 32 (177 -> 192, 98 -> 128 in the decoupled head) so the consumer conv takes the uniform-tap fast
+    path and whole MFMA tiles; the extra channels are zeros (zero weight rows) and cost no extra tiles."""
+    if c >= 64 and c % 32:
+        return (c + 31) // 32 * 32
     return (c + 3) // 4 * 4
 
 
