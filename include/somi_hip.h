@@ -77,6 +77,16 @@ typedef struct somi_conv_desc {
 
 int somi_conv2d_nhwc_f32(const somi_conv_desc *d, somi_stream_t stream);
 
+/* Data gradient of the convolution whose FORWARD geometry `fwd` describes (x (B,H,W,Cin) -> y (B,Ho,Wo,Cout); the pointer
+ * fields of `fwd` are ignored):  dx[b,h,w,ci] = sum_{r,q,co} dy[b,(h+p-r)/s,(w+p-q)/s,co] * W[co][ci][r][q]
+ * over the taps for which the divisions are exact and in range (autograd of F.conv2d, train.py:270 `backward()`).
+ * Runs the same MFMA implicit-GEMM kernel with rows = forward-input pixels.  `w_dgrad` is packed [Cin][kh*kw*Cout],
+ * k = (r*kw+q)*Cout + co.  `accumulate` (optional, may alias dx) is added to the result (skip connections).
+ * per_sample_w in `fwd` selects per-image weight sets [B][Cin][kh*kw*Cout]. */
+int somi_conv2d_dgrad_nhwc_f32(const somi_conv_desc *fwd, const float *dy, int dy_cs, int dy_coff, const float *w_dgrad,
+                               float *dx, int dx_cs, int dx_coff, const float *accumulate, int acc_cs, int acc_coff,
+                               somi_stream_t stream);
+
 /* Name of the kernel instantiation somi_conv2d_nhwc_f32 would launch for this descriptor (for profiling: matches the
  * kernel name rocprofv3 reports), or NULL for an invalid descriptor. */
 const char *somi_conv2d_kernel_name(const somi_conv_desc *d);

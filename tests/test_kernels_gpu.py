@@ -218,3 +218,27 @@ def test_detect_decode():
     want = torch.cat((xy, wh, y[..., 4:]), -1).reshape(B, -1, nc + 5)
     rel_close(z[:, row_off:row_off + na * ny * nx], want, rel=1e-5, what='decode')
     assert (z[:, :row_off] == 0).all()
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,s', [(2, 16, 16, 64, 128, 3, 1), (2, 17, 13, 32, 64, 3, 2), (3, 20, 20, 128, 256, 3, 2),
+                                                (2, 12, 12, 96, 64, 1, 1), (2, 9, 11, 20, 36, 3, 1), (2, 10, 10, 64, 32, 3, 2)])
+def test_conv_dgrad(B, H, W, Cin, Cout, k, s):
+    """dx of F.conv2d from the MFMA implicit-GEMM kernel in data-gradient geometry, against torch autograd on the CPU."""
+    from somi_amd import ops
+    from somi_amd.pack import pack_dgrad_weight
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + k + s)
+    d = dev()
+    p = k // 2
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    y = F.conv2d(x, w, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    acc = torch.randn(B, H, W, Cin, generator=g)
+    got = ops.conv2d_dgrad_nhwc(nhwc(dy).to(d), pack_dgrad_weight(w, cin_pad=Cin, cout_pad=Cout).to(d), B=B, H=H, W=W, cin=Cin,
+                                kh=k, kw=k, stride=s, pad=p)
+    rel_close(got, nhwc(x.grad), what='dgrad')
+    accd = acc.to(d)
+    ops.conv2d_dgrad_nhwc(nhwc(dy).to(d), pack_dgrad_weight(w, cin_pad=Cin, cout_pad=Cout).to(d), B=B, H=H, W=W, cin=Cin, kh=k, kw=k,
+                          stride=s, pad=p, out=accd, accumulate=accd)           # in-place accumulate (skip connection)
+    rel_close(accd, nhwc(x.grad) + acc, what='dgrad accumulate')

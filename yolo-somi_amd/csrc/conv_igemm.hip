@@ -44,6 +44,7 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, chan_bytes, pix_bytes;
     int stagger;  // s_sleep units (64 clk) for every second generation of workgroups
+    int dgrad;    // 1: data-gradient geometry (rows = forward-input pixels, source = dy, taps walk backwards, stride parity)
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
 
     // ---- per-thread fetch geometry: 16 B column kc of rows row0 + 32*i
     const int kc = (tid & 7) * 4, row0 = tid >> 3;
-    int a_hi0[A_ROWS], a_wi0[A_ROWS], a_off[A_ROWS], a_pixi[A_ROWS], a_chn[A_ROWS];
+    int a_hi0[A_ROWS], a_wi0[A_ROWS], a_off[A_ROWS], a_pixi[A_ROWS], a_chn[A_ROWS], a_par[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) a_par[i] = 0;
     const int HoWo = d.Ho * d.Wo;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -95,8 +98,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
         if (m < a.M) {
             const int b = m / HoWo + bz, rem = m % HoWo;
             const int ho = rem / d.Wo, wo = rem % d.Wo;
-            a_hi0[i] = ho * d.stride - d.pad;
-            a_wi0[i] = wo * d.stride - d.pad;
+            if (!a.dgrad) {
+                a_hi0[i] = ho * d.stride - d.pad;
+                a_wi0[i] = wo * d.stride - d.pad;
+            } else {                                                      // source row of tap r: (ho+pad)/s - r/s, valid iff r%s == (ho+pad)%s
+                a_hi0[i] = (ho + d.pad) / d.stride;
+                a_wi0[i] = (wo + d.pad) / d.stride;
+                a_par[i] = ((ho + d.pad) % d.stride) | (((wo + d.pad) % d.stride) << 8);
+            }
             a_pixi[i] = (b * d.H + a_hi0[i]) * d.W + a_wi0[i];           // pixel index of tap (0,0), may be "before" the image
             a_off[i] = a_pixi[i] * d.x_cs + d.x_coff;
             a_chn[i] = b * d.Cin;
@@ -119,8 +128,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
         for (int i = 0; i < A_ROWS; ++i) {
             unsigned mk = 0;
             for (int t = 0; t < ntap; ++t) {
-                const int hh = a_hi0[i] + (t / d.kw) * d.dil, ww = a_wi0[i] + (t % d.kw) * d.dil;
-                mk |= ((unsigned)hh < (unsigned)d.H && (unsigned)ww < (unsigned)d.W) ? (1u << t) : 0u;
+                const int tr = t / d.kw, tq = t % d.kw;
+                const int hh = a_hi0[i] + (a.dgrad ? -(tr / d.stride) : tr * d.dil);
+                const int ww = a_wi0[i] + (a.dgrad ? -(tq / d.stride) : tq * d.dil);
+                const bool par = !a.dgrad || ((tr % d.stride) == (a_par[i] & 255) && (tq % d.stride) == (a_par[i] >> 8));
+                mk |= (par && (unsigned)hh < (unsigned)d.H && (unsigned)ww < (unsigned)d.W) ? (1u << t) : 0u;
             }
             a_mask[i] = mk;
             a_offb[i] = (unsigned)(a_off[i] + kc) * 4u;
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
     f32x4 ra[A_ROWS], rb[B_ROWS];
     auto fetch_tile = [&](int kt_next) {
         if constexpr (FAST) {
-            const int dpix = (r_u * d.W + q_u) * d.dil;
+            const int dpix = a.dgrad ? -((r_u / d.stride) * d.W + q_u / d.stride) : (r_u * d.W + q_u) * d.dil;
             const unsigned sd = (unsigned)(dpix * d.x_cs + c0_u) * 4u, bit = 1u << tp_u;
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
@@ -155,12 +167,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
             return;
         }
         const bool kin = k < a.K;
-        const int dh = r * d.dil, dw = q * d.dil;
+        const int dh = a.dgrad ? -(r / d.stride) : r * d.dil, dw = a.dgrad ? -(q / d.stride) : q * d.dil;
         const int dpix = dh * d.W + dw;
         const int delta = dpix * d.x_cs + c;
+        const int rpar = a.dgrad ? ((r % d.stride) | ((q % d.stride) << 8)) : 0;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const bool ok = kin && (unsigned)(a_hi0[i] + dh) < (unsigned)d.H && (unsigned)(a_wi0[i] + dw) < (unsigned)d.W;
+            const bool ok = kin && a_par[i] == rpar && (unsigned)(a_hi0[i] + dh) < (unsigned)d.H &&
+                            (unsigned)(a_wi0[i] + dw) < (unsigned)d.W;
             f32x4 v = buf_load4(rx, ok ? (unsigned)(a_off[i] + delta) * 4u : OOB);
             if constexpr (MODULATE) {
                 if (has_chan) v *= buf_load4(rc, ok ? (unsigned)(a_chn[i] + c) * 4u : OOB);
@@ -339,15 +353,15 @@ static int pick_tile(const somi_conv_desc &d, int M) {
 
 }  // namespace somi
 
-extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stream) {
-    using namespace somi;
+namespace somi {
+static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad) {
     SOMI_REQUIRE(dp, SOMI_EINVAL, "conv: null descriptor");
     const somi_conv_desc &d = *dp;
     SOMI_REQUIRE(d.x && d.w && d.y, SOMI_EINVAL, "conv: null tensor");
     SOMI_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0, SOMI_EINVAL, "conv: empty shape");
     SOMI_REQUIRE(d.kh > 0 && d.kw > 0 && d.stride > 0 && d.dil > 0 && d.pad >= 0, SOMI_EINVAL, "conv: bad geometry");
-    SOMI_REQUIRE(d.Ho == (d.H + 2 * d.pad - (d.dil * (d.kh - 1) + 1)) / d.stride + 1 &&
-                     d.Wo == (d.W + 2 * d.pad - (d.dil * (d.kw - 1) + 1)) / d.stride + 1,
+    SOMI_REQUIRE(dgrad || (d.Ho == (d.H + 2 * d.pad - (d.dil * (d.kh - 1) + 1)) / d.stride + 1 &&
+                           d.Wo == (d.W + 2 * d.pad - (d.dil * (d.kw - 1) + 1)) / d.stride + 1),
                  SOMI_EINVAL, "conv: Ho/Wo (%d,%d) do not match the geometry", d.Ho, d.Wo);
     SOMI_REQUIRE(d.Cin % 4 == 0 && d.x_cs % 4 == 0 && d.x_coff % 4 == 0 && aligned16(d.x) && aligned16(d.w),
                  SOMI_EINVAL, "conv: Cin (%d), x_cs (%d), x_coff (%d) must be multiples of 4 and bases 16 B aligned",
@@ -379,6 +393,7 @@ extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stre
     a.pix_bytes = (unsigned)((size_t)d.B * d.H * d.W * 4);
     static const int stagger_env = getenv("SOMI_CONV_STAGGER") ? atoi(getenv("SOMI_CONV_STAGGER")) : 0;
     a.stagger = stagger_env;
+    a.dgrad = dgrad;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (pick_tile(d, a.M)) {
         case 0: return launch<128, 128, 2, 2>(a, s);
@@ -386,6 +401,30 @@ extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stre
         case 2: return launch<128, 64, 2, 2>(a, s);
         default: return launch<128, 32, 4, 1>(a, s);
     }
+}
+}  // namespace somi
+
+extern "C" int somi_conv2d_nhwc_f32(const somi_conv_desc *dp, somi_stream_t stream) { return somi::conv_launch(dp, stream, 0); }
+
+// Data gradient of the convolution described by `f` (forward geometry: x (B,H,W,Cin) -> y (B,Ho,Wo,Cout)):
+//   dx[b,h,w,ci] = sum_{r,q,co} dy[b, (h+p-r)/s, (w+p-q)/s, co] * W[co][ci][r][q]   over taps with (h+p-r) % s == 0 etc.
+// The same implicit-GEMM kernel runs with rows = forward-input pixels and the reduction over (tap, co); `wt` is the
+// dgrad packing [Cin][kh*kw*Cout] (k = (r*kw+q)*Cout + co), see somi_pack_dgrad_weights_f32.
+extern "C" int somi_conv2d_dgrad_nhwc_f32(const somi_conv_desc *f, const float *dy, int dy_cs, int dy_coff, const float *wt,
+                                          float *dx, int dx_cs, int dx_coff, const float *accumulate, int acc_cs, int acc_coff,
+                                          somi_stream_t stream) {
+    using namespace somi;
+    SOMI_REQUIRE(f && dy && wt && dx, SOMI_EINVAL, "conv dgrad: null argument");
+    SOMI_REQUIRE(f->dil == 1, SOMI_ENOTIMPL, "conv dgrad: dilation 1 only");
+    SOMI_REQUIRE(f->Ho == (f->H + 2 * f->pad - f->kh) / f->stride + 1 && f->Wo == (f->W + 2 * f->pad - f->kw) / f->stride + 1,
+                 SOMI_EINVAL, "conv dgrad: Ho/Wo do not match the forward geometry");
+    somi_conv_desc g{};
+    g.x = dy; g.w = wt; g.y = dx; g.residual = accumulate;
+    g.B = f->B; g.H = f->Ho; g.W = f->Wo; g.Cin = f->Cout; g.x_cs = dy_cs; g.x_coff = dy_coff;      // source = dy
+    g.Ho = f->H; g.Wo = f->W; g.Cout = f->Cin; g.y_cs = dx_cs; g.y_coff = dx_coff;                  // rows = forward-input pixels
+    g.kh = f->kh; g.kw = f->kw; g.stride = f->stride; g.pad = f->pad; g.dil = 1;
+    g.res_cs = acc_cs; g.res_coff = acc_coff; g.act = SOMI_ACT_NONE; g.per_sample_w = f->per_sample_w;
+    return conv_launch(&g, stream, 1);
 }
 
 extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {

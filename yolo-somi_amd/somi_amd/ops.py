@@ -231,3 +231,22 @@ def cfs_blend(x, xproj, logit, G, Gc):
     check(_lib.lib().somi_dcnv3_cfs_blend_f32(_ptr(_f32c(x)), _ptr(_f32c(xproj)), _ptr(_f32c(logit)), logit.shape[-1], _ptr(out),
                                               x.numel() // (G * Gc), G, Gc, _stream()), 'cfs_blend')
     return out
+
+
+def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cout=None, dy_coff=0, out=None, dx_coff=0,
+                      accumulate=None, acc_coff=0, per_sample_w=False):
+    """dx of the conv x (B,H,W,cin) -> y (B,Ho,Wo,cout); dy is (B,Ho,Wo,dy_cs); w_dgrad packed [cin][kh*kw*cout]."""
+    _, Ho, Wo, dy_cs = dy.shape
+    cout = dy_cs - dy_coff if cout is None else cout
+    if out is None:
+        out = torch.empty(B, H, W, cin, device=dy.device, dtype=torch.float32)
+    d = ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, cin, Ho, Wo, cout
+    d.kh, d.kw, d.stride, d.pad, d.dil, d.per_sample_w = kh, kw, stride, pad, 1, int(per_sample_w)
+    if w_dgrad.numel() != (B if per_sample_w else 1) * cin * kh * kw * cout:
+        raise RuntimeError('dgrad weight has the wrong number of elements')
+    check(_lib.lib().somi_conv2d_dgrad_nhwc_f32(C.byref(d), _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(w_dgrad)), _ptr(_f32c(out)),
+                                                out.shape[3], dx_coff, _ptr(accumulate),
+                                                accumulate.shape[3] if accumulate is not None else 0, acc_coff, _stream()),
+          'conv2d_dgrad_nhwc')
+    return out

@@ -26,3 +26,13 @@ def bn_fold(bn):
     """eval-mode BatchNorm as y = x*scale + shift (utils/torch_utils.py:212-219 uses the same two terms)."""
     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     return scale, bn.bias - bn.running_mean * scale
+
+
+def pack_dgrad_weight(w, cin_pad=None, cout_pad=None):
+    """(Cout,Cin,kh,kw) -> [Cin_pad][kh*kw*Cout_pad], k = (r*kw+q)*Cout_pad + co (operand of somi_conv2d_dgrad_nhwc_f32)."""
+    Cout, Cin, kh, kw = w.shape
+    cin_pad = pad4(Cin) if cin_pad is None else cin_pad
+    cout_pad = pad4(Cout) if cout_pad is None else cout_pad
+    out = torch.zeros(cin_pad, kh, kw, cout_pad, dtype=torch.float32, device=w.device)
+    out[:Cin, :, :, :Cout] = w.permute(1, 2, 3, 0)
+    return out.reshape(cin_pad, kh * kw * cout_pad).contiguous()
