@@ -87,6 +87,16 @@ int somi_conv2d_dgrad_nhwc_f32(const somi_conv_desc *fwd, const float *dy, int d
                                float *dx, int dx_cs, int dx_coff, const float *accumulate, int acc_cs, int acc_coff,
                                somi_stream_t stream);
 
+/* Weight gradient of the convolution whose FORWARD geometry `fwd` describes:
+ *   dw[co][(r*kw+q)*Cin + ci] = sum_{b,ho,wo} dy[b,ho,wo,co] * x[b, ho*s-p+r, wo*s-p+q, ci]     (same packing as the forward weights)
+ * MFMA GEMM with the reduction over pixels, split over workgroups; the split partials live in `workspace`
+ * (somi_conv2d_wgrad_workspace_bytes) and are summed in a fixed order, on top of `accumulate` if given (may alias dw).
+ * per_sample_w: one gradient per image, dw is [B][Cout][K]. Cin, Cout multiples of 4. */
+size_t somi_conv2d_wgrad_workspace_bytes(const somi_conv_desc *fwd);
+int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float *x, int x_cs, int x_coff, const float *dy, int dy_cs,
+                               int dy_coff, float *dw, const float *accumulate, void *workspace, size_t workspace_bytes,
+                               somi_stream_t stream);
+
 /* Name of the kernel instantiation somi_conv2d_nhwc_f32 would launch for this descriptor (for profiling: matches the
  * kernel name rocprofv3 reports), or NULL for an invalid descriptor. */
 const char *somi_conv2d_kernel_name(const somi_conv_desc *d);

@@ -242,3 +242,36 @@ def test_conv_dgrad(B, H, W, Cin, Cout, k, s):
     ops.conv2d_dgrad_nhwc(nhwc(dy).to(d), pack_dgrad_weight(w, cin_pad=Cin, cout_pad=Cout).to(d), B=B, H=H, W=W, cin=Cin, kh=k, kw=k,
                           stride=s, pad=p, out=accd, accumulate=accd)           # in-place accumulate (skip connection)
     rel_close(accd, nhwc(x.grad) + acc, what='dgrad accumulate')
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,s,ps', [(2, 16, 16, 64, 128, 3, 1, False), (2, 17, 13, 32, 64, 3, 2, False),
+                                                   (4, 40, 40, 128, 256, 3, 2, False), (2, 12, 12, 96, 68, 1, 1, False),
+                                                   (2, 9, 11, 20, 36, 3, 1, False), (3, 33, 31, 4, 64, 3, 2, False),
+                                                   (3, 12, 12, 32, 48, 3, 2, True), (16, 20, 20, 256, 132, 1, 1, False)])
+def test_conv_wgrad(B, H, W, Cin, Cout, k, s, ps):
+    """dW of F.conv2d from the MFMA split-K weight-gradient kernel, against torch autograd on the CPU."""
+    from somi_amd import ops
+    from somi_amd.pack import pack_conv_weight
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + k + s)
+    d = dev()
+    p = k // 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy_shape = F.conv2d(x[:1], torch.zeros(Cout, Cin, k, k), None, s, p).shape
+    dy = torch.randn(B, *dy_shape[1:], generator=g)
+    if ps:
+        want = []
+        for b in range(B):
+            w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+            F.conv2d(x[b:b + 1], w, None, s, p).backward(dy[b:b + 1])
+            want.append(pack_conv_weight(w.grad, cin_pad=Cin))
+        want = torch.stack(want)
+    else:
+        w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+        F.conv2d(x, w, None, s, p).backward(dy)
+        want = pack_conv_weight(w.grad, cin_pad=Cin)
+    got = ops.conv2d_wgrad_nhwc(nhwc(x).to(d), nhwc(dy).to(d), kh=k, kw=k, stride=s, pad=p, per_sample_w=ps)
+    rel_close(got, want, what='wgrad')
+    prev = torch.randn(want.shape, generator=g)
+    acc = prev.to(d)
+    ops.conv2d_wgrad_nhwc(nhwc(x).to(d), nhwc(dy).to(d), kh=k, kw=k, stride=s, pad=p, per_sample_w=ps, out=acc, accumulate=acc)
+    rel_close(acc, want + prev, what='wgrad accumulate')

@@ -1,0 +1,263 @@
+// Weight gradient of the NHWC convolution on the fp32 matrix cores of gfx950 (autograd of F.conv2d w.r.t. its weight,
+// train.py:270 `scaler.scale(loss).backward()`):
+//   dW[co][(r*kw+q)*Cin + ci] = sum over pixels (b,ho,wo) of dy[b,ho,wo,co] * x[b, ho*s-p+r, wo*s-p+q, ci]
+// GEMM view: rows = co, columns = (tap, ci), reduction = pixels.  A workgroup (256 threads, 4 waves) owns a 128 (co) x BN (ci,
+// one tap) tile and a contiguous slice of the pixel range (split-K); every 32-pixel K-tile it stages dy[32][128] and the
+// tap-shifted x[32][BN] rows (16 B buffer loads, padding by the hardware range check) into a double-buffered LDS image
+// [pixel][channel] and feeds v_mfma_f32_32x32x2_f32 with one ds_read_b32 per operand value (lanes = consecutive channels,
+// conflict-free).  Partial tiles of the splits go to a workspace and are summed in a fixed order (deterministic), optionally
+// on top of an existing gradient.
+#include "common.h"
+
+namespace somi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_PIX = 32;                  // pixels per K-tile
+constexpr unsigned W_OOB = 0xFFFFFFE0u;
+constexpr unsigned W_MAX_BUF = 0xE0000000u;
+
+struct WgradArgs {
+    const float *x, *dy;
+    float *out;                              // [splits][n_sets][Cout][K]  (workspace) or dW itself when splits == 1
+    int B, H, W, Cin, x_cs, x_coff, Ho, Wo, Cout, dy_cs, dy_coff, kh, kw, stride, pad;
+    int K;                                   // kh*kw*Cin
+    int tiles_co, tiles_ci, splits, pix_per_split, npix;   // npix = pixels per weight set (B*Ho*Wo, or Ho*Wo per sample)
+    int per_sample;
+    unsigned x_bytes, dy_bytes;
+};
+
+__device__ __forceinline__ f32x4 wbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+template <int BN>   // BN in {128, 64, 32}: ci columns per tile; co rows are always 128
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs a) {
+    constexpr int BM = 128;
+    constexpr int WAVES_N = BN == 128 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM, B_LD = BN;
+    constexpr int TILE = WG_PIX * (A_LD + B_LD);
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntaps = a.kh * a.kw;
+    // tile decode: blockIdx.x = ((tile_co * ntaps + tap) * tiles_ci + tile_ci), blockIdx.y = split, blockIdx.z = weight set
+    int t = blockIdx.x;
+    const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
+    const int tap = t % ntaps;
+    const int tile_co = t / ntaps;
+    const int split = blockIdx.y, set = blockIdx.z;
+    const int co0 = tile_co * BM, ci0 = tile_ci * BN;
+    const int r = tap / a.kw, q = tap % a.kw;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
+
+    // pixel range of this split inside the weight set
+    const int p_lo = split * a.pix_per_split, p_hi = min(p_lo + a.pix_per_split, a.npix);
+    const long set_pix0 = (long)set * a.npix;                            // first pixel of this set in the flattened (b,ho,wo) order
+
+    // fetch geometry.  A (dy): 32 pixels x BM floats = BM/4 quads per pixel.  thread -> (pixel row, quad), rows strided.
+    constexpr int A_QUADS = BM / 4, B_QUADS = BN / 4;
+    constexpr int A_ROWS_PER_PASS = 256 / A_QUADS, B_ROWS_PER_PASS = 256 / B_QUADS;      // 8 ; 8,16,32
+    const int a_quad = tid % A_QUADS, a_row0 = tid / A_QUADS;
+    const int b_quad = tid % B_QUADS, b_row0 = tid / B_QUADS;
+    const bool a_col_ok = co0 + a_quad * 4 < a.Cout, b_col_ok = ci0 + b_quad * 4 < a.Cin;
+    constexpr int A_N = WG_PIX / A_ROWS_PER_PASS, B_N = WG_PIX / B_ROWS_PER_PASS;        // 4 ; 4,2,1
+
+    // per B-row pixel coordinates (b, ho, wo) advanced incrementally by WG_PIX per K-tile
+    int bb[B_N], bho[B_N], bwo[B_N];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+        const long P = set_pix0 + p_lo + b_row0 + i * B_ROWS_PER_PASS;
+        bb[i] = (int)(P / HoWo);
+        const int rem = (int)(P % HoWo);
+        bho[i] = rem / a.Wo;
+        bwo[i] = rem % a.Wo;
+    }
+    f32x4 ra[A_N], rb[B_N];
+    auto fetch = [&](int pt) {                                            // pt = first pixel (inside the split) of the K-tile
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+            const int pl = pt + a_row0 + i * A_ROWS_PER_PASS;
+            const bool ok = a_col_ok && p_lo + pl < p_hi;
+            const unsigned off = (unsigned)(((set_pix0 + p_lo + pl) * a.dy_cs + a.dy_coff + co0 + a_quad * 4) * 4);
+            ra[i] = wbuf_load4(rdy, ok ? off : W_OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) {
+            const int pl = pt + b_row0 + i * B_ROWS_PER_PASS;
+            const int hi = bho[i] * a.stride - a.pad + r, wi = bwo[i] * a.stride - a.pad + q;
+            const bool ok = b_col_ok && p_lo + pl < p_hi && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const unsigned off = (unsigned)((((long)(bb[i] * a.H + hi) * a.W + wi) * a.x_cs + a.x_coff + ci0 + b_quad * 4) * 4);
+            rb[i] = wbuf_load4(rx, ok ? off : W_OOB);
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) {
+            bwo[i] += WG_PIX;
+            while (bwo[i] >= a.Wo) {
+                bwo[i] -= a.Wo;
+                if (++bho[i] == a.Ho) { bho[i] = 0; ++bb[i]; }
+            }
+        }
+    };
+    auto store = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < A_N; ++i)
+            *reinterpret_cast<f32x4 *>(&buf[(a_row0 + i * A_ROWS_PER_PASS) * A_LD + a_quad * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_N; ++i)
+            *reinterpret_cast<f32x4 *>(&buf[WG_PIX * A_LD + (b_row0 + i * B_ROWS_PER_PASS) * B_LD + b_quad * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nkt = (p_hi - p_lo + WG_PIX - 1) / WG_PIX;
+    const int a_frag = (lane >> 5) * A_LD + wm * WM + (lane & 31);
+    const int b_frag = WG_PIX * A_LD + (lane >> 5) * B_LD + wn * WN + (lane & 31);
+    auto mma_quarter = [&](const float *buf, int qtr) {                   // 4 of the 16 k-steps (8 pixels)
+#pragma unroll
+        for (int ks = qtr * 4; ks < qtr * 4 + 4; ++ks) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = buf[a_frag + ks * 2 * A_LD + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = buf[b_frag + ks * 2 * B_LD + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nkt > 0) {
+        fetch(0);
+        store(lds);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const float *cur = lds + (kt & 1) * TILE;
+        float *nxt = lds + ((kt + 1) & 1) * TILE;
+        const bool more = kt + 1 < nkt;
+        mma_quarter(cur, 0);
+        if (more) {
+            advance();
+            fetch((kt + 1) * WG_PIX);
+        }
+        mma_quarter(cur, 1);
+        mma_quarter(cur, 2);
+        if (more) store(nxt);
+        mma_quarter(cur, 3);
+        __syncthreads();
+    }
+
+    // D[co][ci]: col = lane&31 -> ci, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -> co
+    float *out = a.out + ((size_t)split * gridDim.z + set) * a.Cout * a.K;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + wn * WN + j * 32 + (lane & 31);
+        if (ci >= a.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout) out[(size_t)co * a.K + tap * a.Cin + ci] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+// dW = (accumulate ? accumulate : 0) + sum_s part[s]   (fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int splits, long n, const float *accumulate,
+                                                           float *__restrict__ dw) {
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 s = accumulate ? *reinterpret_cast<const f32x4 *>(accumulate + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(part + (size_t)k * n + i * 4);
+        *reinterpret_cast<f32x4 *>(dw + i * 4) = s;
+    }
+}
+
+static int plan(const somi_conv_desc &f, WgradArgs &a) {
+    SOMI_REQUIRE(f.B > 0 && f.H > 0 && f.W > 0 && f.Cin > 0 && f.Cout > 0 && f.kh > 0 && f.kw > 0 && f.stride > 0 && f.pad >= 0,
+                 SOMI_EINVAL, "conv wgrad: bad geometry");
+    SOMI_REQUIRE(f.dil == 1, SOMI_ENOTIMPL, "conv wgrad: dilation 1 only");
+    SOMI_REQUIRE(f.Ho == (f.H + 2 * f.pad - f.kh) / f.stride + 1 && f.Wo == (f.W + 2 * f.pad - f.kw) / f.stride + 1, SOMI_EINVAL,
+                 "conv wgrad: Ho/Wo do not match the forward geometry");
+    SOMI_REQUIRE(f.Cin % 4 == 0 && f.Cout % 4 == 0, SOMI_EINVAL, "conv wgrad: Cin and Cout must be multiples of 4");
+    a.B = f.B; a.H = f.H; a.W = f.W; a.Cin = f.Cin; a.Ho = f.Ho; a.Wo = f.Wo; a.Cout = f.Cout;
+    a.kh = f.kh; a.kw = f.kw; a.stride = f.stride; a.pad = f.pad;
+    a.K = f.kh * f.kw * f.Cin;
+    a.per_sample = f.per_sample_w ? 1 : 0;
+    a.npix = a.per_sample ? f.Ho * f.Wo : f.B * f.Ho * f.Wo;
+    const int bn = f.Cin > 64 ? 128 : (f.Cin > 32 ? 64 : 32);
+    a.tiles_co = cdiv(f.Cout, 128);
+    a.tiles_ci = cdiv(f.Cin, bn);
+    const long tiles = (long)a.tiles_co * a.tiles_ci * f.kh * f.kw * (a.per_sample ? f.B : 1);
+    // enough splits to fill the chip a few times over, but at least 8 K-tiles of work per split
+    long want = (1536 + tiles - 1) / tiles;
+    const long max_splits = (a.npix + WG_PIX * 8 - 1) / (WG_PIX * 8);
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    a.pix_per_split = (int)(((a.npix + want - 1) / want + WG_PIX - 1) / WG_PIX * WG_PIX);
+    a.splits = cdiv(a.npix, a.pix_per_split);
+    return 0;
+}
+
+}  // namespace somi
+
+using namespace somi;
+
+extern "C" size_t somi_conv2d_wgrad_workspace_bytes(const somi_conv_desc *fwd) {
+    WgradArgs a{};
+    if (!fwd || plan(*fwd, a)) return 0;
+    if (a.splits <= 1) return 256;
+    return (size_t)a.splits * (a.per_sample ? a.B : 1) * a.Cout * a.K * 4 + 256;
+}
+
+extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float *x, int x_cs, int x_coff, const float *dy, int dy_cs,
+                                          int dy_coff, float *dw, const float *accumulate, void *workspace, size_t workspace_bytes,
+                                          somi_stream_t stream) {
+    SOMI_REQUIRE(fwd && x && dy && dw && workspace, SOMI_EINVAL, "conv wgrad: null argument");
+    WgradArgs a{};
+    int rc = plan(*fwd, a);
+    if (rc) return rc;
+    SOMI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && dy_cs % 4 == 0 && dy_coff % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dw),
+                 SOMI_EINVAL, "conv wgrad: strides / offsets must be multiples of 4 and bases 16 B aligned");
+    SOMI_REQUIRE(x_coff + a.Cin <= x_cs && dy_coff + a.Cout <= dy_cs, SOMI_EINVAL, "conv wgrad: channel slice out of range");
+    SOMI_REQUIRE(workspace_bytes >= somi_conv2d_wgrad_workspace_bytes(fwd), SOMI_EWORKSPACE, "conv wgrad: workspace too small");
+    const size_t xb = (size_t)a.B * a.H * a.W * x_cs * 4, yb = (size_t)a.B * a.Ho * a.Wo * dy_cs * 4;
+    SOMI_REQUIRE(xb <= W_MAX_BUF && yb <= W_MAX_BUF, SOMI_ENOTIMPL, "conv wgrad: tensors exceed the 4 GiB descriptor range; split the batch");
+    a.x = x; a.dy = dy; a.x_cs = x_cs; a.x_coff = x_coff; a.dy_cs = dy_cs; a.dy_coff = dy_coff;
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    const int sets = a.per_sample ? a.B : 1;
+    const bool direct = a.splits == 1 && !accumulate;
+    a.out = direct ? dw : static_cast<float *>(workspace);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(a.tiles_co * a.tiles_ci * a.kh * a.kw, a.splits, sets);
+    if (a.Cin > 64) hipLaunchKernelGGL(conv_wgrad_f32_kernel<128>, grid, dim3(256), 0, s, a);
+    else if (a.Cin > 32) hipLaunchKernelGGL(conv_wgrad_f32_kernel<64>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_f32_kernel<32>, grid, dim3(256), 0, s, a);
+    if (!direct) {
+        const long n = (long)sets * a.Cout * a.K;
+        long g = (n / 4 + 255) / 256;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s,
+                           static_cast<const float *>(workspace), a.splits, n, accumulate, dw);
+    }
+    return launch_status("somi_conv2d_wgrad_nhwc_f32");
+}

@@ -250,3 +250,24 @@ def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cou
                                                 accumulate.shape[3] if accumulate is not None else 0, acc_coff, _stream()),
           'conv2d_dgrad_nhwc')
     return out
+
+
+def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cout=None, dy_coff=0, out=None, accumulate=None,
+                      per_sample_w=False):
+    """dW [Cout][kh*kw*Cin] (forward packing) of the conv x (B,H,W,cin) -> y (B,Ho,Wo,cout) from x and dy."""
+    B, H, W, x_cs = x.shape
+    _, Ho, Wo, dy_cs = dy.shape
+    cin = x_cs - x_coff if cin is None else cin
+    cout = dy_cs - dy_coff if cout is None else cout
+    d = ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, cin, Ho, Wo, cout
+    d.kh, d.kw, d.stride, d.pad, d.dil, d.per_sample_w = kh, kw, stride, pad, 1, int(per_sample_w)
+    shape = ((B,) if per_sample_w else ()) + (cout, kh * kw * cin)
+    if out is None:
+        out = torch.empty(*shape, device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    nbytes = L.somi_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
+    check(L.somi_conv2d_wgrad_nhwc_f32(C.byref(d), _ptr(_f32c(x)), x_cs, x_coff, _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(out)),
+                                       _ptr(accumulate), _ptr(ws), nbytes, _stream()), 'conv2d_wgrad_nhwc')
+    return out
