@@ -216,6 +216,32 @@ int somi_detect_decode_f32(const float *box, int box_cs, const float *cls, int c
                            int row_off, somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-mode normalisation / activation (nn.BatchNorm2d with batch statistics: models/common.py:64-66 under model.train(),
+ * eps 1e-3 / momentum 0.03 from utils/torch_utils.py:165-174; SEAM's act-then-norm stages models/common.py:8454-8466).
+ * Tensors are channel slices (cs, coff) of NHWC buffers with npix = B*H*W rows.  order 0: z = act(x*scale+shift) (norm then
+ * act); order 1: z = act(x)*scale+shift (act then norm).  Workspaces: bn_stats 2*nchunk*C floats,
+ * bn_act_backward 2*nchunk*C + 3*C(+pad to 4) floats, chan_sum 2*nchunk*C floats, nchunk = somi_red_nchunk(npix).
+ */
+int somi_red_nchunk(long npix);
+/* batch mean / biased variance of x per channel -> mean, rstd = 1/sqrt(var+eps), scale = gamma*rstd, shift = beta - mean*scale;
+ * running_mean / running_var (optional) updated with `momentum` and the unbiased variance like nn.BatchNorm2d. */
+int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float eps, float momentum,
+                           const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                           float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
+int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act,
+                                  int order, float *z, int z_cs, int z_coff, long npix, int C, somi_stream_t stream);
+/* gradient of z = [order 0] act(norm(x)) / [order 1] norm(act(x)) w.r.t. x (written to dx, may alias dz), and dgamma / dbeta
+ * ACCUMULATED into the given arrays (may be NULL).  batch_stats = 1: statistics were computed from this batch (train);
+ * 0: frozen statistics (the norm is a per-channel affine map). */
+int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
+                                  const float *rstd, const float *scale, const float *shift, int act, int order,
+                                  int batch_stats, float *dx, int dx_cs, int dx_coff, float *dgamma, float *dbeta, long npix,
+                                  int C, float *workspace, somi_stream_t stream);
+/* out[c] += sum over pixels of x[p,c] (bias gradients) */
+int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float *out_accumulate, float *workspace,
+                           somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.
  * Selection is bit-exact with the oracle: candidates in prediction order (row-major over (box, class) for

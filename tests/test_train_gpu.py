@@ -1,0 +1,68 @@
+"""Training-mode kernels and block backward passes on the MI355X against torch autograd on the CPU (the oracle blocks in
+train mode).  Bar 1e-3 relative."""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ACTS = {'none': lambda v: v, 'silu': F.silu, 'gelu': F.gelu, 'relu': F.relu}
+
+
+def rel_close(got, want, rel=1e-3, what=''):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-12
+    assert err <= rel * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('order,act,batch_stats', [(0, 'silu', True), (1, 'gelu', True), (0, 'silu', False), (0, 'none', True)])
+def test_bn_act_forward_backward(order, act, batch_stats):
+    from somi_amd import ops
+    g = torch.Generator().manual_seed(order * 10 + len(act))
+    B, C, H, W = 3, 24, 13, 9
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train(batch_stats)
+    z = ACTS[act](bn(x)) if order == 0 else bn(ACTS[act](x))
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    d = torch.device('cuda')
+    wide = torch.zeros(B, H, W, C + 8)
+    wide[..., 4:4 + C] = nhwc(x.detach())
+    xd = wide.to(d)
+    gam, bet = bn.weight.detach().to(d), bn.bias.detach().to(d)
+    if batch_stats:
+        rm, rv = rm0.to(d), rv0.to(d)
+        src = xd if order == 0 else ops.chan_affine_act(xd, C, 4, torch.ones(C, device=d), torch.zeros(C, device=d), act, 0,
+                                                        torch.zeros_like(xd), 4)
+        mean, rstd, scale, shift = ops.bn_stats(src, C, 4, gam, bet, 1e-3, 0.03, rm, rv)
+        rel_close(rm, bn.running_mean, what='running_mean')
+        rel_close(rv, bn.running_var, what='running_var')
+    else:
+        mean = rm0.to(d)
+        rstd = (1.0 / torch.sqrt(rv0 + 1e-3)).to(d)
+        scale = gam * rstd
+        shift = bet - mean * scale
+    out = torch.zeros(B, H, W, C, device=d)
+    ops.chan_affine_act(xd, C, 4, scale, shift, act, order, out)
+    rel_close(out, nhwc(z), what='forward')
+    dgam, dbet = torch.zeros(C, device=d), torch.zeros(C, device=d)
+    dx = torch.zeros(B, H, W, C, device=d)
+    ops.bn_act_backward(nhwc(dz).to(d), 0, xd, 4, C, mean, rstd, scale, shift, act, order, batch_stats, dx, 0, dgam, dbet)
+    rel_close(dx, nhwc(x.grad), what='dx')
+    rel_close(dgam, bn.weight.grad, what='dgamma')
+    rel_close(dbet, bn.bias.grad, what='dbeta')

@@ -1,0 +1,274 @@
+// Training-mode kernels around the convolutions: batch-norm statistics, the fused normalise+activation pass and its
+// backward (reduce + apply), activation derivatives.  All NHWC fp32, channel slices via (cs, coff), 16 B per lane.
+//
+// Conv block in training mode (models/common.py:64-66, nn.BatchNorm2d with batch statistics, eps 1e-3, momentum 0.03 set by
+// utils/torch_utils.py:165-174):      y = conv(x);  z = act(y * scale[c] + shift[c])   with scale = gamma*rstd, shift = beta - mean*scale
+// SEAM stage (models/common.py:8454-8466): g = act(u); z = g * scale[c] + shift[c]      (activation BEFORE the norm)
+// Backward of the norm with batch statistics over N = B*H*W samples per channel, for its input v and upstream gradient dv_out:
+//   d v = scale * ( d - mean(d) - vhat * mean(d * vhat) ),   vhat = (v - mean) * rstd
+// which is affine per channel in (d, v):  dv = A[c]*d + Bc[c]*v + Cc[c].  The reduce kernel produces S1 = sum d, S2 = sum d*v,
+// a tiny finalize turns them into (A, Bc, Cc, dgamma, dbeta), the apply kernel writes dv (fused with the activation derivative).
+#include "common.h"
+
+namespace somi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RED_CHUNK = 512;       // pixels per stage-1 workgroup
+
+__device__ __forceinline__ float act_fwd(float u, int act) { return apply_act_rt(u, act); }
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case SOMI_ACT_SILU: { const float s = 1.f / (1.f + expf(-u)); return s * (1.f + u * (1.f - s)); }
+        case SOMI_ACT_GELU: return 0.5f * (1.f + erff(u * 0.70710678118654752440f)) + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+        case SOMI_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case SOMI_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-u)); return s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+
+// ---- generic two-stage per-channel reduction over pixels: each workgroup reduces RED_CHUNK pixels for all channels.
+// F(p, c4) returns up to two float4 terms for pixel p, channel quad c4.
+template <typename F>
+__device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, float *part2, int nchunk, F f) {
+    __shared__ f32x4 l1[256], l2[256];
+    const int chunk = blockIdx.x;
+    const int C4 = C >> 2;
+    const long p0 = (long)chunk * RED_CHUNK, p1 = min(p0 + RED_CHUNK, npix);
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (rr < rows_par)
+            for (long p = p0 + rr; p < p1; p += rows_par) f(p, (cq0 + cq) * 4, s1, s2);
+        l1[threadIdx.x] = s1;
+        l2[threadIdx.x] = s2;
+        __syncthreads();
+        if (threadIdx.x < ncq) {
+            for (int r2 = 1; r2 < rows_par; ++r2) { s1 += l1[r2 * ncq + cq]; s2 += l2[r2 * ncq + cq]; }
+            const long o = (long)chunk * C + (cq0 + cq) * 4;
+            *reinterpret_cast<f32x4 *>(part1 + o) = s1;
+            *reinterpret_cast<f32x4 *>(part2 + o) = s2;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN statistics
+__global__ __launch_bounds__(256) void bn_stats_stage1(const float *__restrict__ x, int cs, int coff, long npix, int C,
+                                                       float *__restrict__ p1, float *__restrict__ p2, int nchunk) {
+    chunk_reduce2(npix, C, p1, p2, nchunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * cs + coff + c);
+        s1 += v;
+        s2 += v * v;
+    });
+}
+// mean, biased var; scale/shift for the normalise pass; running statistics update (unbiased var, momentum), like nn.BatchNorm2d
+__global__ __launch_bounds__(256) void bn_stats_stage2(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C,
+                                                       long npix, float eps, float momentum, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float *__restrict__ mean, float *__restrict__ rstd,
+                                                       float *__restrict__ scale, float *__restrict__ shift, float *running_mean,
+                                                       float *running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) { s += p1[(long)k * C + c]; q += p2[(long)k * C + c]; }
+    const double m = s / (double)npix;
+    double var = q / (double)npix - m * m;
+    if (var < 0.0) var = 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    rstd[c] = rs;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * rs;
+    shift[c] = b - (float)m * g * rs;
+    if (running_mean) {
+        const double unb = npix > 1 ? var * (double)npix / (double)(npix - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ affine + activation
+// order 0: z = act(x*scale + shift) ; order 1: z = act(x)*scale + shift        (x, z: channel slices; in place allowed)
+__global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__restrict__ x, int x_cs, int x_coff,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift, int act,
+                                                              int order, float *__restrict__ z, int z_cs, int z_coff, long npix, int C) {
+    const int C4 = C >> 2;
+    const long items = npix * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long p = it / C4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+        if (order == 0) {
+            v = v * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
+            v = v * sc + sh;
+        }
+        *reinterpret_cast<f32x4 *>(z + p * z_cs + z_coff + c) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: reduce
+// order 0 (norm then act): d = dz * act'(x*scale+shift), v = x.      S1 = sum d, S2 = sum d*v
+// order 1 (act then norm): d = dz,                       v = act(x). S1 = sum d, S2 = sum d*v
+__global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
+                                                         int x_cs, int x_coff, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int act, int order, long npix, int C,
+                                                         float *__restrict__ p1, float *__restrict__ p2, int nchunk) {
+    chunk_reduce2(npix, C, p1, p2, nchunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
+        f32x4 d, w;
+        if (order == 0) {
+            const f32x4 u = v * *reinterpret_cast<const f32x4 *>(scale + c) + *reinterpret_cast<const f32x4 *>(shift + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = g[e] * act_grad(u[e], act);
+            w = v;
+        } else {
+            d = g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = act_fwd(v[e], act);
+        }
+        s1 += d;
+        s2 += d * w;
+    });
+}
+// finalize: per channel coefficients of dv = A*d + Bc*v + Cc, and the parameter gradients (accumulated into dgamma / dbeta)
+//   batch statistics (train):  D = rstd*(S2 - mean*S1) = sum d*vhat;  A = scale, Bc = -scale*rstd*D/N, Cc = scale*(rstd*D*mean - S1)/N
+//   frozen statistics (eval):  A = scale, Bc = Cc = 0
+__global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C,
+                                                         long npix, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                         const float *__restrict__ scale, int batch_stats, float *__restrict__ coefA,
+                                                         float *__restrict__ coefB, float *__restrict__ coefC, float *dgamma, float *dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) { s1 += p1[(long)k * C + c]; s2 += p2[(long)k * C + c]; }
+    const double m = mean[c], rs = rstd[c], sc = scale[c];
+    const double D = rs * (s2 - m * s1);
+    coefA[c] = (float)sc;
+    if (batch_stats) {
+        coefB[c] = (float)(-sc * rs * D / (double)npix);
+        coefC[c] = (float)(sc * (rs * D * m - s1) / (double)npix);
+    } else {
+        coefB[c] = 0.f;
+        coefC[c] = 0.f;
+    }
+    if (dgamma) dgamma[c] += (float)D;
+    if (dbeta) dbeta[c] += (float)s1;
+}
+// apply: order 0: dx = A*d + Bc*x + Cc with d = dz*act'(x*scale+shift)
+//        order 1: dx = (A*dz + Bc*act(x) + Cc) * act'(x)
+__global__ __launch_bounds__(256) void bn_act_bwd_apply(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
+                                                        int x_cs, int x_coff, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, const float *__restrict__ coefA,
+                                                        const float *__restrict__ coefB, const float *__restrict__ coefC, int act, int order,
+                                                        float *__restrict__ dx, int dx_cs, int dx_coff, long npix, int C) {
+    const int C4 = C >> 2;
+    const long items = npix * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long p = it / C4;
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
+        const f32x4 A = *reinterpret_cast<const f32x4 *>(coefA + c), Bc = *reinterpret_cast<const f32x4 *>(coefB + c),
+                    Cc = *reinterpret_cast<const f32x4 *>(coefC + c);
+        f32x4 r;
+        if (order == 0) {
+            const f32x4 u = v * *reinterpret_cast<const f32x4 *>(scale + c) + *reinterpret_cast<const f32x4 *>(shift + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = A[e] * (g[e] * act_grad(u[e], act)) + Bc[e] * v[e] + Cc[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (A[e] * g[e] + Bc[e] * act_fwd(v[e], act) + Cc[e]) * act_grad(v[e], act);
+        }
+        *reinterpret_cast<f32x4 *>(dx + p * dx_cs + dx_coff + c) = r;
+    }
+}
+
+// per-channel sum over pixels of a tensor (bias gradients): out[c] += sum_p x[p,c]
+__global__ __launch_bounds__(256) void chan_sum_stage1(const float *__restrict__ x, int cs, int coff, long npix, int C, float *__restrict__ p1,
+                                                       float *__restrict__ p2, int nchunk) {
+    chunk_reduce2(npix, C, p1, p2, nchunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
+        s1 += *reinterpret_cast<const f32x4 *>(x + p * cs + coff + c);
+    });
+}
+__global__ __launch_bounds__(256) void chan_sum_stage2(const float *__restrict__ p1, int nchunk, int C, float *out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += p1[(long)k * C + c];
+    out[c] += (float)s;
+}
+
+static inline int ew_grid(long items) {
+    long g = (items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+static inline bool slice_ok(const void *p, int cs, int coff, int C) { return p && cs % 4 == 0 && coff % 4 == 0 && coff + C <= cs && aligned16(p); }
+
+}  // namespace somi
+
+using namespace somi;
+
+extern "C" int somi_red_nchunk(long npix) { return (int)((npix + RED_CHUNK - 1) / RED_CHUNK); }
+
+extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float eps, float momentum,
+                                      const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                                      float *running_mean, float *running_var, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && npix > 0 && C > 0 && C % 4 == 0 && mean && rstd && scale && shift && workspace, SOMI_EINVAL,
+                 "bn stats: bad arguments");
+    SOMI_REQUIRE(!running_mean == !running_var, SOMI_EINVAL, "bn stats: running_mean and running_var go together");
+    const int nchunk = somi_red_nchunk(npix);
+    float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, p1, p2, nchunk);
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 256)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
+                       scale, shift, running_mean, running_var);
+    return launch_status("somi_bn_stats_nhwc_f32");
+}
+
+extern "C" int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act,
+                                             int order, float *z, int z_cs, int z_coff, long npix, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && slice_ok(z, z_cs, z_coff, C) && scale && shift && npix > 0 && C % 4 == 0 &&
+                     (order == 0 || order == 1) && aligned16(scale) && aligned16(shift), SOMI_EINVAL, "chan affine act: bad arguments");
+    hipLaunchKernelGGL(chan_affine_act_kernel, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, scale, shift,
+                       act, order, z, z_cs, z_coff, npix, C);
+    return launch_status("somi_chan_affine_act_nhwc_f32");
+}
+
+extern "C" int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
+                                             const float *rstd, const float *scale, const float *shift, int act, int order,
+                                             int batch_stats, float *dx, int dx_cs, int dx_coff, float *dgamma, float *dbeta, long npix,
+                                             int C, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(dz, dz_cs, dz_coff, C) && slice_ok(x, x_cs, x_coff, C) && slice_ok(dx, dx_cs, dx_coff, C) && mean && rstd && scale &&
+                     shift && workspace && npix > 0 && C % 4 == 0 && (order == 0 || order == 1), SOMI_EINVAL, "bn act backward: bad arguments");
+    const int nchunk = somi_red_nchunk(npix);
+    const size_t cpad = ((size_t)C + 3) / 4 * 4;
+    float *p1 = workspace, *p2 = p1 + (size_t)nchunk * C, *cA = p2 + (size_t)nchunk * C, *cB = cA + cpad, *cC = cB + cpad;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, act, order, npix, C,
+                       p1, p2, nchunk);
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, 256)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
+                       dgamma, dbeta);
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, cA, cB,
+                       cC, act, order, dx, dx_cs, dx_coff, npix, C);
+    return launch_status("somi_bn_act_backward_nhwc_f32");
+}
+
+extern "C" int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float *out_accumulate, float *workspace,
+                                      somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && out_accumulate && workspace && npix > 0 && C % 4 == 0, SOMI_EINVAL, "chan sum: bad arguments");
+    const int nchunk = somi_red_nchunk(npix);
+    float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
+    hipLaunchKernelGGL(chan_sum_stage1, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, npix, C, p1, p2, nchunk);
+    hipLaunchKernelGGL(chan_sum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, p1, nchunk, C, out_accumulate);
+    return launch_status("somi_chan_sum_nhwc_f32");
+}

@@ -62,6 +62,11 @@ SIGNATURES = {
     'somi_scale_channels_nhwc_f32': (I, [P, P, P, P, I, I, I, S]),
     'somi_odconv_weights_f32': (I, [P] * 18 + [I] * 7 + [S]),
     'somi_detect_decode_f32': (I, [P, I, P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
+    'somi_red_nchunk': (I, [C.c_long]),
+    'somi_bn_stats_nhwc_f32': (I, [P, I, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
+    'somi_chan_affine_act_nhwc_f32': (I, [P, I, I, P, P, I, I, P, I, I, C.c_long, I, S]),
+    'somi_bn_act_backward_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, P, I, I, P, P, C.c_long, I, P, S]),
+    'somi_chan_sum_nhwc_f32': (I, [P, I, I, C.c_long, I, P, P, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),

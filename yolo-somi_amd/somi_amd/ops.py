@@ -271,3 +271,44 @@ def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cou
     check(L.somi_conv2d_wgrad_nhwc_f32(C.byref(d), _ptr(_f32c(x)), x_cs, x_coff, _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(out)),
                                        _ptr(accumulate), _ptr(ws), nbytes, _stream()), 'conv2d_wgrad_nhwc')
     return out
+
+
+# ---------------------------------------------------------------------------------------------- training-mode helpers
+def _npix(t):
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+def bn_stats(x, c, x_coff, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """Batch statistics of a channel slice -> (mean, rstd, scale, shift); optionally updates the running statistics."""
+    dev = x.device
+    mean, rstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
+    n = _npix(x)
+    ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c, device=dev, dtype=torch.float32)
+    check(_lib.lib().somi_bn_stats_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, n, c, float(eps), float(momentum), _ptr(gamma), _ptr(beta),
+                                            _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var),
+                                            _ptr(ws), _stream()), 'bn_stats')
+    return mean, rstd, scale, shift
+
+
+def chan_affine_act(x, c, x_coff, scale, shift, act, order, out, out_coff=0):
+    check(_lib.lib().somi_chan_affine_act_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, _ptr(scale), _ptr(shift), ACT[act], order,
+                                                   _ptr(_f32c(out)), out.shape[3], out_coff, _npix(x), c, _stream()), 'chan_affine_act')
+    return out
+
+
+def bn_act_backward(dz, dz_coff, x, x_coff, c, mean, rstd, scale, shift, act, order, batch_stats, dx, dx_coff=0, dgamma=None,
+                    dbeta=None):
+    n = _npix(x)
+    ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c + 3 * ((c + 3) // 4 * 4), device=x.device, dtype=torch.float32)
+    check(_lib.lib().somi_bn_act_backward_nhwc_f32(_ptr(_f32c(dz)), dz.shape[3], dz_coff, _ptr(_f32c(x)), x.shape[3], x_coff, _ptr(mean),
+                                                   _ptr(rstd), _ptr(scale), _ptr(shift), ACT[act], order, int(batch_stats), _ptr(_f32c(dx)),
+                                                   dx.shape[3], dx_coff, _ptr(dgamma), _ptr(dbeta), n, c, _ptr(ws), _stream()),
+          'bn_act_backward')
+    return dx
+
+
+def chan_sum_(x, c, x_coff, out_accumulate):
+    n = _npix(x)
+    ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c, device=x.device, dtype=torch.float32)
+    check(_lib.lib().somi_chan_sum_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, n, c, _ptr(out_accumulate), _ptr(ws), _stream()), 'chan_sum')
+    return out_accumulate
