@@ -237,6 +237,9 @@ int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const
                                   const float *rstd, const float *scale, const float *shift, int act, int order,
                                   int batch_stats, float *dx, int dx_cs, int dx_coff, float *dgamma, float *dbeta, long npix,
                                   int C, float *workspace, somi_stream_t stream);
+/* out = a + b on channel slices (residual connections, gradient accumulation); out may alias a or b */
+int somi_add_nhwc_f32(const float *a, int a_cs, int a_coff, const float *b, int b_cs, int b_coff, float *out, int o_cs,
+                      int o_coff, long npix, int C, somi_stream_t stream);
 /* out[c] += sum over pixels of x[p,c] (bias gradients) */
 int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float *out_accumulate, float *workspace,
                            somi_stream_t stream);

@@ -66,3 +66,46 @@ def test_bn_act_forward_backward(order, act, batch_stats):
     rel_close(dx, nhwc(x.grad), what='dx')
     rel_close(dgam, bn.weight.grad, what='dgamma')
     rel_close(dbet, bn.bias.grad, what='dbeta')
+
+
+def _grads_close(mine, ref, what):
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            continue
+        assert p.grad is not None, f'{what}: {n} has no gradient'
+        rel_close(p.grad, q.grad, what=f'{what}: d{n}')
+
+
+def test_conv_block_train_forward_backward():
+    """Conv (conv -> BN batch stats -> SiLU) chain in training mode: outputs, running stats, dx and all parameter gradients."""
+    from oracle.somi_ref import blocks as OB
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd import blocks as MB
+    g = torch.Generator().manual_seed(11)
+    cfgs = [(16, 32, 3, 1), (32, 48, 3, 2), (48, 20, 1, 1)]
+    ref = nn.Sequential(*[OB.Conv(*c) for c in cfgs])
+    fill_state(ref, 4)
+    OB.initialize_weights(ref)
+    mine = nn.Sequential(*[MB.Conv(*c) for c in cfgs])
+    mine.load_state_dict(ref.state_dict())
+    for m in mine.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    mine = mine.cuda().train()
+    ref.train()
+    x = torch.randn(3, 16, 14, 10, generator=g, requires_grad=True)
+    y = ref(x)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    a = MB.Act(nhwc(x.detach()).cuda())
+    for m in mine:
+        a = m(a)
+    rel_close(a.t[..., :20], nhwc(y), what='train forward')
+    for m, r in zip(mine, ref):
+        rel_close(m.bn.running_mean, r.bn.running_mean, what='running_mean')
+        rel_close(m.bn.running_var, r.bn.running_var, what='running_var')
+    d = MB.Act(nhwc(dy).cuda())
+    for m in reversed(list(mine)):
+        d = m.backward(d)
+    rel_close(d.t, nhwc(x.grad), what='dx')
+    _grads_close(mine, ref, 'conv chain')

@@ -208,6 +208,19 @@ __global__ __launch_bounds__(256) void chan_sum_stage2(const float *__restrict__
     out[c] += (float)s;
 }
 
+// out = a + b on channel slices (residual adds / gradient accumulation); out may alias a or b
+__global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, int a_cs, int a_coff, const float *__restrict__ b, int b_cs,
+                                                  int b_coff, float *__restrict__ o, int o_cs, int o_coff, long npix, int C) {
+    const int C4 = C >> 2;
+    const long items = npix * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long p = it / C4;
+        *reinterpret_cast<f32x4 *>(o + p * o_cs + o_coff + c) =
+            *reinterpret_cast<const f32x4 *>(a + p * a_cs + a_coff + c) + *reinterpret_cast<const f32x4 *>(b + p * b_cs + b_coff + c);
+    }
+}
+
 static inline int ew_grid(long items) {
     long g = (items + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -271,4 +284,13 @@ extern "C" int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long
     hipLaunchKernelGGL(chan_sum_stage1, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, npix, C, p1, p2, nchunk);
     hipLaunchKernelGGL(chan_sum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, p1, nchunk, C, out_accumulate);
     return launch_status("somi_chan_sum_nhwc_f32");
+}
+
+extern "C" int somi_add_nhwc_f32(const float *a, int a_cs, int a_coff, const float *b, int b_cs, int b_coff, float *out, int o_cs,
+                                 int o_coff, long npix, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(a, a_cs, a_coff, C) && slice_ok(b, b_cs, b_coff, C) && slice_ok(out, o_cs, o_coff, C) && npix > 0 && C % 4 == 0,
+                 SOMI_EINVAL, "add: bad arguments");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, a_cs, a_coff, b, b_cs, b_coff, out, o_cs,
+                       o_coff, npix, C);
+    return launch_status("somi_add_nhwc_f32");
 }

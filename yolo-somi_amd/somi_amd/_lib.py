@@ -66,6 +66,7 @@ SIGNATURES = {
     'somi_bn_stats_nhwc_f32': (I, [P, I, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
     'somi_chan_affine_act_nhwc_f32': (I, [P, I, I, P, P, I, I, P, I, I, C.c_long, I, S]),
     'somi_bn_act_backward_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, P, I, I, P, P, C.c_long, I, P, S]),
+    'somi_add_nhwc_f32': (I, [P, I, I, P, I, I, P, I, I, C.c_long, I, S]),
     'somi_chan_sum_nhwc_f32': (I, [P, I, I, C.c_long, I, P, P, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),

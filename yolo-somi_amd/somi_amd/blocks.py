@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .pack import pack_conv_weight, pad4, bn_fold
+from .pack import pack_conv_weight, pack_dgrad_weight, pad4, bn_fold
 
 
 class Act:
@@ -58,6 +58,15 @@ class _Packed(nn.Module):
 
     def invalidate(self):
         self.__dict__.pop('_pk', None)
+
+
+def _acc_grad(param, g):
+    """param.grad += g (reference layout, like autograd's accumulation)."""
+    g = g.detach().to(param.dtype)
+    if param.grad is None:
+        param.grad = g.clone().contiguous()
+    else:
+        param.grad.add_(g)
 
 
 def _act_name(m):
@@ -105,11 +114,70 @@ class Conv(_Packed):
         self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
 
     def _pack(self, dev):
-        if self.training:
-            raise NotImplementedError('training-mode BatchNorm (batch statistics) is not built yet on the HIP path')
+        if self.training:                                        # raw weights, batch-norm applied from batch statistics
+            w = self.conv.weight.detach().float()
+            c2 = w.shape[0]
+            padv = lambda t, fill: torch.cat([t.detach().float().to(dev), torch.full((pad4(c2) - c2,), fill, device=dev)])   # noqa: E731
+            return dict(wp=pack_conv_weight(w, cout_pad=pad4(c2)).to(dev), wt=pack_dgrad_weight(w).to(dev),
+                        gamma=padv(self.bn.weight, 0.), beta=padv(self.bn.bias, 0.), rm=padv(self.bn.running_mean, 0.),
+                        rv=padv(self.bn.running_var, 1.))
         return _pack_wb(*_fold_conv_bn(self.conv, getattr(self, 'bn', None)), dev)
 
+    # ------------------------------------------------------------------------------------------ training mode
+    def _forward_train(self, x, out, residual):
+        """y = conv(x) (raw) -> batch statistics -> z = act(y*scale+shift) [+ residual]; keeps what backward needs."""
+        self.invalidate()                                        # parameters change every step: repack
+        pk = self._packed(x.t.device)
+        k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
+        c2, cp = self.conv.out_channels, pad4(self.conv.out_channels)
+        B, H, W, _ = x.shape
+        Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+        y = torch.empty(B, Ho, Wo, cp, device=x.t.device, dtype=torch.float32)
+        ops.conv2d_nhwc(x.t, pk['wp'], None, kh=k, kw=k, stride=s, pad=p, act='none', cin=pad4(x.c), x_coff=x.coff, out=y, cout=cp,
+                        alg_cin=x.c, alg_cout=c2)
+        mean, rstd, scale, shift = ops.bn_stats(y, cp, 0, pk['gamma'], pk['beta'], self.bn.eps, self.bn.momentum, pk['rm'], pk['rv'])
+        with torch.no_grad():                                    # running statistics back into the module buffers
+            self.bn.running_mean.copy_(pk['rm'][:c2])
+            self.bn.running_var.copy_(pk['rv'][:c2])
+            self.bn.num_batches_tracked += 1
+        if out is None:
+            out = new_act(x.t, Ho, Wo, c2)
+        elif c2 % 4:
+            raise NotImplementedError('writing into a channel slice needs c2 % 4 == 0')
+        cw = cp if out.coff == 0 and out.t.shape[3] == cp else c2
+        ops.chan_affine_act(y, cw, 0, scale, shift, _act_name(self.act), 0, out.t, out.coff)
+        if residual is not None:
+            ops.add_(out.t, out.coff, residual.t, residual.coff, c2)
+        self.__dict__['_ctx'] = (x, y, mean, rstd, scale, shift, pk)
+        return Act(out.t, out.coff, c2)
+
+    def backward(self, dz, dx_out=None, accumulate=False):
+        """dz: gradient w.r.t. this block's output (Act).  Returns the gradient w.r.t. the input as an Act (written into
+        dx_out if given, added to it if accumulate).  Parameter gradients are accumulated into .grad (reference layout)."""
+        x, y, mean, rstd, scale, shift, pk = self.__dict__.pop('_ctx')
+        k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
+        c1, c2, cp = self.conv.in_channels, self.conv.out_channels, pad4(self.conv.out_channels)
+        dev = y.device
+        dy = torch.zeros_like(y) if cp != c2 else torch.empty_like(y)
+        dgam, dbet = torch.zeros(cp, device=dev), torch.zeros(cp, device=dev)
+        cw = cp if (dz.coff == 0 and dz.t.shape[3] == cp) else c2     # whole padded tensor, or an aligned slice
+        if cw % 4:
+            raise NotImplementedError('training backward on a channel slice needs out_channels % 4 == 0')
+        ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, dgam, dbet)
+        _acc_grad(self.bn.weight, dgam[:c2])
+        _acc_grad(self.bn.bias, dbet[:c2])
+        B, H, W, _ = x.shape
+        dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp)
+        _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))
+        if dx_out is None:
+            dx_out = Act(torch.empty(B, H, W, pad4(c1), device=dev, dtype=torch.float32), 0, c1)
+        ops.conv2d_dgrad_nhwc(dy, pk['wt'], B=B, H=H, W=W, cin=pad4(c1), kh=k, kw=k, stride=s, pad=p, cout=cp, out=dx_out.t,
+                              dx_coff=dx_out.coff, accumulate=dx_out.t if accumulate else None, acc_coff=dx_out.coff)
+        return dx_out
+
     def forward(self, x, out=None, residual=None, a_chan=None, a_pix=None):
+        if self.training:
+            return self._forward_train(x, out, residual)
         wp, bp = self._packed(x.t.device)
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         c2 = self.conv.out_channels

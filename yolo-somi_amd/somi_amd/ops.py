@@ -312,3 +312,12 @@ def chan_sum_(x, c, x_coff, out_accumulate):
     ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c, device=x.device, dtype=torch.float32)
     check(_lib.lib().somi_chan_sum_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, n, c, _ptr(out_accumulate), _ptr(ws), _stream()), 'chan_sum')
     return out_accumulate
+
+
+def add_(a, a_coff, b, b_coff, c, out=None, out_coff=None):
+    """out[slice] = a[slice] + b[slice]; defaults to in place on a."""
+    out = a if out is None else out
+    out_coff = a_coff if out_coff is None else out_coff
+    check(_lib.lib().somi_add_nhwc_f32(_ptr(_f32c(a)), a.shape[3], a_coff, _ptr(_f32c(b)), b.shape[3], b_coff, _ptr(_f32c(out)),
+                                       out.shape[3], out_coff, _npix(a), c, _stream()), 'add')
+    return out
