@@ -245,6 +245,34 @@ int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int 
                            somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of the attention pieces (autograd of models/common.py:339-405, 671-691 CBAM; :8483-8490 SEAM squeeze).
+ * See yolo-somi_amd/csrc/train_blocks.hip for the derivation.  Per-image reductions use nchunk = somi_img_nchunk(H*W).
+ */
+int somi_img_nchunk(int HW);
+/* A: dlogit[p] = (sum_c dt2*t*ca) * sa*(1-sa), amaxc[p] = argmax_c(t*ca) */
+int somi_cbam_bwd_pixel_f32(const float *dt2, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
+                            const float *sa, float *dlogit, int32_t *amaxc, int B, int HW, int C, somi_stream_t stream);
+/* B: gradient of sigmoid's argument through the k x k conv: dstats (B,H,W,2); dw [k][k][2] and dbias ACCUMULATED.
+ * workspace: ceil(B*H*W/1024) * (2*k*k+1) floats */
+int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const float *w, float *dstats, float *dw_accumulate,
+                              float *dbias_accumulate, float *workspace, int B, int H, int W, int k, somi_stream_t stream);
+/* C: dt1 = dt2*sa + dstats0/C + [c==amaxc]*dstats1; dca[b,c] = sum_p dt1*t; dt2 <- dt1*ca (in place).
+ * workspace: B*nchunk*C floats */
+int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
+                           const float *sa, const float *dstats, const int32_t *amaxc, float *dca, float *workspace, int B, int HW,
+                           int C, somi_stream_t stream);
+/* D: amaxp[b,c] = first pixel index of max_p x[b,p,c]. workspace: 2*B*nchunk*C 4-byte words */
+int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int32_t *amaxp, void *workspace,
+                              somi_stream_t stream);
+/* E: backward of somi_attn_mlp_f32 (same modes); dW1/db1/dW2/db2 ACCUMULATED (db* may be NULL), davg / dmax overwritten */
+int somi_attn_mlp_bwd_f32(int mode, const float *dout, const float *out, const float *avg, const float *mx, const float *W1,
+                          const float *b1, const float *W2, float *dW1, float *db1, float *dW2, float *db2, float *davg,
+                          float *dmax, int B, int C, int mid, somi_stream_t stream);
+/* F: dt[p,c] += davg[b,c]/HW + [p==amaxp[b,c]]*dmax[b,c]  (dmax / amaxp may be NULL: average pool only) */
+int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff, const float *davg, const float *dmax, const int32_t *amaxp,
+                               int B, int HW, int C, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.
  * Selection is bit-exact with the oracle: candidates in prediction order (row-major over (box, class) for

@@ -109,3 +109,35 @@ def test_conv_block_train_forward_backward():
         d = m.backward(d)
     rel_close(d.t, nhwc(x.grad), what='dx')
     _grads_close(mine, ref, 'conv chain')
+
+
+def _run_block_train(mine, ref, x, seed, what, cin):
+    from somi_amd import blocks as MB
+    g = torch.Generator().manual_seed(seed)
+    for m in mine.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    mine = mine.cuda().train()
+    ref.train()
+    x = x.clone().requires_grad_(True)
+    y = ref(x)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    out = mine(MB.Act(nhwc(x.detach()).cuda()))
+    rel_close(out.t[..., out.coff:out.coff + out.c], nhwc(y), what=f'{what} forward')
+    dx = mine.backward(MB.Act(nhwc(dy).cuda()))
+    rel_close(dx.t[..., :cin], nhwc(x.grad), what=f'{what} dx')
+    _grads_close(mine, ref, what)
+
+
+@pytest.mark.parametrize('c1,c2,n,shortcut', [(32, 32, 2, True), (48, 32, 1, False)])
+def test_c2fcbam_train_forward_backward(c1, c2, n, shortcut):
+    from oracle.somi_ref import blocks as OB
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd import blocks as MB
+    ref = fill_state(OB.C2fCBAM(c1, c2, n, shortcut), 6)
+    OB.initialize_weights(ref)
+    mine = MB.C2fCBAM(c1, c2, n, shortcut)
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(2, c1, 12, 10, generator=torch.Generator().manual_seed(c1))
+    _run_block_train(mine, ref, x, 21, 'C2fCBAM', c1)

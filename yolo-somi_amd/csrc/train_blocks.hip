@@ -1,0 +1,379 @@
+// Backward kernels of the attention pieces of the SOMI blocks (CBAM: models/common.py:339-405, 671-691; SEAM squeeze:
+// :8483-8490; global pools).  All are bandwidth-bound passes over activation-sized tensors or tiny per-sample MLPs.
+//
+// CBAM forward (per bottleneck):  ca = sigmoid(MLP(avg_hw t) + MLP(max_hw t));  t1 = t*ca;  stats = [mean_c t1, max_c t1];
+//                                 sa = sigmoid(conv7x7(stats) + b);  t2 = t1*sa.
+// Backward, given d t2:
+//   A  per pixel:   dlogit = (sum_c dt2*t*ca) * sa*(1-sa);  amaxc = argmax_c (t*ca)
+//   B  7x7 conv:    dstats = conv7x7^T(dlogit);  dW7 += sum_p dlogit * stats(shifted);  db7 += sum_p dlogit
+//   C  per element: dt1 = dt2*sa + dstats[.,0]/C + [c==amaxc]*dstats[.,1];  dca[b,c] = sum_p dt1*t;  dt = dt1*ca
+//   D  per (b,c):   amaxp = argmax_p t            (the max-pool's winner)
+//   E  per sample:  MLP backward -> dW1,db1,dW2,db2 (accumulated), d avg, d max
+//   F  per element: dt += davg/HW + [p==amaxp]*dmax
+#include "common.h"
+
+namespace somi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int IMG_CHUNK = 256;       // pixels per workgroup in the per-image reductions
+
+static inline int ew_grid(long items) {
+    long g = (items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+// ------------------------------------------------------------------------------------------------ A
+__global__ __launch_bounds__(256) void cbam_bwd_pixel_kernel(const float *__restrict__ dt2, int d_cs, int d_coff, const float *__restrict__ t,
+                                                             int t_cs, int t_coff, const float *__restrict__ ca, const float *__restrict__ sa,
+                                                             float *__restrict__ dlogit, int *__restrict__ amaxc, int B, int HW, int C) {
+    const int lane = threadIdx.x & 63;
+    const long wave_id = (blockIdx.x * 256L + threadIdx.x) >> 6, nwave = (long)gridDim.x * 4;
+    const long npix = (long)B * HW;
+    for (long p = wave_id; p < npix; p += nwave) {
+        const long b = p / HW;
+        const float *tr = t + p * t_cs + t_coff, *dr = dt2 + p * d_cs + d_coff, *cr = ca + b * C;
+        float s = 0.f, m = -__builtin_huge_valf();
+        int mi = 0x7fffffff;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + c) * *reinterpret_cast<const f32x4 *>(cr + c);
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(dr + c);
+            s += (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] > m) { m = v[e]; mi = c + e; }                  // first maximum inside the lane (ascending c)
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            const float om = __shfl_xor(m, o);
+            const int oi = __shfl_xor(mi, o);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }   // lowest index on ties (torch.max)
+        }
+        if (lane == 0) {
+            const float a = sa[p];
+            dlogit[p] = s * a * (1.f - a);
+            amaxc[p] = mi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B
+__global__ __launch_bounds__(256) void spatial_attn_bwd_data_kernel(const float *__restrict__ dlogit, const float *__restrict__ w,
+                                                                    float *__restrict__ dstats, int B, int H, int W, int k) {
+    const long npix = (long)B * H * W;
+    const int pad = k >> 1;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const int wv = (int)(p % W), hv = (int)((p / W) % H);
+        const long b = p / ((long)W * H);
+        float a0 = 0.f, a1 = 0.f;
+        for (int r = 0; r < k; ++r) {
+            const int ho = hv - (r - pad);                              // logit[ho,wo] used stats[ho + r - pad, wo + q - pad]
+            if ((unsigned)ho >= (unsigned)H) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wo = wv - (q - pad);
+                if ((unsigned)wo >= (unsigned)W) continue;
+                const float g = dlogit[(b * H + ho) * W + wo];
+                a0 += g * w[(r * k + q) * 2];
+                a1 += g * w[(r * k + q) * 2 + 1];
+            }
+        }
+        *reinterpret_cast<float2 *>(dstats + p * 2) = make_float2(a0, a1);
+    }
+}
+// weight / bias gradient: thread j < k*k*2 owns one weight and walks the workgroup's pixel chunk; thread k*k*2 owns the bias
+__global__ __launch_bounds__(128) void spatial_attn_bwd_weight_kernel(const float *__restrict__ dlogit, const float *__restrict__ stats,
+                                                                      float *__restrict__ part, int B, int H, int W, int k, int chunk) {
+    const long npix = (long)B * H * W;
+    const int nw = k * k * 2, pad = k >> 1;
+    const int j = threadIdx.x;
+    if (j > nw) return;
+    const long p0 = (long)blockIdx.x * chunk, p1 = min(p0 + chunk, npix);
+    float acc = 0.f;
+    if (j == nw) {
+        for (long p = p0; p < p1; ++p) acc += dlogit[p];
+    } else {
+        const int ch = j & 1, rq = j >> 1, r = rq / k, q = rq % k;
+        for (long p = p0; p < p1; ++p) {
+            const int wv = (int)(p % W), hv = (int)((p / W) % H);
+            const int hi = hv + r - pad, wi = wv + q - pad;
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                acc += dlogit[p] * stats[(p + (long)(r - pad) * W + (q - pad)) * 2 + ch];
+        }
+    }
+    part[(long)blockIdx.x * (nw + 1) + j] = acc;
+}
+__global__ __launch_bounds__(128) void spatial_attn_bwd_weight_final(const float *__restrict__ part, int nblk, int nw, float *dw, float *dbias) {
+    const int j = threadIdx.x;
+    if (j > nw) return;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += part[(long)i * (nw + 1) + j];
+    if (j == nw) *dbias += (float)s;
+    else dw[j] += (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ C
+// grid (nchunk, B): lanes over channel quads, rows over the chunk's pixels; writes dt in place of dt2 and the partial dca sums
+__global__ __launch_bounds__(256) void cbam_bwd_chan_kernel(float *__restrict__ dt2, int d_cs, int d_coff, const float *__restrict__ t, int t_cs,
+                                                            int t_coff, const float *__restrict__ ca, const float *__restrict__ sa,
+                                                            const float *__restrict__ dstats, const int *__restrict__ amaxc,
+                                                            float *__restrict__ part, int HW, int C, int nchunk) {
+    __shared__ f32x4 l1[256];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int C4 = C >> 2;
+    const int p0 = chunk * IMG_CHUNK, p1 = min(p0 + IMG_CHUNK, HW);
+    const float inv_c = 1.f / (float)C;
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        const int c = (cq0 + cq) * 4;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        if (rr < rows_par) {
+            const f32x4 cav = *reinterpret_cast<const f32x4 *>(ca + (long)b * C + c);
+            for (int pl = p0 + rr; pl < p1; pl += rows_par) {
+                const long p = (long)b * HW + pl;
+                const f32x4 tv = *reinterpret_cast<const f32x4 *>(t + p * t_cs + t_coff + c);
+                f32x4 g = *reinterpret_cast<const f32x4 *>(dt2 + p * d_cs + d_coff + c);
+                const float2 ds = *reinterpret_cast<const float2 *>(dstats + p * 2);
+                const int am = amaxc[p];
+                g = g * sa[p] + ds.x * inv_c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e == am) g[e] += ds.y;
+                s1 += g * tv;                                            // d ca
+                *reinterpret_cast<f32x4 *>(dt2 + p * d_cs + d_coff + c) = g * cav;
+            }
+        }
+        l1[threadIdx.x] = s1;
+        __syncthreads();
+        if (threadIdx.x < ncq) {
+            for (int r2 = 1; r2 < rows_par; ++r2) s1 += l1[r2 * ncq + cq];
+            *reinterpret_cast<f32x4 *>(part + ((long)b * nchunk + chunk) * C + c) = s1;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void img_partial_sum_kernel(const float *__restrict__ part, int nchunk, int C, int B, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += part[((long)b * nchunk + k) * C + c];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ D
+__global__ __launch_bounds__(256) void pool_argmax_stage1(const float *__restrict__ x, int x_cs, int x_coff, int HW, int C,
+                                                          float *__restrict__ pmax, int *__restrict__ pidx, int nchunk) {
+    __shared__ float lm[256][4];
+    __shared__ int li[256][4];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int C4 = C >> 2;
+    const int p0 = chunk * IMG_CHUNK, p1 = min(p0 + IMG_CHUNK, HW);
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        const int c = (cq0 + cq) * 4;
+        float m[4];
+        int mi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { m[e] = -__builtin_huge_valf(); mi[e] = 0x7fffffff; }
+        if (rr < rows_par)
+            for (int pl = p0 + rr; pl < p1; pl += rows_par) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)b * HW + pl) * x_cs + x_coff + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > m[e]) { m[e] = v[e]; mi[e] = pl; }
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lm[threadIdx.x][e] = m[e]; li[threadIdx.x][e] = mi[e]; }
+        __syncthreads();
+        if (threadIdx.x < ncq) {
+            for (int r2 = 1; r2 < rows_par; ++r2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float om = lm[r2 * ncq + cq][e];
+                    const int oi = li[r2 * ncq + cq][e];
+                    if (om > m[e] || (om == m[e] && oi < mi[e])) { m[e] = om; mi[e] = oi; }
+                }
+            const long o = ((long)b * nchunk + chunk) * C + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pmax[o + e] = m[e]; pidx[o + e] = mi[e]; }
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void pool_argmax_stage2(const float *__restrict__ pmax, const int *__restrict__ pidx, int nchunk, int C, int B,
+                                                          int *__restrict__ amaxp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float m = -__builtin_huge_valf();
+    int mi = 0x7fffffff;
+    for (int k = 0; k < nchunk; ++k) {                                   // chunks ascend in pixel order: strict > keeps the first maximum
+        const float om = pmax[((long)b * nchunk + k) * C + c];
+        if (om > m) { m = om; mi = pidx[((long)b * nchunk + k) * C + c]; }
+    }
+    amaxp[i] = mi;
+}
+
+// ------------------------------------------------------------------------------------------------ E
+// one workgroup per sample.  mode 0 (CBAM): out = sigmoid(o_avg + o_max), o_x = W2 relu(W1 x + b1) + b2
+//                            mode 1 (SEAM): out = exp(sigmoid(W2 relu(W1 avg)))               (no biases)
+// dout = gradient w.r.t. `out`.  Weight gradients are accumulated with float atomics across samples.
+__global__ __launch_bounds__(256) void attn_mlp_bwd_kernel(int mode, const float *__restrict__ dout, const float *__restrict__ out,
+                                                           const float *__restrict__ avg, const float *__restrict__ mx,
+                                                           const float *__restrict__ W1, const float *__restrict__ b1,
+                                                           const float *__restrict__ W2, float *dW1, float *db1, float *dW2, float *db2,
+                                                           float *__restrict__ davg, float *__restrict__ dmax, int C, int mid) {
+    __shared__ float h_avg[64], h_max[64], dh_avg[64], dh_max[64];
+    __shared__ float dov[1024];                                          // d(pre-activation of the second layer), C <= 1024
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *va = avg + (long)b * C, *vm = mx ? mx + (long)b * C : nullptr;
+    for (int j = wave; j < mid; j += 4) {
+        float sa = 0.f, sm = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float w = W1[(long)j * C + c];
+            sa += w * va[c];
+            if (vm) sm += w * vm[c];
+        }
+        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_down(sa, o); sm += __shfl_down(sm, o); }
+        if (lane == 0) {
+            const float bb = b1 ? b1[j] : 0.f;
+            h_avg[j] = sa + bb;                                          // pre-ReLU
+            h_max[j] = sm + bb;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float o = out[(long)b * C + c], g = dout[(long)b * C + c];
+        float d;
+        if (mode == 0) d = g * o * (1.f - o);                            // sigmoid'
+        else { const float sg = logf(o); d = g * o * sg * (1.f - sg); }  // out = exp(s), s = sigmoid(.): d/dpre = out * s(1-s)
+        dov[c] = d;
+        if (db2) atomicAdd(db2 + c, mode == 0 ? 2.f * d : d);
+        for (int j = 0; j < mid; ++j) {
+            const float ra = fmaxf(h_avg[j], 0.f) + (mode == 0 ? fmaxf(h_max[j], 0.f) : 0.f);
+            atomicAdd(dW2 + (long)c * mid + j, d * ra);
+        }
+    }
+    __syncthreads();
+    for (int j = wave; j < mid; j += 4) {                                // dh = W2^T dov, gated by the ReLU
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += W2[(long)c * mid + j] * dov[c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) {
+            dh_avg[j] = h_avg[j] > 0.f ? s : 0.f;
+            dh_max[j] = (mode == 0 && h_max[j] > 0.f) ? s : 0.f;
+            if (db1) atomicAdd(db1 + j, dh_avg[j] + dh_max[j]);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float da = 0.f, dm = 0.f;
+        for (int j = 0; j < mid; ++j) {
+            const float w = W1[(long)j * C + c];
+            da += w * dh_avg[j];
+            dm += w * dh_max[j];
+            atomicAdd(dW1 + (long)j * C + c, dh_avg[j] * va[c] + (vm ? dh_max[j] * vm[c] : 0.f));
+        }
+        davg[(long)b * C + c] = da;
+        if (dmax) dmax[(long)b * C + c] = dm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ F
+__global__ __launch_bounds__(256) void pool_bwd_add_kernel(float *__restrict__ dt, int d_cs, int d_coff, const float *__restrict__ davg,
+                                                           const float *__restrict__ dmax, const int *__restrict__ amaxp, int B, int HW, int C) {
+    const int C4 = C >> 2;
+    const long items = (long)B * HW * C4;
+    const float inv = 1.f / (float)HW;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long p = it / C4, b = p / HW;
+        const int pl = (int)(p % HW);
+        f32x4 g = *reinterpret_cast<const f32x4 *>(dt + p * d_cs + d_coff + c);
+        g += *reinterpret_cast<const f32x4 *>(davg + b * C + c) * inv;
+        if (dmax) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (amaxp[b * C + c + e] == pl) g[e] += dmax[b * C + c + e];
+        }
+        *reinterpret_cast<f32x4 *>(dt + p * d_cs + d_coff + c) = g;
+    }
+}
+
+static inline bool sl_ok(const void *p, int cs, int coff, int C) { return p && cs % 4 == 0 && coff % 4 == 0 && coff + C <= cs && aligned16(p); }
+
+}  // namespace somi
+
+using namespace somi;
+
+extern "C" int somi_img_nchunk(int HW) { return (HW + IMG_CHUNK - 1) / IMG_CHUNK; }
+
+extern "C" int somi_cbam_bwd_pixel_f32(const float *dt2, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
+                                       const float *sa, float *dlogit, int32_t *amaxc, int B, int HW, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(sl_ok(dt2, d_cs, d_coff, C) && sl_ok(t, t_cs, t_coff, C) && ca && sa && dlogit && amaxc && B > 0 && HW > 0 && C % 4 == 0 &&
+                     aligned16(ca), SOMI_EINVAL, "cbam bwd pixel: bad arguments");
+    hipLaunchKernelGGL(cbam_bwd_pixel_kernel, dim3(ew_grid((long)B * HW * 64)), dim3(256), 0, (hipStream_t)stream, dt2, d_cs, d_coff, t, t_cs,
+                       t_coff, ca, sa, dlogit, amaxc, B, HW, C);
+    return launch_status("somi_cbam_bwd_pixel_f32");
+}
+
+extern "C" int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const float *w, float *dstats, float *dw_accumulate,
+                                         float *dbias_accumulate, float *workspace, int B, int H, int W, int k, somi_stream_t stream) {
+    SOMI_REQUIRE(dlogit && stats && w && dstats && dw_accumulate && dbias_accumulate && workspace && B > 0 && H > 0 && W > 0 &&
+                     (k == 3 || k == 5 || k == 7), SOMI_EINVAL, "spatial attn bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(spatial_attn_bwd_data_kernel, dim3(ew_grid(npix)), dim3(256), 0, s, dlogit, w, dstats, B, H, W, k);
+    const int chunk = 1024, nblk = (int)((npix + chunk - 1) / chunk), nw = k * k * 2;
+    hipLaunchKernelGGL(spatial_attn_bwd_weight_kernel, dim3(nblk), dim3(128), 0, s, dlogit, stats, workspace, B, H, W, k, chunk);
+    hipLaunchKernelGGL(spatial_attn_bwd_weight_final, dim3(1), dim3(128), 0, s, workspace, nblk, nw, dw_accumulate, dbias_accumulate);
+    return launch_status("somi_spatial_attn_bwd_f32");
+}
+
+extern "C" int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
+                                      const float *sa, const float *dstats, const int32_t *amaxc, float *dca, float *workspace, int B, int HW,
+                                      int C, somi_stream_t stream) {
+    SOMI_REQUIRE(sl_ok(dt2_inout, d_cs, d_coff, C) && sl_ok(t, t_cs, t_coff, C) && ca && sa && dstats && amaxc && dca && workspace && B > 0 &&
+                     HW > 0 && C % 4 == 0 && aligned16(ca) && aligned16(workspace), SOMI_EINVAL, "cbam bwd chan: bad arguments");
+    const int nchunk = somi_img_nchunk(HW);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbam_bwd_chan_kernel, dim3(nchunk, B), dim3(256), 0, s, dt2_inout, d_cs, d_coff, t, t_cs, t_coff, ca, sa, dstats, amaxc,
+                       workspace, HW, C, nchunk);
+    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, workspace, nchunk, C, B, dca);
+    return launch_status("somi_cbam_bwd_chan_f32");
+}
+
+extern "C" int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int32_t *amaxp, void *workspace,
+                                         somi_stream_t stream) {
+    SOMI_REQUIRE(sl_ok(x, x_cs, x_coff, C) && amaxp && workspace && B > 0 && HW > 0 && C % 4 == 0, SOMI_EINVAL, "pool argmax: bad arguments");
+    const int nchunk = somi_img_nchunk(HW);
+    float *pm = static_cast<float *>(workspace);
+    int *pi = reinterpret_cast<int *>(pm + (size_t)B * nchunk * C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pool_argmax_stage1, dim3(nchunk, B), dim3(256), 0, s, x, x_cs, x_coff, HW, C, pm, pi, nchunk);
+    hipLaunchKernelGGL(pool_argmax_stage2, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, pm, pi, nchunk, C, B, amaxp);
+    return launch_status("somi_pool_argmax_nhwc_f32");
+}
+
+extern "C" int somi_attn_mlp_bwd_f32(int mode, const float *dout, const float *out, const float *avg, const float *mx, const float *W1,
+                                     const float *b1, const float *W2, float *dW1, float *db1, float *dW2, float *db2, float *davg,
+                                     float *dmax, int B, int C, int mid, somi_stream_t stream) {
+    SOMI_REQUIRE(dout && out && avg && W1 && W2 && dW1 && dW2 && davg && B > 0 && C > 0 && C <= 1024 && mid > 0 && mid <= 64, SOMI_EINVAL,
+                 "attn mlp bwd: bad arguments (C <= 1024, mid <= 64)");
+    SOMI_REQUIRE((mode == 0 && mx && dmax) || mode == 1, SOMI_EINVAL, "attn mlp bwd: mode 0 needs max inputs/outputs");
+    hipLaunchKernelGGL(attn_mlp_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mode, dout, out, avg, mode == 0 ? mx : nullptr, W1, b1, W2,
+                       dW1, db1, dW2, db2, davg, mode == 0 ? dmax : nullptr, C, mid);
+    return launch_status("somi_attn_mlp_bwd_f32");
+}
+
+extern "C" int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff, const float *davg, const float *dmax, const int32_t *amaxp,
+                                          int B, int HW, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(sl_ok(dt_inout, d_cs, d_coff, C) && davg && (!dmax || amaxp) && B > 0 && HW > 0 && C % 4 == 0 && aligned16(davg), SOMI_EINVAL,
+                 "pool bwd add: bad arguments");
+    hipLaunchKernelGGL(pool_bwd_add_kernel, dim3(ew_grid((long)B * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, dt_inout, d_cs, d_coff, davg,
+                       dmax, amaxp, B, HW, C);
+    return launch_status("somi_pool_bwd_add_nhwc_f32");
+}

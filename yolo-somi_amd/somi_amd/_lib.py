@@ -68,6 +68,13 @@ SIGNATURES = {
     'somi_bn_act_backward_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, P, I, I, P, P, C.c_long, I, P, S]),
     'somi_add_nhwc_f32': (I, [P, I, I, P, I, I, P, I, I, C.c_long, I, S]),
     'somi_chan_sum_nhwc_f32': (I, [P, I, I, C.c_long, I, P, P, S]),
+    'somi_img_nchunk': (I, [I]),
+    'somi_cbam_bwd_pixel_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, S]),
+    'somi_spatial_attn_bwd_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, S]),
+    'somi_cbam_bwd_chan_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, I, I, I, S]),
+    'somi_pool_argmax_nhwc_f32': (I, [P, I, I, I, I, I, P, P, S]),
+    'somi_attn_mlp_bwd_f32': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    'somi_pool_bwd_add_nhwc_f32': (I, [P, I, I, P, P, P, I, I, I, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),

@@ -231,9 +231,25 @@ class ChannelAttentionModule(_Packed):
         return tuple(t.detach().float().contiguous().to(dev) for t in (l1.weight, l1.bias, l2.weight, l2.bias))
 
     def forward(self, x):
+        if self.training:
+            self.invalidate()
         W1, b1, W2, b2 = self._packed(x.t.device)
         avg, mx = ops.global_pool(x.t, c=x.c, x_coff=x.coff)
-        return ops.attn_mlp(0, avg, mx, W1, b1, W2, b2)
+        ca = ops.attn_mlp(0, avg, mx, W1, b1, W2, b2)
+        if self.training:
+            self.__dict__['_ctx'] = (x, avg, mx, ca, (W1, b1, W2, b2))
+        return ca
+
+    def backward(self, dca, dt):
+        """dca (B,C): gradient w.r.t. the attention vector; adds the pooled-input gradient into dt (Act) in place."""
+        x, avg, mx, ca, (W1, b1, W2, b2) = self.__dict__.pop('_ctx')
+        g = [torch.zeros_like(t) for t in (W1, b1, W2, b2)]
+        davg, dmax = ops.attn_mlp_backward(0, dca, ca, avg, mx, W1, b1, W2, g[0], g[1], g[2], g[3])
+        l1, l2 = self.shared_MLP[0], self.shared_MLP[2]
+        for prm, gr in zip((l1.weight, l1.bias, l2.weight, l2.bias), g):
+            _acc_grad(prm, gr)
+        amaxp = ops.pool_argmax(x.t, x.c, x.coff)
+        ops.pool_backward_add_(dt.t, dt.coff, x.c, davg, dmax, amaxp)
 
 
 class SpatialAttentionModule(_Packed):
@@ -249,11 +265,33 @@ class SpatialAttentionModule(_Packed):
         return w, float(self.cv1.bias.detach()[0])
 
     def forward(self, x, ca):
-        """Applies both attentions to x in place: x <- x * ca * sa (one stats pass + one apply pass)."""
+        """Applies both attentions: x <- x * ca * sa.  Eval: in place (one stats pass + one apply pass).  Train: x is kept
+        (backward needs it) and the product goes to a new tensor."""
+        if self.training:
+            self.invalidate()
         w, b = self._packed(x.t.device)
         stats = ops.chan_stats(x.t, ca, c=x.c, x_coff=x.coff)
-        ops.cbam_apply_(x.t, ca, stats, w, b, self.cv1.kernel_size[0], c=x.c, x_coff=x.coff)
-        return x
+        k = self.cv1.kernel_size[0]
+        if not self.training:
+            ops.cbam_apply_(x.t, ca, stats, w, b, k, c=x.c, x_coff=x.coff)
+            return x
+        if x.coff != 0 or x.t.shape[3] != x.c:
+            raise NotImplementedError('CBAM training path works on whole tensors')
+        sa = ops.spatial_attn(stats, w, b, k)
+        out = ops.scale_channels(x.t, ca, sa)
+        self.__dict__['_ctx'] = (x, ca, stats, sa, w)
+        return Act(out, 0, x.c)
+
+    def backward(self, dt2):
+        """dt2: gradient tensor w.r.t. x*ca*sa (whole tensor, modified in place into the x-gradient through both products and
+        the spatial branch).  Returns dca (B,C)."""
+        x, ca, stats, sa, w = self.__dict__.pop('_ctx')
+        k = self.cv1.kernel_size[0]
+        dw, db = torch.zeros_like(w), torch.zeros(1, device=w.device)
+        dca = ops.cbam_backward(dt2, x.t, x.coff, x.c, ca, sa, stats, w, k, dw, db)
+        _acc_grad(self.cv1.weight, dw.permute(2, 0, 1).unsqueeze(0))          # [k][k][2] -> (1,2,k,k)
+        _acc_grad(self.cv1.bias, db)
+        return dca
 
 
 class CBAMBottleneck(nn.Module):
@@ -273,8 +311,22 @@ class CBAMBottleneck(nn.Module):
     def forward(self, x, out=None):
         t = self.cv1(x)
         ca = self.channel_attention(t)
-        t = self.spatial_attention(t, ca)
-        return self.cv2(t, out=out, residual=x if self.add else None)
+        t2 = self.spatial_attention(t, ca)
+        if self.training:
+            self.__dict__['_ctx'] = (x, t)
+        return self.cv2(t2, out=out, residual=x if self.add else None)
+
+    def backward(self, dout, dx_out):
+        """dout: gradient w.r.t. the block output (Act); the input gradient is ADDED into dx_out (Act, e.g. a slice of the
+        C2f gradient buffer that already holds the gradient of the input's other consumers)."""
+        x, t = self.__dict__.pop('_ctx')
+        d = self.cv2.backward(dout)                               # d(t*ca*sa)
+        dca = self.spatial_attention.backward(d.t)                # d.t now holds the direct part of dt
+        self.channel_attention.backward(dca, d)                   # + pooled paths
+        self.cv1.backward(d, dx_out=dx_out, accumulate=True)
+        if self.add:
+            ops.add_(dx_out.t, dx_out.coff, dout.t, dout.coff, x.c)
+        return dx_out
 
 
 class C2fCBAM(nn.Module):
@@ -299,6 +351,13 @@ class C2fCBAM(nn.Module):
         for i, blk in enumerate(self.m):
             blk(cat.slice((1 + i) * c, c), out=cat.slice((2 + i) * c, c))
         return self.cv2(cat)
+
+    def backward(self, dout, dx_out=None, accumulate=False):
+        c, n = self.c, len(self.m)
+        dcat = self.cv2.backward(dout)                            # gradient of every piece through the 1x1 mix
+        for i in reversed(range(n)):
+            self.m[i].backward(dcat.slice((2 + i) * c, c), dcat.slice((1 + i) * c, c))
+        return self.cv1.backward(dcat.slice(0, 2 * c), dx_out=dx_out, accumulate=accumulate)
 
 
 class SPPF(nn.Module):

@@ -321,3 +321,50 @@ def add_(a, a_coff, b, b_coff, c, out=None, out_coff=None):
     check(_lib.lib().somi_add_nhwc_f32(_ptr(_f32c(a)), a.shape[3], a_coff, _ptr(_f32c(b)), b.shape[3], b_coff, _ptr(_f32c(out)),
                                        out.shape[3], out_coff, _npix(a), c, _stream()), 'add')
     return out
+
+
+def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7):
+    """Steps A-C of train_blocks.hip: turns d(t*ca*sa) (dt2, whole tensor, modified in place) into the part of dt that flows
+    through the two multiplications and the spatial branch; returns dca (B,C).  dw7 / db7 are accumulated."""
+    B, H, W, _ = t.shape
+    dev = t.device
+    L = _lib.lib()
+    dlogit = torch.empty(B, H, W, device=dev, dtype=torch.float32)
+    amaxc = torch.empty(B, H, W, device=dev, dtype=torch.int32)
+    check(L.somi_cbam_bwd_pixel_f32(_ptr(_f32c(dt2)), dt2.shape[3], 0, _ptr(_f32c(t)), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dlogit),
+                                    _ptr(amaxc), B, H * W, c, _stream()), 'cbam_bwd_pixel')
+    dstats = torch.empty(B, H, W, 2, device=dev, dtype=torch.float32)
+    ws = torch.empty(((B * H * W + 1023) // 1024) * (2 * k * k + 1), device=dev, dtype=torch.float32)
+    check(L.somi_spatial_attn_bwd_f32(_ptr(dlogit), _ptr(stats), _ptr(w7), _ptr(dstats), _ptr(dw7), _ptr(db7), _ptr(ws), B, H, W, k,
+                                      _stream()), 'spatial_attn_bwd')
+    dca = torch.empty(B, c, device=dev, dtype=torch.float32)
+    ws2 = torch.empty(B * L.somi_img_nchunk(H * W) * c, device=dev, dtype=torch.float32)
+    check(L.somi_cbam_bwd_chan_f32(_ptr(dt2), dt2.shape[3], 0, _ptr(t), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dstats), _ptr(amaxc),
+                                   _ptr(dca), _ptr(ws2), B, H * W, c, _stream()), 'cbam_bwd_chan')
+    return dca
+
+
+def pool_argmax(x, c, x_coff=0):
+    B, H, W, cs = x.shape
+    L = _lib.lib()
+    out = torch.empty(B, c, device=x.device, dtype=torch.int32)
+    ws = torch.empty(2 * B * L.somi_img_nchunk(H * W) * c, device=x.device, dtype=torch.float32)
+    check(L.somi_pool_argmax_nhwc_f32(_ptr(_f32c(x)), cs, x_coff, B, H * W, c, _ptr(out), _ptr(ws), _stream()), 'pool_argmax')
+    return out
+
+
+def attn_mlp_backward(mode, dout, out, avg, mx, W1, b1, W2, dW1, db1, dW2, db2):
+    B, Cc = avg.shape
+    davg = torch.empty_like(avg)
+    dmax = torch.empty_like(avg) if mode == 0 else None
+    check(_lib.lib().somi_attn_mlp_bwd_f32(mode, _ptr(dout), _ptr(out), _ptr(avg), _ptr(mx), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(dW1),
+                                           _ptr(db1), _ptr(dW2), _ptr(db2), _ptr(davg), _ptr(dmax), B, Cc, W1.shape[0], _stream()),
+          'attn_mlp_bwd')
+    return davg, dmax
+
+
+def pool_backward_add_(dt, d_coff, c, davg, dmax=None, amaxp=None):
+    B, H, W, cs = dt.shape
+    check(_lib.lib().somi_pool_bwd_add_nhwc_f32(_ptr(_f32c(dt)), cs, d_coff, _ptr(davg), _ptr(dmax), _ptr(amaxp), B, H * W, c, _stream()),
+          'pool_bwd_add')
+    return dt
