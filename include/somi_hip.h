@@ -272,6 +272,25 @@ int somi_attn_mlp_bwd_f32(int mode, const float *dout, const float *out, const f
 int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff, const float *davg, const float *dmax, const int32_t *amaxp,
                                int B, int HW, int C, somi_stream_t stream);
 
+/* Backward of the remaining layer kernels (train_blocks.hip).
+ * detect: d raw (B,na,ny,nx,no) -> d box (B,ny,nx,box_cs), d cls (B,ny,nx,cls_cs) (inverse of the interleave; pads zeroed).
+ * sppf:   dbuf slices 1..3 (the 5/9/13 pools) are routed to the arg-max positions and ADDED into slice 0 of dbuf.
+ * bifpn:  dsrc_i = wn_i*dout (2x2 sum for an upsampled source, dsrc_i low-res); dw ACCUMULATED incl. the normalisation's chain
+ *         rule.  workspace: 3*2048 floats.
+ * dwconv: dx (+dx_accumulate), dw [3][3][C] and dbias ACCUMULATED.  workspace: ceil(B*H*W/512)*10*C floats.
+ * scale:  y = x*s[b][c]: dx = dout*s, ds[b,c] = sum_p dout*x.  workspace: B*nchunk*C floats. */
+int somi_detect_raw_bwd_f32(const float *draw, float *dbox, int box_cs, float *dcls, int cls_cs, int B, int ny, int nx, int na,
+                            int nc, somi_stream_t stream);
+int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream);
+int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *wn_host,
+                            const float *w_dev, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
+                            int W, int C, somi_stream_t stream);
+int somi_dwconv3x3_bwd_nhwc_f32(const float *dy, const float *x, const float *w, float *dx, const float *dx_accumulate,
+                                float *dw_accumulate, float *dbias_accumulate, float *workspace, int B, int H, int W, int C,
+                                somi_stream_t stream);
+int somi_scale_channels_bwd_nhwc_f32(const float *dout, const float *x, const float *s, float *dx, float *ds, float *workspace, int B,
+                                     int HW, int C, somi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.

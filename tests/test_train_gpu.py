@@ -141,3 +141,71 @@ def test_c2fcbam_train_forward_backward(c1, c2, n, shortcut):
     mine.load_state_dict(ref.state_dict())
     x = torch.randn(2, c1, 12, 10, generator=torch.Generator().manual_seed(c1))
     _run_block_train(mine, ref, x, 21, 'C2fCBAM', c1)
+
+
+def test_sppf_seam_train_forward_backward():
+    from oracle.somi_ref import blocks as OB
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd import blocks as MB
+    for name, ctor_o, ctor_m, cin in (('SPPF', lambda: OB.SPPF(32, 32, 5), lambda: MB.SPPF(32, 32, 5), 32),
+                                      ('SEAM', lambda: OB.SEAM(32, 32, 1, 16), lambda: MB.SEAM(32, 32, 1, 16), 32)):
+        ref = fill_state(ctor_o(), 8)
+        OB.initialize_weights(ref)
+        mine = ctor_m()
+        mine.load_state_dict(ref.state_dict())
+        x = torch.randn(2, cin, 11, 9, generator=torch.Generator().manual_seed(3))
+        _run_block_train(mine, ref, x, 31, name, cin)
+
+
+def test_bifpn_train_backward():
+    from oracle.somi_ref import blocks as OB
+    from somi_amd import blocks as MB
+    g = torch.Generator().manual_seed(17)
+    ref = OB.BiFPN(3)
+    with torch.no_grad():
+        ref.weight.copy_(torch.tensor([0.7, 1.3, 0.4]))
+    mine = MB.BiFPN(3)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda().train()
+    lo = torch.randn(2, 16, 5, 6, generator=g, requires_grad=True)
+    a = torch.randn(2, 16, 10, 12, generator=g, requires_grad=True)
+    b = torch.randn(2, 16, 10, 12, generator=g, requires_grad=True)
+    y = ref([F.interpolate(lo, scale_factor=2, mode='nearest'), a, b])
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    up = MB.Upsample(None, 2, 'nearest')
+    out = mine([up(MB.Act(nhwc(lo.detach()).cuda())), MB.Act(nhwc(a.detach()).cuda()), MB.Act(nhwc(b.detach()).cuda())])
+    rel_close(out.t, nhwc(y), what='bifpn forward')
+    ds = mine.backward(MB.Act(nhwc(dy).cuda()))
+    for d, r, nm in zip(ds, (lo, a, b), ('up', 'a', 'b')):
+        rel_close(d.t, nhwc(r.grad), what=f'bifpn d{nm}')
+    rel_close(mine.weight.grad, ref.weight.grad, what='bifpn dweight')
+
+
+def test_decoupled_detect_train_backward():
+    from oracle.somi_ref import blocks as OB
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd import blocks as MB
+    g = torch.Generator().manual_seed(23)
+    anchors = [list(range(8))] * 2
+    ref = fill_state(OB.DecoupledDetect(10, anchors, (64, 96)), 9)
+    OB.initialize_weights(ref)
+    mine = MB.DecoupledDetect(10, anchors, (64, 96))
+    mine.load_state_dict(ref.state_dict())
+    for m in mine.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    mine = mine.cuda().train()
+    ref.train()
+    ref.stride = mine.stride = torch.tensor([8., 16.])
+    xs = [torch.randn(2, 64, 8, 8, generator=g, requires_grad=True), torch.randn(2, 96, 4, 4, generator=g, requires_grad=True)]
+    ys = ref(list(xs))
+    dys = [torch.randn(y.shape, generator=g) for y in ys]
+    torch.autograd.backward(ys, dys)
+    outs = mine([MB.Act(nhwc(x.detach()).cuda()) for x in xs])
+    for o, y in zip(outs, ys):
+        rel_close(o, y, what='detect raw')
+    dxs = mine.backward([d.cuda() for d in dys])
+    for d, x in zip(dxs, xs):
+        rel_close(d.t[..., :x.shape[1]], nhwc(x.grad), what='detect dx')
+    _grads_close(mine, ref, 'DecoupledDetect')

@@ -377,3 +377,309 @@ extern "C" int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff,
                        dmax, amaxp, B, HW, C);
     return launch_status("somi_pool_bwd_add_nhwc_f32");
 }
+
+// =================================================================================================================
+// Backward of the remaining layer kernels: detect raw assembly, SPPF pooling, BiFPN fusion, depthwise 3x3, SEAM scaling.
+namespace somi {
+
+// ---- detect: d raw (B,na,ny,nx,no) -> d box (B,ny,nx,box_cs) / d cls (B,ny,nx,cls_cs); pad channels get zeros
+__global__ __launch_bounds__(256) void detect_raw_bwd_kernel(const float *__restrict__ draw, float *__restrict__ dbox, int box_cs,
+                                                             float *__restrict__ dcls, int cls_cs, int B, int ny, int nx, int na, int nc) {
+    const int no = nc + 5;
+    const long npix = (long)B * ny * nx;
+    const long items = npix * (box_cs + cls_cs);
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int j = (int)(it % (box_cs + cls_cs));
+        const long pix = it / (box_cs + cls_cs);
+        const int xg = (int)(pix % nx), yg = (int)((pix / nx) % ny);
+        const long b = pix / ((long)nx * ny);
+        if (j < box_cs) {
+            float v = 0.f;
+            if (j < na * 5) { const int an = j / 5, o = j % 5; v = draw[((((b * na + an) * ny + yg) * nx + xg)) * no + o]; }
+            dbox[pix * box_cs + j] = v;
+        } else {
+            const int jc = j - box_cs;
+            float v = 0.f;
+            if (jc < na * nc) { const int an = jc / nc, o = jc % nc; v = draw[((((b * na + an) * ny + yg) * nx + xg)) * no + 5 + o]; }
+            dcls[pix * cls_cs + jc] = v;
+        }
+    }
+}
+
+// ---- SPPF: the three pooled slices' gradients are routed to the arg-max of their 5/9/13 windows in slice 0 (atomics; tiny maps)
+__global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const float *__restrict__ buf, float *__restrict__ dbuf, int B, int H, int W, int C,
+                                                            int cs, int x_coff) {
+    const long items = (long)B * H * W * C;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C);
+        const long pix = it / C;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        float m[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+        long mi[3] = {0, 0, 0};
+        for (int dh = -6; dh <= 6; ++dh) {
+            const int hi = hv + dh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            const int ah = dh < 0 ? -dh : dh;
+            for (int dw = -6; dw <= 6; ++dw) {
+                const int wi = wv + dw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const int aw = dw < 0 ? -dw : dw;
+                const int rad = ah > aw ? ah : aw;
+                const long q = (b * H + hi) * W + wi;
+                const float v = buf[q * cs + x_coff + c];
+                if (v > m[2]) { m[2] = v; mi[2] = q; }
+                if (rad <= 4 && v > m[1]) { m[1] = v; mi[1] = q; }
+                if (rad <= 2 && v > m[0]) { m[0] = v; mi[0] = q; }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) atomicAdd(dbuf + mi[l] * cs + x_coff + c, dbuf[pix * cs + x_coff + (l + 1) * C + c]);
+    }
+}
+
+// ---- BiFPN: dx_i = wn_i * dout (2x2 sum for an upsampled source); dwn_i = sum dout * src_i
+struct BifpnBwdArgs {
+    const float *src[3];
+    float *dsrc[3];
+    int up[3];
+    float wn[3];
+    int n_in;
+};
+__global__ __launch_bounds__(256) void bifpn_bwd_kernel(BifpnBwdArgs a, const float *__restrict__ dout, float *__restrict__ part, int B, int H,
+                                                        int W, int C) {
+    __shared__ float red[3][4];
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(dout + pix * C + c);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i >= a.n_in) break;
+            const int u = a.up[i];
+            const long sp = (b * (H >> u) + (hv >> u)) * (W >> u) + (wv >> u);
+            const f32x4 sv = *reinterpret_cast<const f32x4 *>(a.src[i] + sp * C + c);
+            acc[i] += (g[0] * sv[0] + g[1] * sv[1]) + (g[2] * sv[2] + g[3] * sv[3]);
+            if (!u) *reinterpret_cast<f32x4 *>(a.dsrc[i] + pix * C + c) = g * a.wn[i];
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        float v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) part[(long)blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+__global__ __launch_bounds__(256) void bifpn_bwd_up_kernel(const float *__restrict__ dout, float *__restrict__ dsrc, float wn, int B, int Hl, int Wl,
+                                                           int C) {
+    const int C4 = C >> 2;
+    const long items = (long)B * Hl * Wl * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % Wl), hv = (int)((pix / Wl) % Hl);
+        const long b = pix / ((long)Wl * Hl);
+        const long base = ((b * (Hl * 2) + hv * 2) * (Wl * 2) + wv * 2) * C + c;
+        const f32x4 s = (*reinterpret_cast<const f32x4 *>(dout + base) + *reinterpret_cast<const f32x4 *>(dout + base + C)) +
+                        (*reinterpret_cast<const f32x4 *>(dout + base + (long)Wl * 2 * C) +
+                         *reinterpret_cast<const f32x4 *>(dout + base + (long)Wl * 2 * C + C));
+        *reinterpret_cast<f32x4 *>(dsrc + pix * C + c) = s * wn;
+    }
+}
+// dw_k += dwn_k / S - (sum_i dwn_i w_i / S^2) * swish'(w_k),  S = sum swish(w) + eps   (models/common.py:3696)
+__global__ void bifpn_bwd_weight_kernel(const float *__restrict__ part, int nblk, const float *__restrict__ w, int n_in, float eps, float *dw) {
+    if (threadIdx.x != 0) return;
+    double dwn[3] = {0, 0, 0};
+    for (int i = 0; i < nblk; ++i)
+        for (int k = 0; k < n_in; ++k) dwn[k] += part[(long)i * 3 + k];
+    double S = eps, T = 0.0;
+    for (int k = 0; k < n_in; ++k) { const double sg = 1.0 / (1.0 + exp(-(double)w[k])); S += w[k] * sg; }
+    for (int k = 0; k < n_in; ++k) T += dwn[k] * w[k];
+    for (int k = 0; k < n_in; ++k) {
+        const double sg = 1.0 / (1.0 + exp(-(double)w[k]));
+        const double dsw = sg * (1.0 + w[k] * (1.0 - sg));
+        dw[k] += (float)(dwn[k] / S - T / (S * S) * dsw);
+    }
+}
+
+// ---- depthwise 3x3: data gradient (the transposed stencil) and weight / bias gradient (per-channel reduction over pixels)
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_data_kernel(const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx,
+                                                                 const float *__restrict__ accumulate, int B, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        f32x4 acc = accumulate ? *reinterpret_cast<const f32x4 *>(accumulate + pix * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ho = hv - (r - 1);
+            if ((unsigned)ho >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int wo = wv - (q - 1);
+                if ((unsigned)wo >= (unsigned)W) continue;
+                acc += *reinterpret_cast<const f32x4 *>(dy + ((b * H + ho) * W + wo) * C + c) * *reinterpret_cast<const f32x4 *>(w + (r * 3 + q) * C + c);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(dx + pix * C + c) = acc;
+    }
+}
+// grid (nchunk): 512-pixel chunks of the flattened batch; per chunk [10][C] partials (9 taps + bias)
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ part,
+                                                                   long npix, int H, int W, int C) {
+    __shared__ f32x4 ls[256];
+    const int C4 = C >> 2;
+    const long p0 = (long)blockIdx.x * 512, p1 = min(p0 + 512, npix);
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        const int c = (cq0 + cq) * 4;
+        f32x4 acc[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rr < rows_par)
+            for (long p = p0 + rr; p < p1; p += rows_par) {
+                const int wv = (int)(p % W), hv = (int)((p / W) % H);
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + p * C + c);
+                acc[9] += g;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int hi = hv + r - 1;
+                    if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int wi = wv + q - 1;
+                        if ((unsigned)wi >= (unsigned)W) continue;
+                        acc[r * 3 + q] += g * *reinterpret_cast<const f32x4 *>(x + (p + (long)(r - 1) * W + (q - 1)) * C + c);
+                    }
+                }
+            }
+        for (int k = 0; k < 10; ++k) {
+            ls[threadIdx.x] = acc[k];
+            __syncthreads();
+            if (threadIdx.x < ncq) {
+                f32x4 s = acc[k];
+                for (int r2 = 1; r2 < rows_par; ++r2) s += ls[r2 * ncq + cq];
+                *reinterpret_cast<f32x4 *>(part + ((long)blockIdx.x * 10 + k) * C + c) = s;
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_final(const float *__restrict__ part, int nchunk, int C, float *dw, float *dbias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 10 * C) return;
+    const int k = i / C, c = i % C;
+    double s = 0.0;
+    for (int j = 0; j < nchunk; ++j) s += part[((long)j * 10 + k) * C + c];
+    if (k == 9) { if (dbias) dbias[c] += (float)s; }
+    else dw[k * C + c] += (float)s;
+}
+
+// ---- y = x * s[b][c] backward: dx = dout * s ; ds[b,c] = sum_p dout * x     (SEAM output, models/common.py:8489-8490)
+__global__ __launch_bounds__(256) void scale_channels_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ x, const float *__restrict__ s,
+                                                                 float *__restrict__ dx, float *__restrict__ part, int HW, int C, int nchunk) {
+    __shared__ f32x4 l1[256];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int C4 = C >> 2;
+    const int p0 = chunk * IMG_CHUNK, p1 = min(p0 + IMG_CHUNK, HW);
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        const int c = (cq0 + cq) * 4;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        if (rr < rows_par) {
+            const f32x4 sv = *reinterpret_cast<const f32x4 *>(s + (long)b * C + c);
+            for (int pl = p0 + rr; pl < p1; pl += rows_par) {
+                const long p = (long)b * HW + pl;
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(dout + p * C + c);
+                s1 += g * *reinterpret_cast<const f32x4 *>(x + p * C + c);
+                *reinterpret_cast<f32x4 *>(dx + p * C + c) = g * sv;
+            }
+        }
+        l1[threadIdx.x] = s1;
+        __syncthreads();
+        if (threadIdx.x < ncq) {
+            for (int r2 = 1; r2 < rows_par; ++r2) s1 += l1[r2 * ncq + cq];
+            *reinterpret_cast<f32x4 *>(part + ((long)b * nchunk + chunk) * C + c) = s1;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace somi
+
+extern "C" int somi_detect_raw_bwd_f32(const float *draw, float *dbox, int box_cs, float *dcls, int cls_cs, int B, int ny, int nx, int na,
+                                       int nc, somi_stream_t stream) {
+    SOMI_REQUIRE(draw && dbox && dcls && B > 0 && ny > 0 && nx > 0 && na > 0 && nc > 0 && box_cs >= na * 5 && cls_cs >= na * nc, SOMI_EINVAL,
+                 "detect raw bwd: bad arguments");
+    hipLaunchKernelGGL(detect_raw_bwd_kernel, dim3(ew_grid((long)B * ny * nx * (box_cs + cls_cs))), dim3(256), 0, (hipStream_t)stream, draw, dbox,
+                       box_cs, dcls, cls_cs, B, ny, nx, na, nc);
+    return launch_status("somi_detect_raw_bwd_f32");
+}
+
+extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream) {
+    SOMI_REQUIRE(buf && dbuf && B > 0 && H > 0 && W > 0 && C > 0 && x_coff + 4 * C <= cs, SOMI_EINVAL, "sppf bwd: bad arguments");
+    hipLaunchKernelGGL(sppf_pool_bwd_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, buf, dbuf, B, H, W, C, cs, x_coff);
+    return launch_status("somi_sppf_pool_bwd_nhwc_f32");
+}
+
+extern "C" int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *wn_host,
+                                       const float *w_dev, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
+                                       int W, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(src_host && dsrc_host && up_host && wn_host && w_dev && dout && dw_accumulate && workspace && (n_in == 2 || n_in == 3) &&
+                     C % 4 == 0, SOMI_EINVAL, "bifpn bwd: bad arguments");
+    BifpnBwdArgs a;
+    for (int i = 0; i < 3; ++i) {
+        a.src[i] = i < n_in ? src_host[i] : nullptr;
+        a.dsrc[i] = i < n_in ? dsrc_host[i] : nullptr;
+        a.up[i] = i < n_in ? up_host[i] : 0;
+        a.wn[i] = i < n_in ? wn_host[i] : 0.f;
+        SOMI_REQUIRE(i >= n_in || (a.src[i] && a.dsrc[i] && (a.up[i] == 0 || a.up[i] == 1)), SOMI_EINVAL, "bifpn bwd: bad source %d", i);
+    }
+    a.n_in = n_in;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ew_grid((long)B * H * W * (C / 4));
+    hipLaunchKernelGGL(bifpn_bwd_kernel, dim3(nblk), dim3(256), 0, s, a, dout, workspace, B, H, W, C);
+    for (int i = 0; i < n_in; ++i)
+        if (a.up[i])
+            hipLaunchKernelGGL(bifpn_bwd_up_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, dout, a.dsrc[i], a.wn[i], B,
+                               H / 2, W / 2, C);
+    hipLaunchKernelGGL(bifpn_bwd_weight_kernel, dim3(1), dim3(64), 0, s, workspace, nblk, w_dev, n_in, 1e-4f, dw_accumulate);
+    return launch_status("somi_bifpn_bwd_nhwc_f32");
+}
+
+extern "C" int somi_dwconv3x3_bwd_nhwc_f32(const float *dy, const float *x, const float *w, float *dx, const float *dx_accumulate, float *dw_accumulate,
+                                           float *dbias_accumulate, float *workspace, int B, int H, int W, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(dy && x && w && dx && dw_accumulate && workspace && B > 0 && H > 0 && W > 0 && C % 4 == 0 && aligned16(dy) && aligned16(x) &&
+                     aligned16(dx) && aligned16(w), SOMI_EINVAL, "dwconv bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dy, w, dx, dx_accumulate, B, H, W, C);
+    const int nchunk = (int)((npix + 511) / 512);
+    hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(nchunk), dim3(256), 0, s, dy, x, workspace, npix, H, W, C);
+    hipLaunchKernelGGL(dwconv3x3_bwd_weight_final, dim3(cdiv(10L * C, 256)), dim3(256), 0, s, workspace, nchunk, C, dw_accumulate, dbias_accumulate);
+    return launch_status("somi_dwconv3x3_bwd_nhwc_f32");
+}
+
+extern "C" int somi_scale_channels_bwd_nhwc_f32(const float *dout, const float *x, const float *s, float *dx, float *ds, float *workspace, int B,
+                                                int HW, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(dout && x && s && dx && ds && workspace && B > 0 && HW > 0 && C % 4 == 0 && aligned16(dout) && aligned16(x) && aligned16(dx) &&
+                     aligned16(s), SOMI_EINVAL, "scale channels bwd: bad arguments");
+    const int nchunk = somi_img_nchunk(HW);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(scale_channels_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, dout, x, s, dx, workspace, HW, C, nchunk);
+    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, workspace, nchunk, C, B, ds);
+    return launch_status("somi_scale_channels_bwd_nhwc_f32");
+}

@@ -75,6 +75,11 @@ SIGNATURES = {
     'somi_pool_argmax_nhwc_f32': (I, [P, I, I, I, I, I, P, P, S]),
     'somi_attn_mlp_bwd_f32': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
     'somi_pool_bwd_add_nhwc_f32': (I, [P, I, I, P, P, P, I, I, I, S]),
+    'somi_detect_raw_bwd_f32': (I, [P, P, I, P, I, I, I, I, I, I, S]),
+    'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, I, I, I, I, I, I, S]),
+    'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float), P, I, P, P, P, I, I, I, I, S]),
+    'somi_dwconv3x3_bwd_nhwc_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, S]),
+    'somi_scale_channels_bwd_nhwc_f32': (I, [P, P, P, P, P, P, I, I, I, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),

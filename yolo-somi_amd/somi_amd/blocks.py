@@ -209,13 +209,34 @@ class PlainConv(_Packed):
         return _pack_wb(*_fold_conv_bn(self.conv, None), dev)
 
     def forward(self, x):
+        if self.training:
+            self.invalidate()
         wp, bp = self._packed(x.t.device)
         k = self.conv.kernel_size[0]
         B, H, W, _ = x.shape
         out = new_act(x.t, H, W, self.conv.out_channels)
         ops.conv2d_nhwc(x.t, wp, bp, kh=k, kw=k, stride=1, pad=k // 2, act='none', cin=pad4(x.c), x_coff=x.coff,
                         out=out.t, cout=pad4(self.conv.out_channels), alg_cin=x.c, alg_cout=self.conv.out_channels)
+        if self.training:
+            self.__dict__['_ctx'] = x
         return out
+
+    def backward(self, dy):
+        """dy: whole padded gradient tensor (pad channels zero).  Returns dx (Act)."""
+        x = self.__dict__.pop('_ctx')
+        k = self.conv.kernel_size[0]
+        c1, c2 = self.conv.in_channels, self.conv.out_channels
+        cp = pad4(c2)
+        B, H, W, _ = x.shape
+        dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=1, pad=k // 2, cin=pad4(c1), x_coff=x.coff, cout=cp)
+        _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))
+        db = torch.zeros(cp, device=dy.device)
+        ops.chan_sum_(dy, cp, 0, db)
+        _acc_grad(self.conv.bias, db[:c2])
+        wt = pack_dgrad_weight(self.conv.weight.detach().float()).to(dy.device)
+        dx = Act(torch.empty(B, H, W, pad4(c1), device=dy.device, dtype=torch.float32), 0, c1)
+        ops.conv2d_dgrad_nhwc(dy, wt, B=B, H=H, W=W, cin=pad4(c1), kh=k, kw=k, stride=1, pad=k // 2, cout=cp, out=dx.t)
+        return dx
 
 
 class ChannelAttentionModule(_Packed):
@@ -377,7 +398,16 @@ class SPPF(nn.Module):
         cat = Act(torch.empty(B, H, W, 4 * c_, device=x.t.device, dtype=torch.float32))
         self.cv1(x, out=cat.slice(0, c_))
         ops.sppf_pool_(cat.t, c_, 0)
+        if self.training:
+            self.__dict__['_ctx'] = cat
         return self.cv2(cat)
+
+    def backward(self, dout, dx_out=None, accumulate=False):
+        cat = self.__dict__.pop('_ctx')
+        c_ = self.cv1.conv.out_channels
+        dcat = self.cv2.backward(dout)
+        ops.sppf_pool_backward_(cat.t, dcat.t, c_, 0)
+        return self.cv1.backward(dcat.slice(0, c_), dx_out=dx_out, accumulate=accumulate)
 
 
 class Swish(nn.Module):
@@ -405,7 +435,18 @@ class BiFPN(_Packed):
             if a.coff != 0 or a.t.shape[3] != xs[0].t.shape[3]:
                 raise NotImplementedError('BiFPN inputs must be whole tensors of equal width')
         out = ops.bifpn([a.t for a in xs], [a.up for a in xs], wn)
+        if self.training:
+            self.__dict__['_ctx'] = (xs, wn)
         return Act(out, 0, xs[0].c)
+
+    def backward(self, dout):
+        """Returns the list of input gradients (low-resolution for the virtually upsampled inputs)."""
+        xs, wn = self.__dict__.pop('_ctx')
+        dw = torch.zeros_like(self.weight.data)
+        ds = ops.bifpn_backward([a.t for a in xs], [a.up for a in xs], wn, self.weight.detach(), dout.t, dw)
+        _acc_grad(self.weight, dw)
+        self.invalidate()
+        return [Act(d, 0, a.c) for d, a in zip(ds, xs)]
 
 
 class Upsample(nn.Module):
@@ -418,6 +459,9 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         return Act(x.t, x.coff, x.c, up=x.up + 1)
+
+    def backward(self, dout):
+        return dout                                              # the consumer (BiFPN) already produced the low-resolution gradient
 
 
 class ODConv2d_3rd(_Packed):
@@ -524,11 +568,14 @@ class SEAM(_Packed):
                 nn.init.constant_(m.bias, 0)
 
     def _pack(self, dev):
-        if self.training:
-            raise NotImplementedError('training-mode BatchNorm (batch statistics) is not built yet on the HIP path')
         f = lambda t: t.detach().float().contiguous().to(dev)   # noqa: E731
         dw = lambda conv: f(conv.weight[:, 0].permute(1, 2, 0).reshape(9, -1))   # noqa: E731  [9][C]
         d = self.DCovN
+        if self.training:
+            st = d[3]
+            return dict(dw0=dw(d[0]), b0=f(d[0].bias), dw1=dw(st[0].fn[0]), b1=f(st[0].fn[0].bias), pw=f(st[1].weight.flatten(1)),
+                        pb=f(st[1].bias), pwt=pack_dgrad_weight(st[1].weight.detach().float()).to(dev), W1=f(self.fc[0].weight),
+                        W2=f(self.fc[2].weight))
         st = d[3]
         pw = st[1]
         return dict(dw0=dw(d[0]), b0=f(d[0].bias), bn0=tuple(map(f, bn_fold(d[2]))),
@@ -536,10 +583,82 @@ class SEAM(_Packed):
                     pw=f(pw.weight.flatten(1)), pb=f(pw.bias), bn2=tuple(map(f, bn_fold(st[3]))),
                     W1=f(self.fc[0].weight), W2=f(self.fc[2].weight))
 
-    def forward(self, x):
+    # ------------------------------------------------------------------------------------------ training mode
+    def _bn_train(self, u, bn):
+        """z = BN_batch(GELU(u)) (act before the norm, models/common.py:8455-8457); returns z and the saved statistics."""
+        dev, c = u.device, u.shape[3]
+        g = ops.chan_affine_act(u, c, 0, torch.ones(c, device=dev), torch.zeros(c, device=dev), 'gelu', 0, torch.empty_like(u))
+        rm, rv = bn.running_mean.detach().clone(), bn.running_var.detach().clone()
+        mean, rstd, scale, shift = ops.bn_stats(g, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv)
+        with torch.no_grad():
+            bn.running_mean.copy_(rm)
+            bn.running_var.copy_(rv)
+            bn.num_batches_tracked += 1
+        z = ops.chan_affine_act(g, c, 0, scale, shift, 'none', 0, g)
+        return z, (mean, rstd, scale, shift)
+
+    def _bn_backward(self, dz, u, st, bn):
+        """gradient w.r.t. u of BN_batch(GELU(u)) (order 1), parameter gradients accumulated."""
+        c = u.shape[3]
+        dg, db = torch.zeros(c, device=u.device), torch.zeros(c, device=u.device)
+        du = ops.bn_act_backward(dz, 0, u, 0, c, *st, 'gelu', 1, True, torch.empty_like(u), 0, dg, db)
+        _acc_grad(bn.weight, dg)
+        _acc_grad(bn.bias, db)
+        return du
+
+    def _forward_train(self, x):
+        self.invalidate()
         pk = self._packed(x.t.device)
+        d, st = self.DCovN, self.DCovN[3]
+        u0 = ops.dwconv3x3(x.t, pk['dw0'], pk['b0'])
+        y0, s0 = self._bn_train(u0, d[2])
+        u1 = ops.dwconv3x3(y0, pk['dw1'], pk['b1'])
+        z1, s1 = self._bn_train(u1, st[0].fn[2])
+        y1 = ops.add_(z1, 0, y0, 0, x.c)
+        u2 = ops.conv2d_nhwc(y1, pk['pw'], pk['pb'], kh=1, kw=1)
+        y2, s2 = self._bn_train(u2, st[3])
+        avg, _ = ops.global_pool(y2, want_max=False)
+        sc = ops.attn_mlp(1, avg, None, pk['W1'], None, pk['W2'], None)
+        self.__dict__['_ctx'] = (x, u0, s0, y0, u1, s1, y1, u2, s2, avg, sc, pk)
+        return Act(ops.scale_channels(x.t, sc), 0, x.c)
+
+    def backward(self, dout):
+        x, u0, s0, y0, u1, s1, y1, u2, s2, avg, sc, pk = self.__dict__.pop('_ctx')
+        d, st = self.DCovN, self.DCovN[3]
+        c = x.c
+        dev = x.t.device
+        dx, dsc = ops.scale_channels_backward(dout.t, x.t, sc)
+        gW1, gW2 = torch.zeros_like(pk['W1']), torch.zeros_like(pk['W2'])
+        davg, _ = ops.attn_mlp_backward(1, dsc, sc, avg, None, pk['W1'], None, pk['W2'], gW1, None, gW2, None)
+        _acc_grad(self.fc[0].weight, gW1)
+        _acc_grad(self.fc[2].weight, gW2)
+        dy2 = torch.zeros_like(u2)
+        ops.pool_backward_add_(dy2, 0, c, davg)
+        du2 = self._bn_backward(dy2, u2, s2, st[3])
+        dwp = ops.conv2d_wgrad_nhwc(y1, du2, kh=1, kw=1)
+        _acc_grad(st[1].weight, dwp.view(c, c, 1, 1))
+        dbp = torch.zeros(c, device=dev)
+        ops.chan_sum_(du2, c, 0, dbp)
+        _acc_grad(st[1].bias, dbp)
+        dy1 = ops.conv2d_dgrad_nhwc(du2, pk['pwt'], B=x.shape[0], H=x.shape[1], W=x.shape[2], cin=c, kh=1, kw=1)
+        du1 = self._bn_backward(dy1, u1, s1, st[0].fn[2])
+        gw, gb = torch.zeros_like(pk['dw1']), torch.zeros(c, device=dev)
+        dy0 = ops.dwconv3x3_backward(du1, y0, pk['dw1'], gw, gb, dx_accumulate=dy1)       # + the residual branch
+        _acc_grad(st[0].fn[0].weight, gw.view(3, 3, c).permute(2, 0, 1).unsqueeze(1))
+        _acc_grad(st[0].fn[0].bias, gb)
+        du0 = self._bn_backward(dy0, u0, s0, d[2])
+        gw0, gb0 = torch.zeros_like(pk['dw0']), torch.zeros(c, device=dev)
+        dx = ops.dwconv3x3_backward(du0, x.t, pk['dw0'], gw0, gb0, dx_accumulate=dx)
+        _acc_grad(d[0].weight, gw0.view(3, 3, c).permute(2, 0, 1).unsqueeze(1))
+        _acc_grad(d[0].bias, gb0)
+        return Act(dx, 0, c)
+
+    def forward(self, x):
         if x.coff != 0 or x.t.shape[3] != x.c or x.c % 4:
             raise NotImplementedError('SEAM input must be a whole tensor with channels a multiple of 4')
+        if self.training:
+            return self._forward_train(x)
+        pk = self._packed(x.t.device)
         y0 = ops.dwconv3x3(x.t, pk['dw0'], pk['b0'], *pk['bn0'], act='gelu')
         y1 = ops.dwconv3x3(y0, pk['dw1'], pk['b1'], *pk['bn1'], residual=y0, act='gelu')
         y2 = ops.conv2d_nhwc(y1, pk['pw'], pk['pb'], kh=1, kw=1, act='gelu', post_scale=pk['bn2'][0],
@@ -568,10 +687,19 @@ class Decouple(nn.Module):
         self._c3.invalidate()
 
     def forward(self, x):
+        if self.training:
+            self._b3.train(), self._c3.train()
+        else:
+            self._b3.eval(), self._c3.eval()
         x = self.a(x)
         b = self._b3(self.b2(self.b1(x)))
         c = self._c3(self.c2(self.c1(x)))
         return b, c
+
+    def backward(self, dbox, dcls):
+        d = self.c1.backward(self.c2.backward(self._c3.backward(dcls)))
+        d = self.b1.backward(self.b2.backward(self._b3.backward(dbox)), dx_out=d, accumulate=True)
+        return self.a.backward(d)
 
 
 class DecoupledDetect(nn.Module):
@@ -607,4 +735,15 @@ class DecoupledDetect(nn.Module):
                               z=z, total=total, row_off=row)
             raws.append(raw)
             row += self.na * ny * nx
+            if self.training:
+                self.__dict__.setdefault('_ctx', []).append((b.t.shape[3], c.t.shape[3]))
         return raws if self.training else (z, raws)
+
+    def backward(self, draws):
+        """draws: gradients w.r.t. the nl training outputs (B,na,ny,nx,no).  Returns the per-level input gradients."""
+        widths = self.__dict__.pop('_ctx')
+        outs = []
+        for i in range(self.nl):
+            dbox, dcls = ops.detect_raw_backward(draws[i].contiguous(), widths[i][0], widths[i][1], self.na, self.nc)
+            outs.append(self.m[i].backward(dbox, dcls))
+        return outs

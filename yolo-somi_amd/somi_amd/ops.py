@@ -368,3 +368,49 @@ def pool_backward_add_(dt, d_coff, c, davg, dmax=None, amaxp=None):
     check(_lib.lib().somi_pool_bwd_add_nhwc_f32(_ptr(_f32c(dt)), cs, d_coff, _ptr(davg), _ptr(dmax), _ptr(amaxp), B, H * W, c, _stream()),
           'pool_bwd_add')
     return dt
+
+
+def detect_raw_backward(draw, box_cs, cls_cs, na, nc):
+    B, _, ny, nx, _ = draw.shape
+    dbox = torch.empty(B, ny, nx, box_cs, device=draw.device, dtype=torch.float32)
+    dcls = torch.empty(B, ny, nx, cls_cs, device=draw.device, dtype=torch.float32)
+    check(_lib.lib().somi_detect_raw_bwd_f32(_ptr(_f32c(draw)), _ptr(dbox), box_cs, _ptr(dcls), cls_cs, B, ny, nx, na, nc, _stream()),
+          'detect_raw_bwd')
+    return dbox, dcls
+
+
+def sppf_pool_backward_(buf, dbuf, c, x_coff=0):
+    B, H, W, cs = buf.shape
+    check(_lib.lib().somi_sppf_pool_bwd_nhwc_f32(_ptr(_f32c(buf)), _ptr(_f32c(dbuf)), B, H, W, c, cs, x_coff, _stream()), 'sppf_pool_bwd')
+    return dbuf
+
+
+def bifpn_backward(srcs, ups, wn, w_dev, dout, dw):
+    n = len(srcs)
+    B, H, W, Cc = dout.shape
+    dsrcs = [torch.empty_like(s) for s in srcs]
+    sp = (C.c_void_p * n)(*[_ptr(_f32c(s)) for s in srcs])
+    dp = (C.c_void_p * n)(*[_ptr(d) for d in dsrcs])
+    ws = torch.empty(3 * 2048, device=dout.device, dtype=torch.float32)
+    check(_lib.lib().somi_bifpn_bwd_nhwc_f32(sp, dp, (C.c_int * n)(*ups), (C.c_float * n)(*[float(v) for v in wn]), _ptr(w_dev), n,
+                                             _ptr(_f32c(dout)), _ptr(dw), _ptr(ws), B, H, W, Cc, _stream()), 'bifpn_bwd')
+    return dsrcs
+
+
+def dwconv3x3_backward(dy, x, w, dw, dbias, dx_accumulate=None):
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    ws = torch.empty(((B * H * W + 511) // 512) * 10 * Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().somi_dwconv3x3_bwd_nhwc_f32(_ptr(_f32c(dy)), _ptr(_f32c(x)), _ptr(w), _ptr(dx), _ptr(dx_accumulate), _ptr(dw), _ptr(dbias),
+                                                 _ptr(ws), B, H, W, Cc, _stream()), 'dwconv3x3_bwd')
+    return dx
+
+
+def scale_channels_backward(dout, x, s):
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    ds = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * _lib.lib().somi_img_nchunk(H * W) * Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().somi_scale_channels_bwd_nhwc_f32(_ptr(_f32c(dout)), _ptr(_f32c(x)), _ptr(s), _ptr(dx), _ptr(ds), _ptr(ws), B, H * W, Cc,
+                                                      _stream()), 'scale_channels_bwd')
+    return dx, ds
