@@ -209,3 +209,55 @@ def test_decoupled_detect_train_backward():
     for d, x in zip(dxs, xs):
         rel_close(d.t[..., :x.shape[1]], nhwc(x.grad), what='detect dx')
     _grads_close(mine, ref, 'DecoupledDetect')
+
+
+def _train_cfg(odconv):
+    from oracle.somi_ref.testing import somi_cfg, SOMI_ANCHORS
+    cfg = somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS)
+    if not odconv:                                           # the graph walk without the dynamic-conv layers
+        for sect in ('backbone', 'head'):
+            for l in cfg[sect]:
+                if l[2] == 'ODConv_3rd':
+                    l[2], l[3] = 'Conv', [l[3][0], 3, 2]
+    return cfg
+
+
+@pytest.mark.parametrize('odconv', [False])
+def test_whole_model_train_step_gradients(odconv):
+    """loss.backward() through the whole SOMI graph on HIP vs the CPU oracle (torch autograd): loss, every parameter gradient,
+    BN running statistics."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.loss import ComputeLoss as OLoss
+    from oracle.somi_ref.testing import fill_state, synthetic_batch, HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    from somi_amd.model import Model
+    cfg = _train_cfg(odconv)
+    ref = fill_state(OModel(cfg), 2)
+    mine = Model(cfg)
+    mine.load_state_dict(ref.state_dict())
+    ref.hyp = mine.hyp = dict(HYP_VISDRONE)
+    imgs, targets = synthetic_batch(2, 64, seed=1)
+    ref.train()
+    pr = ref(imgs.float() / 255)
+    lr, ir = OLoss(ref)(pr, targets)
+    lr.backward()
+    mine = mine.cuda().train()
+    pm = mine(imgs.cuda())
+    for a, b in zip(pm, pr):
+        rel_close(a, b, what='train outputs')
+    lm, im = ComputeLoss(mine)(pm, targets.cuda())
+    rel_close(lm, lr, rel=1e-4, what='loss')
+    lm.backward()
+    bad = []
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            continue
+        assert p.grad is not None, n
+        err = (p.grad.cpu().double() - q.grad.double()).abs().max().item()
+        scale = q.grad.double().abs().max().item() + 1e-9
+        if err > 2e-3 * scale + 1e-7:
+            bad.append((n, err, scale))
+    assert not bad, bad[:8]
+    for (n, p), (_, q) in zip(mine.named_buffers(), ref.named_buffers()):
+        if 'running' in n:
+            rel_close(p, q, what=n)

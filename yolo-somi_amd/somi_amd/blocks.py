@@ -151,7 +151,7 @@ class Conv(_Packed):
         self.__dict__['_ctx'] = (x, y, mean, rstd, scale, shift, pk)
         return Act(out.t, out.coff, c2)
 
-    def backward(self, dz, dx_out=None, accumulate=False):
+    def backward(self, dz, dx_out=None, accumulate=False, need_dx=True):
         """dz: gradient w.r.t. this block's output (Act).  Returns the gradient w.r.t. the input as an Act (written into
         dx_out if given, added to it if accumulate).  Parameter gradients are accumulated into .grad (reference layout)."""
         x, y, mean, rstd, scale, shift, pk = self.__dict__.pop('_ctx')
@@ -169,6 +169,8 @@ class Conv(_Packed):
         B, H, W, _ = x.shape
         dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp)
         _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))
+        if not need_dx:
+            return None
         if dx_out is None:
             dx_out = Act(torch.empty(B, H, W, pad4(c1), device=dev, dtype=torch.float32), 0, c1)
         ops.conv2d_dgrad_nhwc(dy, pk['wt'], B=B, H=H, W=W, cin=pad4(c1), kh=k, kw=k, stride=s, pad=p, cout=cp, out=dx_out.t,

@@ -169,6 +169,40 @@ class Model(nn.Module):
             raise NotImplementedError('TTA (_forward_augment, models/yolo.py:1253-1267) is outside the hot path')
         return self._forward_once(x)
 
+    # ---------------------------------------------------------------------------------------------- training
+    def _sources(self, m):
+        f = m.f if isinstance(m.f, (list, tuple)) else [m.f]
+        return [m.i - 1 if j == -1 else j for j in f]
+
+    def _backward_walk(self, draws):
+        """Reverse walk of the layer graph (the autograd of models/yolo.py:1269-1290 done by hand): `draws` are the gradients
+        w.r.t. the training outputs; parameter gradients are accumulated into .grad by the blocks."""
+        grads = {}
+
+        def give(src, d):
+            if src < 0:
+                return                                            # the input image needs no gradient
+            if src not in grads:
+                grads[src] = d
+            else:
+                g = grads[src]
+                ops.add_(g.t, g.coff, d.t, d.coff, g.t.shape[3] - g.coff)
+        det = self.model[-1]
+        for src, d in zip(self._sources(det), det.backward(draws)):
+            give(src, d)
+        for m in reversed(list(self.model)[:-1]):
+            g = grads.pop(m.i, None)
+            if g is None:
+                raise RuntimeError(f'layer {m.i} ({m.type}) received no gradient')
+            srcs = self._sources(m)
+            if isinstance(m, B.BiFPN):
+                for src, d in zip(srcs, m.backward(g)):
+                    give(src, d)
+            elif m.i == 0:
+                m.backward(g, need_dx=False)
+            else:
+                give(srcs[0], m.backward(g))
+
     def _forward_once(self, x):
         """models/yolo.py:1269-1290: walk the layers with the skip list."""
         if not x.is_cuda:
@@ -182,4 +216,27 @@ class Model(nn.Module):
                 a = y[m.f] if isinstance(m.f, int) else [a if j == -1 else y[j] for j in m.f]
             a = m(a)
             y.append(a if m.i in self.save else None)
+        if self.training:
+            return list(_ModelGraph.apply(self._anchor(x.device), self, *a))
         return a
+
+    def _anchor(self, dev):
+        t = self.__dict__.get('_anchor_t')
+        if t is None or t.device != dev:
+            t = self.__dict__['_anchor_t'] = torch.zeros(1, device=dev, requires_grad=True)
+        return t
+
+
+class _ModelGraph(torch.autograd.Function):
+    """Makes `loss.backward()` (train.py:270) drive the hand-written reverse walk: the training outputs are this node's
+    outputs, its backward hands their gradients to Model._backward_walk, which fills the parameters' .grad."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, *raws):
+        ctx.model = model
+        return tuple(r.view_as(r) for r in raws)
+
+    @staticmethod
+    def backward(ctx, *draws):
+        ctx.model._backward_walk([d.contiguous() for d in draws])
+        return (None, None) + (None,) * len(draws)
