@@ -291,6 +291,22 @@ int somi_dwconv3x3_bwd_nhwc_f32(const float *dy, const float *x, const float *w,
 int somi_scale_channels_bwd_nhwc_f32(const float *dout, const float *x, const float *s, float *dx, float *ds, float *workspace, int B,
                                      int HW, int C, somi_stream_t stream);
 
+/* Training path of ODConv (models/common.py:4495-4624), see train_odconv.hip.
+ * linear:     y[b][y_off+o] = act(x[b] . W[o] + bias[o]); act = enum somi_act or 5 = softmax over the nout outputs (<= 64).
+ * linear_bwd: (dy, y) are slices (ld, off) of one buffer pair; computes d(pre-activation) through `act`, then dW, db ACCUMULATED,
+ *             dx (B,nin) written or accumulated.  workspace: B*nout floats.
+ * synth:      per-sample weights / biases from an attention buffer laid out [a_f(Cout) | a_s(kk) | a_c(Cin) | a_w(K)] per sample.
+ * synth_bwd:  from dW_b (B,Cout,kk*Cin_pad) and dbias_b (B,Cout): dWk, dbiask ACCUMULATED (float atomics), dattn (same layout) written. */
+int somi_linear_f32(const float *x, int ldx, const float *W, const float *bias, int act, float *y, int ldy, int y_off, int B, int nin,
+                    int nout, somi_stream_t stream);
+int somi_linear_bwd_f32(const float *x, int ldx, const float *W, const float *dy, const float *y, int ld, int off, int act, float *dW,
+                        float *db, float *dx, int ldx_out, int dx_accumulate, float *workspace, int B, int nin, int nout,
+                        somi_stream_t stream);
+int somi_odconv_synth_f32(const float *attn, const float *Wk, const float *biask, float *wout, float *bout, int B, int Cin, int Cin_pad,
+                          int Cout, int kk, int K, somi_stream_t stream);
+int somi_odconv_synth_bwd_f32(const float *dWb, const float *attn, const float *Wk, const float *biask, const float *dbias_b, float *dWk,
+                              float *dbiask, float *dattn, int B, int Cin, int Cin_pad, int Cout, int kk, int K, somi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.

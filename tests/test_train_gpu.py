@@ -11,12 +11,12 @@ pytestmark = pytest.mark.gpu
 ACTS = {'none': lambda v: v, 'silu': F.silu, 'gelu': F.gelu, 'relu': F.relu}
 
 
-def rel_close(got, want, rel=1e-3, what=''):
+def rel_close(got, want, rel=1e-3, what='', atol=0.0):
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     err = (got - want).abs().max().item()
     scale = want.abs().max().item() + 1e-12
-    assert err <= rel * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+    assert err <= rel * scale + atol, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
 
 
 def nhwc(t):
@@ -73,7 +73,8 @@ def _grads_close(mine, ref, what):
         if q.grad is None:
             continue
         assert p.grad is not None, f'{what}: {n} has no gradient'
-        rel_close(p.grad, q.grad, what=f'{what}: d{n}')
+        # atol: gradients that are analytically zero (e.g. a bias in front of a batch-norm) are rounding noise on both sides
+        rel_close(p.grad, q.grad, what=f'{what}: d{n}', atol=2e-5)
 
 
 def test_conv_block_train_forward_backward():
@@ -222,7 +223,7 @@ def _train_cfg(odconv):
     return cfg
 
 
-@pytest.mark.parametrize('odconv', [False])
+@pytest.mark.parametrize('odconv', [False, True])
 def test_whole_model_train_step_gradients(odconv):
     """loss.backward() through the whole SOMI graph on HIP vs the CPU oracle (torch autograd): loss, every parameter gradient,
     BN running statistics."""
@@ -261,3 +262,16 @@ def test_whole_model_train_step_gradients(odconv):
     for (n, p), (_, q) in zip(mine.named_buffers(), ref.named_buffers()):
         if 'running' in n:
             rel_close(p, q, what=n)
+
+
+@pytest.mark.parametrize('B', [3, 1])
+def test_odconv_train_forward_backward(B):
+    from oracle.somi_ref import blocks as OB
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd import blocks as MB
+    ref = fill_state(OB.ODConv_3rd(16, 32, 3, 2, 4), 12)
+    OB.initialize_weights(ref)
+    mine = MB.ODConv_3rd(16, 32, 3, 2, 4)
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(B, 16, 12, 12, generator=torch.Generator().manual_seed(B))
+    _run_block_train(mine, ref, x, 41 + B, f'ODConv B={B}', 16)

@@ -80,6 +80,10 @@ SIGNATURES = {
     'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float), P, I, P, P, P, I, I, I, I, S]),
     'somi_dwconv3x3_bwd_nhwc_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, S]),
     'somi_scale_channels_bwd_nhwc_f32': (I, [P, P, P, P, P, P, I, I, I, S]),
+    'somi_linear_f32': (I, [P, I, P, P, I, P, I, I, I, I, I, S]),
+    'somi_linear_bwd_f32': (I, [P, I, P, P, P, I, I, I, P, P, P, I, I, P, I, I, I, S]),
+    'somi_odconv_synth_f32': (I, [P, P, P, P, P, I, I, I, I, I, I, S]),
+    'somi_odconv_synth_bwd_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),

@@ -502,9 +502,105 @@ class ODConv_3rd(_Packed):
         self.bn = nn.BatchNorm2d(c2)
         self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
 
+    # ------------------------------------------------------------------------------------------ training mode
+    def _forward_train(self, x):
+        cv = self.conv
+        dev = x.t.device
+        f = lambda t: t.detach().float().contiguous()            # noqa: E731
+        B, H, W, _ = x.shape
+        k, s, p = cv.kernel_size[0], cv.stride, cv.padding
+        cin, cout, kk, K = cv.in_channels, cv.out_channels, k * k, cv.K
+        if cin % 4 or cout % 4 or x.coff != 0 or x.t.shape[3] != cin:
+            raise NotImplementedError('ODConv training path needs whole tensors with channels % 4 == 0')
+        hid = cv.fc.weight.shape[0]
+        fcw = f(cv.fc.weight).flatten(1)
+        gap, _ = ops.global_pool(x.t, want_max=False)
+        zpre = ops.linear(gap, fcw, None, 'none')
+        one, zero = torch.ones(hid, device=dev), torch.zeros(hid, device=dev)
+        if B > 1:                                                 # BatchNorm over the B samples (models/common.py:4562-4563)
+            rm, rv = cv.bn.running_mean.detach().clone(), cv.bn.running_var.detach().clone()
+            st = ops.bn_stats(zpre.view(B, 1, 1, hid), hid, 0, f(cv.bn.weight), f(cv.bn.bias), cv.bn.eps, cv.bn.momentum, rm, rv)
+            with torch.no_grad():
+                cv.bn.running_mean.copy_(rm)
+                cv.bn.running_var.copy_(rv)
+                cv.bn.num_batches_tracked += 1
+        else:
+            st = (zero, one, one, zero)
+        z = ops.chan_affine_act(zpre.view(B, 1, 1, hid), hid, 0, st[2], st[3], 'relu', 0, torch.empty(B, 1, 1, hid, device=dev)).view(B, hid)
+        na = cout + kk + cin + K
+        attn = torch.empty(B, na, device=dev)
+        heads = ((cv.fc_f, 0, 'sigmoid'), (cv.fc_s, cout, 'sigmoid'), (cv.fc_c, cout + kk, 'sigmoid'), (cv.fc_w, cout + kk + cin, 'softmax'))
+        for lin, off, act in heads:
+            ops.linear(z, f(lin.weight), f(lin.bias), act, attn, off)
+        Wk = pack_conv_weight(cv.weight.detach().float()).to(dev)            # [K][Cout][kk*Cin]
+        biask = f(cv.bias) if cv.bias is not None else None
+        wout, bout = ops.odconv_synth(attn, Wk, biask, cin, cin, cout, kk, K)
+        Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+        y = torch.empty(B, Ho, Wo, cout, device=dev)
+        ops.conv2d_nhwc(x.t, wout, bout, kh=k, kw=k, stride=s, pad=p, act='none', out=y, cout=cout, per_sample_w=True)
+        rm, rv = self.bn.running_mean.detach().clone(), self.bn.running_var.detach().clone()
+        so = ops.bn_stats(y, cout, 0, f(self.bn.weight), f(self.bn.bias), self.bn.eps, self.bn.momentum, rm, rv)
+        with torch.no_grad():
+            self.bn.running_mean.copy_(rm)
+            self.bn.running_var.copy_(rv)
+            self.bn.num_batches_tracked += 1
+        out = torch.empty_like(y)
+        ops.chan_affine_act(y, cout, 0, so[2], so[3], _act_name(self.act), 0, out)
+        self.__dict__['_ctx'] = (x, gap, fcw, zpre, st, z, attn, heads, Wk, biask, wout, y, so)
+        return Act(out, 0, cout)
+
+    def backward(self, dz, need_dx=True):
+        x, gap, fcw, zpre, st, z, attn, heads, Wk, biask, wout, y, so = self.__dict__.pop('_ctx')
+        cv = self.conv
+        dev = y.device
+        B, H, W, _ = x.shape
+        k, s, p = cv.kernel_size[0], cv.stride, cv.padding
+        cin, cout, kk, K = cv.in_channels, cv.out_channels, k * k, cv.K
+        hid = fcw.shape[0]
+        f = lambda t: t.detach().float().contiguous()            # noqa: E731
+        dg, db = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+        dy = ops.bn_act_backward(dz.t, dz.coff, y, 0, cout, *so, _act_name(self.act), 0, True, torch.empty_like(y), 0, dg, db)
+        _acc_grad(self.bn.weight, dg)
+        _acc_grad(self.bn.bias, db)
+        # per-sample conv: bias, weight and data gradients
+        dbias_b, _ = ops.global_pool(dy, want_max=False)
+        dbias_b = dbias_b * float(dy.shape[1] * dy.shape[2])                  # sum over pixels = mean * HoWo
+        dWb = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, per_sample_w=True)
+        dx = None
+        if need_dx:
+            wt = wout.view(B, cout, kk, cin).permute(0, 3, 2, 1).contiguous().view(B, cin, kk * cout)
+            dx = ops.conv2d_dgrad_nhwc(dy, wt, B=B, H=H, W=W, cin=cin, kh=k, kw=k, stride=s, pad=p, per_sample_w=True)
+        # synthesis backward
+        dWk = torch.zeros_like(Wk)
+        dbk = torch.zeros_like(biask) if biask is not None else None
+        dattn = ops.odconv_synth_backward(dWb, attn, Wk, biask, dbias_b if biask is not None else None, dWk, dbk, cin, cin, cout, kk, K)
+        _acc_grad(cv.weight, dWk.view(K, cout, k, k, cin).permute(0, 1, 4, 2, 3))
+        if biask is not None:
+            _acc_grad(cv.bias, dbk)
+        # attention heads -> dz
+        dzv = torch.empty(B, hid, device=dev)
+        for i, (lin, off, act) in enumerate(heads):
+            gW, gb = torch.zeros_like(lin.weight.data), torch.zeros_like(lin.bias.data)
+            ops.linear_backward(z, f(lin.weight), dattn, attn, off, act, gW, gb, dzv, accumulate=i > 0)
+            _acc_grad(lin.weight, gW)
+            _acc_grad(lin.bias, gb)
+        # relu + BatchNorm over the batch (or plain relu for one sample)
+        g2, b2 = torch.zeros(hid, device=dev), torch.zeros(hid, device=dev)
+        dzpre = ops.bn_act_backward(dzv.view(B, 1, 1, hid), 0, zpre.view(B, 1, 1, hid), 0, hid, *st, 'relu', 0, B > 1,
+                                    torch.empty(B, 1, 1, hid, device=dev), 0, g2, b2).view(B, hid)
+        if B > 1:
+            _acc_grad(cv.bn.weight, g2)
+            _acc_grad(cv.bn.bias, b2)
+        gfc = torch.zeros_like(fcw)
+        dgap = torch.empty_like(gap) if need_dx else None
+        ops.linear_backward(gap, fcw, dzpre, dzpre, 0, 'none', gfc, None, dgap)
+        _acc_grad(cv.fc.weight, gfc.view_as(cv.fc.weight))
+        if not need_dx:
+            return None
+        ops.pool_backward_add_(dx, 0, cin, dgap)
+        return Act(dx, 0, cin)
+
     def _pack(self, dev):
-        if self.training:
-            raise NotImplementedError('training-mode BatchNorm (batch statistics) is not built yet on the HIP path')
         cv = self.conv
         f = lambda t: t.detach().float().contiguous().to(dev)   # noqa: E731
         s_in, t_in = bn_fold(cv.bn)
@@ -519,6 +615,8 @@ class ODConv_3rd(_Packed):
         return pk
 
     def forward(self, x):
+        if self.training:
+            return self._forward_train(x)
         pk = self._packed(x.t.device)
         cv = self.conv
         B, H, W, _ = x.shape

@@ -198,7 +198,7 @@ class Model(nn.Module):
             if isinstance(m, B.BiFPN):
                 for src, d in zip(srcs, m.backward(g)):
                     give(src, d)
-            elif m.i == 0:
+            elif srcs[0] < 0:
                 m.backward(g, need_dx=False)
             else:
                 give(srcs[0], m.backward(g))

@@ -12,7 +12,7 @@ from ._lib import ConvDesc, check
 
 PROFILE = None   # bench.py sets this to a list: every conv launch appends (kernel name, algorithmic FLOPs, ev0, ev1)
 
-ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4}
+ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4, 'softmax': 5}
 
 
 def _ptr(t):
@@ -414,3 +414,40 @@ def scale_channels_backward(dout, x, s):
     check(_lib.lib().somi_scale_channels_bwd_nhwc_f32(_ptr(_f32c(dout)), _ptr(_f32c(x)), _ptr(s), _ptr(dx), _ptr(ds), _ptr(ws), B, H * W, Cc,
                                                       _stream()), 'scale_channels_bwd')
     return dx, ds
+
+
+def linear(x, W, bias, act, out=None, out_off=0):
+    """Small dense layer on (B, nin) rows (ODConv attention heads): out[:, out_off:out_off+nout] = act(x W^T + bias)."""
+    B, nin = x.shape
+    nout = W.shape[0]
+    out = torch.empty(B, nout, device=x.device, dtype=torch.float32) if out is None else out
+    check(_lib.lib().somi_linear_f32(_ptr(_f32c(x)), x.shape[1], _ptr(_f32c(W)), _ptr(bias), ACT[act], _ptr(out), out.shape[1], out_off, B, nin,
+                                     nout, _stream()), 'linear')
+    return out
+
+
+def linear_backward(x, W, dy, y, off, act, dW, db, dx=None, accumulate=False):
+    B, nin = x.shape
+    nout = W.shape[0]
+    ws = torch.empty(B * nout, device=x.device, dtype=torch.float32)
+    check(_lib.lib().somi_linear_bwd_f32(_ptr(_f32c(x)), nin, _ptr(_f32c(W)), _ptr(dy), _ptr(y), y.shape[1], off, ACT[act], _ptr(dW), _ptr(db),
+                                         _ptr(dx), dx.shape[1] if dx is not None else 0, int(accumulate), _ptr(ws), B, nin, nout, _stream()),
+          'linear_bwd')
+    return dx
+
+
+def odconv_synth(attn, Wk, biask, cin, cin_pad, cout, kk, K):
+    B = attn.shape[0]
+    wout = torch.empty(B, cout, kk * cin_pad, device=attn.device, dtype=torch.float32)
+    bout = torch.empty(B, cout, device=attn.device, dtype=torch.float32)
+    check(_lib.lib().somi_odconv_synth_f32(_ptr(attn), _ptr(Wk), _ptr(biask), _ptr(wout), _ptr(bout), B, cin, cin_pad, cout, kk, K, _stream()),
+          'odconv_synth')
+    return wout, bout
+
+
+def odconv_synth_backward(dWb, attn, Wk, biask, dbias_b, dWk, dbiask, cin, cin_pad, cout, kk, K):
+    B = attn.shape[0]
+    dattn = torch.empty_like(attn)
+    check(_lib.lib().somi_odconv_synth_bwd_f32(_ptr(_f32c(dWb)), _ptr(attn), _ptr(Wk), _ptr(biask), _ptr(dbias_b), _ptr(dWk), _ptr(dbiask),
+                                               _ptr(dattn), B, cin, cin_pad, cout, kk, K, _stream()), 'odconv_synth_bwd')
+    return dattn
