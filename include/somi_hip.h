@@ -308,6 +308,16 @@ int somi_odconv_synth_bwd_f32(const float *dWb, const float *attn, const float *
                               float *dbiask, float *dattn, int B, int Cin, int Cin_pad, int Cout, int kk, int K, somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam step (train.py:134-140,271) fused with the ModelEMA update
+ * (utils/torch_utils.py:335-345) over one flat, 16 B-aligned parameter segment:
+ *   g' = grad + weight_decay*param; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ *   param -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps);   ema = d*ema + (1-d)*param  (ema may be NULL)
+ * axpby: y = a*y + b*x (EMA of the BN running statistics). */
+int somi_adam_ema_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, long n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float ema_decay, somi_stream_t stream);
+int somi_axpby_f32(float *y, const float *x, long n, float a, float b, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.
  * Selection is bit-exact with the oracle: candidates in prediction order (row-major over (box, class) for

@@ -275,3 +275,49 @@ def test_odconv_train_forward_backward(B):
     mine.load_state_dict(ref.state_dict())
     x = torch.randn(B, 16, 12, 12, generator=torch.Generator().manual_seed(B))
     _run_block_train(mine, ref, x, 41 + B, f'ODConv B={B}', 16)
+
+
+def test_fused_adam_ema_matches_torch():
+    """Three optimizer steps of the fused Adam+EMA kernel vs torch.optim.Adam with the reference's parameter groups and
+    the reference's ModelEMA rule (utils/torch_utils.py:331-345)."""
+    import copy
+    from somi_amd.optim import FusedAdamEMA, reference_param_groups
+    g = torch.Generator().manual_seed(5)
+    net = nn.Sequential(nn.Conv2d(4, 8, 3, bias=False), nn.BatchNorm2d(8), nn.Conv2d(8, 6, 1), nn.Linear(6, 5))
+    ref = copy.deepcopy(net)
+    ema_ref = copy.deepcopy(net)
+    g0, g1, g2 = reference_param_groups(ref)
+    opt = torch.optim.Adam(g0, lr=3e-4, betas=(0.843, 0.999))
+    opt.add_param_group({'params': g1, 'weight_decay': 0.00036})
+    opt.add_param_group({'params': g2})
+    net = net.cuda()
+    mine = FusedAdamEMA(net, lr=3e-4, betas=(0.843, 0.999), weight_decay=0.00036)
+    for step in range(1, 4):
+        for pg in opt.param_groups:
+            pg['lr'] = 3e-4 * step
+        for pg in mine.param_groups:
+            pg['lr'] = 3e-4 * step
+        grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
+        for p, q, gr in zip(ref.parameters(), net.parameters(), grads):
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        with torch.no_grad():
+            ref[1].running_mean += 0.1 * step
+            net[1].running_mean += 0.1 * step
+        opt.step()
+        mine.step()
+        d = 0.9999 * (1 - math.exp(-step / 2000))
+        with torch.no_grad():
+            msd = ref.state_dict()
+            for k, v in ema_ref.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v *= d
+                    v += (1 - d) * msd[k].detach()
+    for (n, p), (_, q) in zip(ref.named_parameters(), net.named_parameters()):
+        rel_close(q, p, rel=1e-5, what=f'param {n}')
+    esd = mine.ema_state_dict()
+    for k, v in ema_ref.state_dict().items():
+        if v.dtype.is_floating_point:
+            rel_close(esd[k], v, rel=1e-5, what=f'ema {k}')
+    mine.zero_grad()
+    assert all(float(q.grad.abs().max()) == 0.0 for q in net.parameters())

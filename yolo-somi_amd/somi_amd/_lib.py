@@ -84,6 +84,8 @@ SIGNATURES = {
     'somi_linear_bwd_f32': (I, [P, I, P, P, P, I, I, I, P, P, P, I, I, P, I, I, I, S]),
     'somi_odconv_synth_f32': (I, [P, P, P, P, P, I, I, I, I, I, I, S]),
     'somi_odconv_synth_bwd_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, S]),
+    'somi_adam_ema_step_f32': (I, [P, P, P, P, P, C.c_long, F, F, F, F, F, I, F, S]),
+    'somi_axpby_f32': (I, [P, P, C.c_long, F, F, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),

@@ -1,0 +1,131 @@
+"""Fused Adam + model-EMA over flat parameter segments, mirroring train.py:125-149,271-277.
+
+`build_optimizer(model, hyp)` reproduces the reference's three parameter groups (BatchNorm weights / other weights with
+weight decay / biases, train.py:125-140) but stores each group contiguously: parameters, gradients, Adam moments and the EMA
+shadow are flat fp32 buffers, the modules' `.data` / `.grad` are views into them.  One `somi_adam_ema_step_f32` launch per group
+does the Adam update and the EMA update in a single pass (the reference sweeps all 77.5 M parameters twice more).
+The flat gradient buffer is also what the data-parallel all-reduce works on (`ddp.GradBuckets`).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check
+from .ops import _ptr, _stream
+
+
+def reference_param_groups(model):
+    """train.py:125-133: g0 = BatchNorm2d weights, g1 = every other `.weight` Parameter, g2 = every `.bias` Parameter."""
+    g0, g1, g2 = [], [], []
+    for v in model.modules():
+        if hasattr(v, 'bias') and isinstance(v.bias, nn.Parameter):
+            g2.append(v.bias)
+        if isinstance(v, nn.BatchNorm2d):
+            g0.append(v.weight)
+        elif hasattr(v, 'weight') and isinstance(v.weight, nn.Parameter):
+            g1.append(v.weight)
+    return g0, g1, g2
+
+
+class _Flat:
+    def __init__(self, tensors, dev):
+        self.tensors = tensors
+        self.sizes = [t.numel() for t in tensors]
+        n = sum(self.sizes)
+        self.n = n
+        self.n_pad = (n + 3) // 4 * 4
+        self.data = torch.zeros(self.n_pad, device=dev, dtype=torch.float32)
+
+    def views(self):
+        o = 0
+        for t, n in zip(self.tensors, self.sizes):
+            yield t, self.data[o:o + n].view_as(t)
+            o += n
+
+
+class FusedAdamEMA:
+    """Adam with the reference's group layout and an optional fused EMA shadow.  `param_groups[i]['lr']` etc. can be edited
+    between steps exactly like torch.optim (the warm-up of train.py:250-256 does that)."""
+
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.9999, ema=True):
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('FusedAdamEMA runs on the MI355X only (no CPU fallback)')
+        self.model = model
+        g0, g1, g2 = reference_param_groups(model)
+        seen = set()
+        groups = []
+        for plist, wd in ((g0, 0.0), (g1, weight_decay), (g2, 0.0)):
+            plist = [p for p in plist if id(p) not in seen and not seen.add(id(p))]
+            groups.append((plist, wd))
+        self.param_groups, self._flat = [], []
+        for plist, wd in groups:
+            fp, fg = _Flat(plist, dev), _Flat(plist, dev)
+            with torch.no_grad():
+                for (p, v), (_, gv) in zip(fp.views(), fg.views()):
+                    v.copy_(p.data)
+                    p.data = v                                   # the module parameter now lives inside the flat buffer
+                    p.grad = gv                                  # and so does its gradient
+            st = dict(p=fp, g=fg, m=torch.zeros_like(fp.data), v=torch.zeros_like(fp.data),
+                      ema=fp.data.clone() if ema else None)
+            self._flat.append(st)
+            self.param_groups.append(dict(params=plist, lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=wd))
+        # float buffers (BN running statistics) for the EMA of non-parameter state
+        self._bufs = [b for b in model.buffers() if b.dtype.is_floating_point and b.numel() > 0 and 'anchor' not in ''] if ema else []
+        self._buf_ema = [b.detach().clone() for b in self._bufs]
+        self.ema_decay, self.updates, self.steps = ema_decay, 0, 0
+        if hasattr(model, 'invalidate'):
+            model.invalidate()
+
+    @property
+    def flat_grads(self):
+        """The flat gradient buffers (one per group) - what the data-parallel all-reduce operates on."""
+        return [st['g'].data for st in self._flat]
+
+    def zero_grad(self, set_to_none=False):
+        for st in self._flat:
+            st['g'].data.zero_()
+
+    def step(self):
+        self.steps += 1
+        d = None
+        if self._flat[0]['ema'] is not None:
+            self.updates += 1
+            d = self.ema_decay * (1 - math.exp(-self.updates / 2000))          # utils/torch_utils.py:331
+        L = _lib.lib()
+        for grp, st in zip(self.param_groups, self._flat):
+            if st['p'].n == 0:
+                continue
+            check(L.somi_adam_ema_step_f32(_ptr(st['p'].data), _ptr(st['g'].data), _ptr(st['m']), _ptr(st['v']), _ptr(st['ema']), st['p'].n_pad,
+                                           float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']),
+                                           float(grp['weight_decay']), self.steps, float(d if d is not None else 0.0), _stream()), 'adam_ema_step')
+        if d is not None:
+            for b, e in zip(self._bufs, self._buf_ema):
+                check(L.somi_axpby_f32(_ptr(e), _ptr(b.detach().float().contiguous()), e.numel(), float(d), float(1 - d), _stream()), 'ema buffers')
+        if hasattr(self.model, 'invalidate'):
+            self.model.invalidate()
+
+    def ema_state_dict(self):
+        """The EMA weights in state_dict form (what the reference's `ema.ema` module would hold)."""
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        name_of = {id(p): n for n, p in self.model.named_parameters()}
+        for st in self._flat:
+            if st['ema'] is None:
+                continue
+            o = 0
+            for p, n in zip(st['p'].tensors, st['p'].sizes):
+                sd[name_of[id(p)]] = st['ema'][o:o + n].view_as(p).clone()
+                o += n
+        bname = {id(b): n for n, b in self.model.named_buffers()}
+        for b, e in zip(self._bufs, self._buf_ema):
+            sd[bname[id(b)]] = e.clone()
+        return sd
+
+
+def build_optimizer(model, hyp, batch_size, nbs=64, ema=True):
+    """train.py:121-140: weight decay scaled by batch_size*accumulate/nbs, Adam(lr=3e-4, betas=(momentum, 0.999))."""
+    accumulate = max(round(nbs / batch_size), 1)
+    wd = hyp['weight_decay'] * batch_size * accumulate / nbs
+    return FusedAdamEMA(model, lr=3e-4, betas=(hyp['momentum'], 0.999), weight_decay=wd, ema=ema)
