@@ -36,6 +36,34 @@ def synthetic_images(batch, size, seed, device):
     return torch.randint(0, 256, (batch, 3, size, size), generator=g, dtype=torch.uint8).to(device)
 
 
+def cpu_baseline_train(size):
+    """The oracle's training step (forward in train mode + ComputeLoss + backward + torch Adam) on the host cores, batch 2."""
+    from oracle.somi_ref import Model as OracleModel
+    from oracle.somi_ref.loss import ComputeLoss as OracleLoss
+    from oracle.somi_ref.testing import fill_state, synthetic_batch, HYP_VISDRONE
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    m = fill_state(OracleModel(somi_cfg_full()), 1).train()
+    m.hyp = dict(HYP_VISDRONE)
+    crit = OracleLoss(m)
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4, betas=(0.843, 0.999))
+    B = 2
+    imgs, targets = synthetic_batch(B, size, seed=0)
+    x = imgs.float() / 255
+    n, t0 = 0, time.time()
+    while True:
+        loss, _ = crit(m(x), targets)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        n += 1
+        if n >= 2 or time.time() - t0 > 30:
+            break
+    dt = time.time() - t0
+    return {'value': round(B * n / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} x (forward + loss + backward + Adam) of yolov5l-SOMI at batch {B}, {size}x{size}, torch CPU fp32, {cores} threads'}
+
+
 def cpu_baseline(size, seconds_budget=25.0):
     """The oracle (CPU restatement of the reference path, kind 'port') timed on this box's host cores: forward + NMS."""
     from oracle.somi_ref import Model as OracleModel
@@ -83,6 +111,8 @@ def main():
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
+    ap.add_argument('--mode', choices=['train', 'infer'], default='train',
+                    help='train: forward(train)+loss+backward+Adam+EMA step (BASELINE configs[1]); infer: forward+NMS')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -109,12 +139,34 @@ def main():
     model = model.to(dev).eval()
     imgs = synthetic_images(args.batch, args.size, 1000 + rank, dev)
 
-    def step():
+    def infer_step():
         with torch.no_grad():
             z, _ = model(imgs)
             if args.no_nms:
                 return None
             return non_max_suppression(z, 0.001, 0.6, multi_label=True)
+
+    # inference throughput (eval mode) is always measured: a few steps, reported next to the training number
+    for _ in range(2):
+        infer_step()
+    torch.cuda.synchronize()
+    t_inf = time.time()
+    for _ in range(3):
+        infer_step()
+    torch.cuda.synchronize()
+    infer_ips = args.batch * 3 / (time.time() - t_inf)
+
+    if args.mode == 'train':
+        from somi_amd.configs import HYP_VISDRONE, synthetic_batch
+        from somi_amd.train import TrainStep
+        _, targets = synthetic_batch(args.batch, args.size, seed=1000 + rank)
+        targets = targets.to(dev)
+        trainer = TrainStep(model, dict(HYP_VISDRONE), args.batch, dist=dist)
+
+        def step():
+            return trainer.step(imgs, targets)
+    else:
+        step = infer_step
 
     from somi_amd.dist import timed_steps, whole_job_rate
     for _ in range(args.warmup):
@@ -136,15 +188,19 @@ def main():
         all_flops, all_secs = sum(v[1] for v in by.values()), sum(v[2] for v in by.values())
         achieved = flops / secs / 1e12
         out = {
-            'metric': 'images/sec infer (forward+NMS) @640, VisDrone-shaped synthetic, yolov5l-SOMI',
+            'metric': ('images/sec train (forward+loss+backward+Adam+EMA) @640, VisDrone-shaped synthetic, yolov5l-SOMI' if args.mode == 'train'
+                       else 'images/sec infer (forward+NMS) @640, VisDrone-shaped synthetic, yolov5l-SOMI'),
             'value': round(whole_job_rate(args.batch, args.steps, world, dt), 2), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'yolov5l-SOMI inference step: uint8 ingest + forward + decode'
-                                   f'{"" if args.no_nms else " + NMS(conf 0.001, iou 0.6, multi_label)"}, '
+            'config': {'workload': (f'yolov5l-SOMI training step: uint8 ingest + forward (batch-stat BN) + ComputeLoss + backward + '
+                                    f'{"gradient all-reduce + " if world > 1 else ""}Adam + EMA, ' if args.mode == 'train' else
+                                    f'yolov5l-SOMI inference step: uint8 ingest + forward + decode'
+                                    f'{"" if args.no_nms else " + NMS(conf 0.001, iou 0.6, multi_label)"}, ') +
                                    f'{args.size}x{args.size}, batch {args.batch}/GPU (BASELINE configs[1] shape)',
                        'batch_per_gpu': args.batch, 'imgsz': args.size, 'params': 77537610,
-                       'parallelism': f'replicas x{world}'},
+                       'parallelism': (f'dp{world}' if args.mode == 'train' else f'replicas x{world}')},
+            'infer_images_per_s_per_gpu': round(infer_ips, 2),
             'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                          'launches': cnt, 'avg_launch_us': round(secs / cnt * 1e6, 2),
@@ -154,7 +210,7 @@ def main():
         }
         out['roofline']['traffic'] = pmc_traffic(name)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.size)
+            out['cpu_baseline'] = cpu_baseline_train(args.size) if args.mode == 'train' else cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -57,3 +57,45 @@ def test_shard_range_covers_everything():
                 lo, hi = shard_range(n, r, w)
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, 'yolo-somi_amd'))
+    from somi_amd.ddp import GradBuckets
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # two "parameter groups"; layers own increasing ranges: layer 0 -> [0,300), 1 -> [300,700), 2 -> [700,1000) of buffer 0
+    g0 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    g1 = torch.ones(10) * (rank + 1)
+    offs = [{0: 0, 1: 300, 2: 700}, {0: 0, 2: 4}]
+    gb = GradBuckets([g0, g1], offs, dist=dist, bucket_bytes=256 * 4, use_streams=False)
+    order = []
+    for layer in (2, 1, 0):                                  # the reverse walk
+        gb.layer_done(layer)
+        order.append(len(gb.launched))
+    gb.finish()
+    q.put((rank, order, list(gb.launched), g0.clone(), g1.clone()))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_all_reduce_sum_two_ranks():
+    """DDP semantics of train.py:208-209,266-267 (mean x WORLD_SIZE == SUM) with buckets launched as layers finish."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, order, launched, g0, g1 in res:
+        assert torch.equal(g0, torch.arange(1000, dtype=torch.float32) * 3)      # (1 + 2) x the base gradient on every rank
+        assert torch.equal(g1, torch.ones(10) * 3)
+        # buffer 0 buckets from the end: [744,1000) after layer 2; [488,744) after layer 1 (>= 300); [232,488) and [0,232) after layer 0
+        b0 = [(s, e) for bi, s, e in launched if bi == 0]
+        assert b0 == [(744, 1000), (488, 744), (232, 488), (0, 232)]
+        assert order[0] >= 1 and order[1] > order[0] and order[2] > order[1]      # something new is launched after every layer
+        covered = sorted(b0)
+        assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1)) and covered[-1][1] == 1000

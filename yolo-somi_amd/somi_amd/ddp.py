@@ -1,0 +1,99 @@
+"""Data-parallel gradient exchange for the training path: one process per GPU, RCCL over xGMI through
+torch.distributed (backend "nccl" on ROCm), the reference's DDP semantics without the DDP wrapper.
+
+Reference (train.py:208-209,266-267): DDP averages gradients over ranks and the loss is multiplied by WORLD_SIZE, i.e. every
+rank ends up with the SUM of the per-rank gradients.  Here the gradients already live in the optimizer's flat per-group buffers
+(optim.FusedAdamEMA.flat_grads); they are all-reduced (SUM) in buckets cut from the END of each buffer, because the reverse
+layer walk finalises gradients from the last layer to the first.  A bucket is launched on a side HIP stream as soon as every
+layer that owns a slice of it has finished its backward, so the exchange overlaps the rest of the backward pass; the optimizer
+step waits for the side stream.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): ~48 MB buckets keep each RCCL call large
+enough to use all links while leaving several buckets to overlap (310 MB of fp32 gradients -> 7 buckets).
+"""
+import torch
+
+
+class GradBuckets:
+    def __init__(self, flat_grads, layer_start_offsets, dist=None, bucket_bytes=48 << 20, use_streams=True):
+        """flat_grads: list of 1-D gradient buffers (one per parameter group).
+        layer_start_offsets: list (per buffer) of dicts layer_index -> first element offset of that layer's parameters in the
+        buffer (layers own contiguous, increasing ranges).  dist: torch.distributed module or None (single process)."""
+        self.flat, self.dist = flat_grads, dist
+        self.use_streams = use_streams and flat_grads[0].is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.use_streams else None
+        self.handles = []
+        self.buckets = []                                        # per buffer: list of (start, end) from the end backwards
+        per = max(bucket_bytes // 4, 1)
+        for buf in flat_grads:
+            n, cuts = buf.numel(), []
+            end = n
+            while end > 0:
+                start = max(end - per, 0)
+                cuts.append((start, end))
+                end = start
+            self.buckets.append(cuts)
+        self.layer_off = layer_start_offsets
+        self.next = [0] * len(flat_grads)                        # next bucket to launch per buffer
+        self.launched = []                                       # (buffer index, start, end) in launch order - for tests
+
+    def reset(self):
+        self.next = [0] * len(self.flat)
+        self.handles, self.launched = [], []
+
+    def _launch(self, bi, start, end):
+        self.launched.append((bi, start, end))
+        if self.dist is None or self.dist.get_world_size() == 1:
+            return
+        view = self.flat[bi][start:end]
+        if self.use_streams:
+            ev = torch.cuda.Event()
+            ev.record()                                           # gradients of this bucket are final on the compute stream
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def layer_done(self, layer_index):
+        """Call after layer `layer_index` (and every later layer) has accumulated its parameter gradients."""
+        for bi, cuts in enumerate(self.buckets):
+            final_from = self.layer_off[bi].get(layer_index)
+            if final_from is None:
+                continue
+            while self.next[bi] < len(cuts) and cuts[self.next[bi]][0] >= final_from:
+                self._launch(bi, *cuts[self.next[bi]])
+                self.next[bi] += 1
+
+    def finish(self):
+        """Launch whatever is left (layer 0 side) and make the compute stream wait for the exchange."""
+        for bi, cuts in enumerate(self.buckets):
+            while self.next[bi] < len(cuts):
+                self._launch(bi, *cuts[self.next[bi]])
+                self.next[bi] += 1
+        for h in self.handles:
+            h.wait()
+        if self.use_streams:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.handles = []
+
+
+def layer_offsets(model, optimizer):
+    """For every flat group buffer: layer index -> smallest offset of that layer's (and all later layers') parameters.  Parameters are
+    laid out in module order, so 'layer i and everything after it' is the tail of the buffer starting at that offset."""
+    owner = {}
+    for m in model.model:
+        for p in m.parameters():
+            owner[id(p)] = m.i
+    res = []
+    for st in optimizer._flat:
+        first = {}
+        for p, o in zip(st['p'].tensors, st['p'].offsets):
+            li = owner.get(id(p))
+            if li is not None:
+                first[li] = min(first.get(li, o), o)
+        # tail property: offset for layer i = min over layers >= i
+        run, out = None, {}
+        for li in sorted(first, reverse=True):
+            run = first[li] if run is None else min(run, first[li])
+            out[li] = run
+        res.append(out)
+    return res

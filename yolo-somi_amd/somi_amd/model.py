@@ -188,8 +188,11 @@ class Model(nn.Module):
                 g = grads[src]
                 ops.add_(g.t, g.coff, d.t, d.coff, g.t.shape[3] - g.coff)
         det = self.model[-1]
+        hook = self.__dict__.get('_grad_hook')                   # called with a layer index once that layer's gradients are final
         for src, d in zip(self._sources(det), det.backward(draws)):
             give(src, d)
+        if hook:
+            hook(det.i)
         for m in reversed(list(self.model)[:-1]):
             g = grads.pop(m.i, None)
             if g is None:
@@ -202,6 +205,8 @@ class Model(nn.Module):
                 m.backward(g, need_dx=False)
             else:
                 give(srcs[0], m.backward(g))
+            if hook:
+                hook(m.i)
 
     def _forward_once(self, x):
         """models/yolo.py:1269-1290: walk the layers with the skip list."""

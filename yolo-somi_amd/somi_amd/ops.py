@@ -245,10 +245,17 @@ def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cou
     d.kh, d.kw, d.stride, d.pad, d.dil, d.per_sample_w = kh, kw, stride, pad, 1, int(per_sample_w)
     if w_dgrad.numel() != (B if per_sample_w else 1) * cin * kh * kw * cout:
         raise RuntimeError('dgrad weight has the wrong number of elements')
+    prof = PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().somi_conv2d_dgrad_nhwc_f32(C.byref(d), _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(w_dgrad)), _ptr(_f32c(out)),
                                                 out.shape[3], dx_coff, _ptr(accumulate),
                                                 accumulate.shape[3] if accumulate is not None else 0, acc_coff, _stream()),
           'conv2d_dgrad_nhwc')
+    if prof:
+        e1.record()
+        PROFILE.append(('conv_igemm_f32_kernel<dgrad>', 2.0 * B * Ho * Wo * cout * cin * kh * kw, e0, e1, (B, H, W, cin, cout, kh, stride, 2)))
     return out
 
 
@@ -268,8 +275,15 @@ def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cou
     L = _lib.lib()
     nbytes = L.somi_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
+    prof = PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.somi_conv2d_wgrad_nhwc_f32(C.byref(d), _ptr(_f32c(x)), x_cs, x_coff, _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(out)),
                                        _ptr(accumulate), _ptr(ws), nbytes, _stream()), 'conv2d_wgrad_nhwc')
+    if prof:
+        e1.record()
+        PROFILE.append(('conv_wgrad_f32_kernel', 2.0 * B * Ho * Wo * cout * cin * kh * kw, e0, e1, (B, H, W, cin, cout, kh, stride, 3)))
     return out
 
 

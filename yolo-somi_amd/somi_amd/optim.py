@@ -33,16 +33,16 @@ class _Flat:
     def __init__(self, tensors, dev):
         self.tensors = tensors
         self.sizes = [t.numel() for t in tensors]
-        n = sum(self.sizes)
-        self.n = n
-        self.n_pad = (n + 3) // 4 * 4
-        self.data = torch.zeros(self.n_pad, device=dev, dtype=torch.float32)
+        self.offsets, o = [], 0
+        for n in self.sizes:                                      # every tensor starts 16 B aligned (kernels take float4)
+            self.offsets.append(o)
+            o += (n + 3) // 4 * 4
+        self.n = self.n_pad = o
+        self.data = torch.zeros(max(o, 4), device=dev, dtype=torch.float32)
 
     def views(self):
-        o = 0
-        for t, n in zip(self.tensors, self.sizes):
+        for t, n, o in zip(self.tensors, self.sizes, self.offsets):
             yield t, self.data[o:o + n].view_as(t)
-            o += n
 
 
 class FusedAdamEMA:
@@ -114,10 +114,8 @@ class FusedAdamEMA:
         for st in self._flat:
             if st['ema'] is None:
                 continue
-            o = 0
-            for p, n in zip(st['p'].tensors, st['p'].sizes):
+            for p, n, o in zip(st['p'].tensors, st['p'].sizes, st['p'].offsets):
                 sd[name_of[id(p)]] = st['ema'][o:o + n].view_as(p).clone()
-                o += n
         bname = {id(b): n for n, b in self.model.named_buffers()}
         for b, e in zip(self._bufs, self._buf_ema):
             sd[bname[id(b)]] = e.clone()
