@@ -256,7 +256,7 @@ def test_whole_model_train_step_gradients(odconv):
         assert p.grad is not None, n
         err = (p.grad.cpu().double() - q.grad.double()).abs().max().item()
         scale = q.grad.double().abs().max().item() + 1e-9
-        if err > 2e-3 * scale + 1e-7:
+        if err > 2e-3 * scale + 2e-6:       # atol: sums of many cancelling fp32 terms (e.g. the 7x7 attention bias) are order-sensitive
             bad.append((n, err, scale))
     assert not bad, bad[:8]
     for (n, p), (_, q) in zip(mine.named_buffers(), ref.named_buffers()):

@@ -79,27 +79,30 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_data_kernel(const float 
         *reinterpret_cast<float2 *>(dstats + p * 2) = make_float2(a0, a1);
     }
 }
-// weight / bias gradient: thread j < k*k*2 owns one weight and walks the workgroup's pixel chunk; thread k*k*2 owns the bias
-__global__ __launch_bounds__(128) void spatial_attn_bwd_weight_kernel(const float *__restrict__ dlogit, const float *__restrict__ stats,
+// weight / bias gradient: workgroup (chunk, j) reduces weight j (j == k*k*2: the bias) over one chunk of pixels, lanes over pixels
+__global__ __launch_bounds__(256) void spatial_attn_bwd_weight_kernel(const float *__restrict__ dlogit, const float *__restrict__ stats,
                                                                       float *__restrict__ part, int B, int H, int W, int k, int chunk) {
+    __shared__ float red[4];
     const long npix = (long)B * H * W;
     const int nw = k * k * 2, pad = k >> 1;
-    const int j = threadIdx.x;
-    if (j > nw) return;
+    const int j = blockIdx.y;
     const long p0 = (long)blockIdx.x * chunk, p1 = min(p0 + chunk, npix);
     float acc = 0.f;
     if (j == nw) {
-        for (long p = p0; p < p1; ++p) acc += dlogit[p];
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) acc += dlogit[p];
     } else {
         const int ch = j & 1, rq = j >> 1, r = rq / k, q = rq % k;
-        for (long p = p0; p < p1; ++p) {
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) {
             const int wv = (int)(p % W), hv = (int)((p / W) % H);
             const int hi = hv + r - pad, wi = wv + q - pad;
             if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
                 acc += dlogit[p] * stats[(p + (long)(r - pad) * W + (q - pad)) * 2 + ch];
         }
     }
-    part[(long)blockIdx.x * (nw + 1) + j] = acc;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)blockIdx.x * (nw + 1) + j] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(128) void spatial_attn_bwd_weight_final(const float *__restrict__ part, int nblk, int nw, float *dw, float *dbias) {
     const int j = threadIdx.x;
@@ -327,8 +330,8 @@ extern "C" int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)B * H * W;
     hipLaunchKernelGGL(spatial_attn_bwd_data_kernel, dim3(ew_grid(npix)), dim3(256), 0, s, dlogit, w, dstats, B, H, W, k);
-    const int chunk = 1024, nblk = (int)((npix + chunk - 1) / chunk), nw = k * k * 2;
-    hipLaunchKernelGGL(spatial_attn_bwd_weight_kernel, dim3(nblk), dim3(128), 0, s, dlogit, stats, workspace, B, H, W, k, chunk);
+    const int chunk = 1024 * 16, nblk = (int)((npix + chunk - 1) / chunk), nw = k * k * 2;
+    hipLaunchKernelGGL(spatial_attn_bwd_weight_kernel, dim3(nblk, nw + 1), dim3(256), 0, s, dlogit, stats, workspace, B, H, W, k, chunk);
     hipLaunchKernelGGL(spatial_attn_bwd_weight_final, dim3(1), dim3(128), 0, s, workspace, nblk, nw, dw_accumulate, dbias_accumulate);
     return launch_status("somi_spatial_attn_bwd_f32");
 }
@@ -494,10 +497,12 @@ __global__ __launch_bounds__(256) void bifpn_bwd_up_kernel(const float *__restri
 }
 // dw_k += dwn_k / S - (sum_i dwn_i w_i / S^2) * swish'(w_k),  S = sum swish(w) + eps   (models/common.py:3696)
 __global__ void bifpn_bwd_weight_kernel(const float *__restrict__ part, int nblk, const float *__restrict__ w, int n_in, float eps, float *dw) {
-    if (threadIdx.x != 0) return;
     double dwn[3] = {0, 0, 0};
-    for (int i = 0; i < nblk; ++i)
+    for (int i = threadIdx.x; i < nblk; i += 64)
         for (int k = 0; k < n_in; ++k) dwn[k] += part[(long)i * 3 + k];
+    for (int k = 0; k < 3; ++k)
+        for (int o = 32; o > 0; o >>= 1) dwn[k] += __shfl_xor(dwn[k], o);
+    if (threadIdx.x != 0) return;
     double S = eps, T = 0.0;
     for (int k = 0; k < n_in; ++k) { const double sg = 1.0 / (1.0 + exp(-(double)w[k])); S += w[k] * sg; }
     for (int k = 0; k < n_in; ++k) T += dwn[k] * w[k];

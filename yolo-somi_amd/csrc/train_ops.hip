@@ -14,7 +14,12 @@ namespace somi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RED_CHUNK = 512;       // pixels per stage-1 workgroup
+// pixels per stage-1 workgroup: about 1024 chunks for large tensors (stage 2 walks the chunks), never fewer than 128 pixels
+static inline int red_chunk(long npix) {
+    long c = (npix + 1023) / 1024;
+    c = (c + 63) / 64 * 64;
+    return (int)(c < 128 ? 128 : (c > 4096 ? 4096 : c));
+}
 
 __device__ __forceinline__ float act_fwd(float u, int act) { return apply_act_rt(u, act); }
 __device__ __forceinline__ float act_grad(float u, int act) {
@@ -30,7 +35,7 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 // ---- generic two-stage per-channel reduction over pixels: each workgroup reduces RED_CHUNK pixels for all channels.
 // F(p, c4) returns up to two float4 terms for pixel p, channel quad c4.
 template <typename F>
-__device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, float *part2, int nchunk, F f) {
+__device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, float *part2, int RED_CHUNK, F f) {
     __shared__ f32x4 l1[256], l2[256];
     const int chunk = blockIdx.x;
     const int C4 = C >> 2;
@@ -55,10 +60,27 @@ __device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, fl
     }
 }
 
+// stage-2 helper: 256 threads = 64 channels x 4 chunk groups; returns (for group 0 lanes) the sums over all chunks of p1 / p2
+__device__ __forceinline__ bool stage2_sums(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C, int &c, double &s1, double &s2) {
+    __shared__ double l1[256], l2[256];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    c = blockIdx.x * 64 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = grp; k < nchunk; k += 4) { a += p1[(long)k * C + c]; if (p2) b += p2[(long)k * C + c]; }
+    l1[threadIdx.x] = a;
+    l2[threadIdx.x] = b;
+    __syncthreads();
+    if (grp != 0 || c >= C) return false;
+    s1 = (l1[cl] + l1[64 + cl]) + (l1[128 + cl] + l1[192 + cl]);
+    s2 = (l2[cl] + l2[64 + cl]) + (l2[128 + cl] + l2[192 + cl]);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ BN statistics
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float *__restrict__ x, int cs, int coff, long npix, int C,
-                                                       float *__restrict__ p1, float *__restrict__ p2, int nchunk) {
-    chunk_reduce2(npix, C, p1, p2, nchunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
+                                                       float *__restrict__ p1, float *__restrict__ p2, int chunk) {
+    chunk_reduce2(npix, C, p1, p2, chunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * cs + coff + c);
         s1 += v;
         s2 += v * v;
@@ -70,10 +92,9 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const float *__restrict__
                                                        const float *__restrict__ beta, float *__restrict__ mean, float *__restrict__ rstd,
                                                        float *__restrict__ scale, float *__restrict__ shift, float *running_mean,
                                                        float *running_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) { s += p1[(long)k * C + c]; q += p2[(long)k * C + c]; }
+    int c;
+    double s, q;
+    if (!stage2_sums(p1, p2, nchunk, C, c, s, q)) return;
     const double m = s / (double)npix;
     double var = q / (double)npix - m * m;
     if (var < 0.0) var = 0.0;
@@ -121,8 +142,8 @@ __global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__res
 __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
                                                          int x_cs, int x_coff, const float *__restrict__ scale,
                                                          const float *__restrict__ shift, int act, int order, long npix, int C,
-                                                         float *__restrict__ p1, float *__restrict__ p2, int nchunk) {
-    chunk_reduce2(npix, C, p1, p2, nchunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
+                                                         float *__restrict__ p1, float *__restrict__ p2, int chunk) {
+    chunk_reduce2(npix, C, p1, p2, chunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
         const f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
         const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
         f32x4 d, w;
@@ -147,10 +168,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict
                                                          long npix, const float *__restrict__ mean, const float *__restrict__ rstd,
                                                          const float *__restrict__ scale, int batch_stats, float *__restrict__ coefA,
                                                          float *__restrict__ coefB, float *__restrict__ coefC, float *dgamma, float *dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) { s1 += p1[(long)k * C + c]; s2 += p2[(long)k * C + c]; }
+    int c;
+    double s1, s2;
+    if (!stage2_sums(p1, p2, nchunk, C, c, s1, s2)) return;
     const double m = mean[c], rs = rstd[c], sc = scale[c];
     const double D = rs * (s2 - m * s1);
     coefA[c] = (float)sc;
@@ -195,16 +215,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float *__restrict_
 
 // per-channel sum over pixels of a tensor (bias gradients): out[c] += sum_p x[p,c]
 __global__ __launch_bounds__(256) void chan_sum_stage1(const float *__restrict__ x, int cs, int coff, long npix, int C, float *__restrict__ p1,
-                                                       float *__restrict__ p2, int nchunk) {
-    chunk_reduce2(npix, C, p1, p2, nchunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
+                                                       float *__restrict__ p2, int chunk) {
+    chunk_reduce2(npix, C, p1, p2, chunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
         s1 += *reinterpret_cast<const f32x4 *>(x + p * cs + coff + c);
     });
 }
 __global__ __launch_bounds__(256) void chan_sum_stage2(const float *__restrict__ p1, int nchunk, int C, float *out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < nchunk; ++k) s += p1[(long)k * C + c];
+    int c;
+    double s, unused;
+    if (!stage2_sums(p1, nullptr, nchunk, C, c, s, unused)) return;
     out[c] += (float)s;
 }
 
@@ -231,7 +250,7 @@ static inline bool slice_ok(const void *p, int cs, int coff, int C) { return p &
 
 using namespace somi;
 
-extern "C" int somi_red_nchunk(long npix) { return (int)((npix + RED_CHUNK - 1) / RED_CHUNK); }
+extern "C" int somi_red_nchunk(long npix) { const int c = red_chunk(npix); return (int)((npix + c - 1) / c); }
 
 extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float eps, float momentum,
                                       const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
@@ -242,8 +261,8 @@ extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long
     const int nchunk = somi_red_nchunk(npix);
     float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, p1, p2, nchunk);
-    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 256)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
+    hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, p1, p2, red_chunk(npix));
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
                        scale, shift, running_mean, running_var);
     return launch_status("somi_bn_stats_nhwc_f32");
 }
@@ -268,8 +287,8 @@ extern "C" int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_
     float *p1 = workspace, *p2 = p1 + (size_t)nchunk * C, *cA = p2 + (size_t)nchunk * C, *cB = cA + cpad, *cC = cB + cpad;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, act, order, npix, C,
-                       p1, p2, nchunk);
-    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, 256)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
+                       p1, p2, red_chunk(npix));
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, 64)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
                        dgamma, dbeta);
     hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, cA, cB,
                        cC, act, order, dx, dx_cs, dx_coff, npix, C);
@@ -281,8 +300,8 @@ extern "C" int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long
     SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && out_accumulate && workspace && npix > 0 && C % 4 == 0, SOMI_EINVAL, "chan sum: bad arguments");
     const int nchunk = somi_red_nchunk(npix);
     float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
-    hipLaunchKernelGGL(chan_sum_stage1, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, npix, C, p1, p2, nchunk);
-    hipLaunchKernelGGL(chan_sum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, p1, nchunk, C, out_accumulate);
+    hipLaunchKernelGGL(chan_sum_stage1, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, npix, C, p1, p2, red_chunk(npix));
+    hipLaunchKernelGGL(chan_sum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, p1, nchunk, C, out_accumulate);
     return launch_status("somi_chan_sum_nhwc_f32");
 }
 
