@@ -221,7 +221,11 @@ def test_detect_decode():
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k,s', [(2, 16, 16, 64, 128, 3, 1), (2, 17, 13, 32, 64, 3, 2), (3, 20, 20, 128, 256, 3, 2),
-                                                (2, 12, 12, 96, 64, 1, 1), (2, 9, 11, 20, 36, 3, 1), (2, 10, 10, 64, 32, 3, 2)])
+                                                (2, 12, 12, 96, 64, 1, 1), (2, 9, 11, 20, 36, 3, 1), (2, 10, 10, 64, 32, 3, 2),
+                                                # stride parity classes: one with no tap at all (k=1), 3x3 taps per class
+                                                # (k=6), stride 3, and a ragged 64-row class tile
+                                                (2, 9, 12, 16, 32, 1, 2), (2, 14, 14, 16, 32, 6, 2), (2, 11, 13, 8, 32, 5, 3),
+                                                (5, 23, 19, 36, 96, 3, 2)])
 def test_conv_dgrad(B, H, W, Cin, Cout, k, s):
     """dx of F.conv2d from the MFMA implicit-GEMM kernel in data-gradient geometry, against torch autograd on the CPU."""
     from somi_amd import ops

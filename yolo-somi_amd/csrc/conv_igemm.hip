@@ -45,6 +45,7 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes, chan_bytes, pix_bytes;
     int stagger;  // s_sleep units (64 clk) for every second generation of workgroups
     int dgrad;    // 1: data-gradient geometry (rows = forward-input pixels, source = dy, taps walk backwards, stride parity)
+    int cls;      // dgrad on the FAST path: grid.y = stride^2 parity classes, each walks only the taps that reach it
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -91,13 +92,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
     int a_hi0[A_ROWS], a_wi0[A_ROWS], a_off[A_ROWS], a_pixi[A_ROWS], a_chn[A_ROWS], a_par[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) a_par[i] = 0;
-    const int HoWo = d.Ho * d.Wo;
+    // dgrad parity class (FAST path): rows are the pixels with (h+pad)%s == ph, (w+pad)%s == pw, i.e. h = h0 + s*hc, and
+    // only the taps r = ph + s*i, q = pw + s*j reach them - a stride-2 3x3 layer does 9/4 taps per pixel instead of 9.
+    const bool cls = FAST && a.cls;
+    const int ph = cls ? (int)blockIdx.y / d.stride : 0, pw = cls ? (int)blockIdx.y % d.stride : 0;
+    const int h0 = cls ? ((ph - d.pad) % d.stride + d.stride) % d.stride : 0;
+    const int w0 = cls ? ((pw - d.pad) % d.stride + d.stride) % d.stride : 0;
+    const int cstep = cls ? d.stride : 1;
+    const int Hc = cls ? (d.Ho - h0 + cstep - 1) / cstep : d.Ho, Wc = cls ? (d.Wo - w0 + cstep - 1) / cstep : d.Wo;
+    const int nr_c = cls ? (d.kh - ph + cstep - 1) / cstep : d.kh, nq_c = cls ? (d.kw - pw + cstep - 1) / cstep : d.kw;
+    const int HoWo = Hc * Wc;
+    const int Mrows = cls ? (d.per_sample_w ? HoWo : d.B * HoWo) : a.M;
+    if (m0 >= Mrows) return;                                              // smaller class than the grid was sized for
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
         const int m = m0 + row0 + 32 * i;
-        if (m < a.M) {
+        if (m < Mrows) {
             const int b = m / HoWo + bz, rem = m % HoWo;
-            const int ho = rem / d.Wo, wo = rem % d.Wo;
+            const int ho = h0 + (rem / Wc) * cstep, wo = w0 + (rem % Wc) * cstep;
             if (!a.dgrad) {
                 a_hi0[i] = ho * d.stride - d.pad;
                 a_wi0[i] = wo * d.stride - d.pad;
@@ -123,16 +135,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
     // FAST path state: per-row tap-validity masks and byte offsets with the thread's column folded in
     unsigned a_mask[A_ROWS], a_offb[A_ROWS], a_pixb[A_ROWS], a_chnb[A_ROWS];
     if constexpr (FAST) {
-        const int ntap = d.kh * d.kw;
+        const int ntap = nr_c * nq_c;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             unsigned mk = 0;
             for (int t = 0; t < ntap; ++t) {
-                const int tr = t / d.kw, tq = t % d.kw;
-                const int hh = a_hi0[i] + (a.dgrad ? -(tr / d.stride) : tr * d.dil);
-                const int ww = a_wi0[i] + (a.dgrad ? -(tq / d.stride) : tq * d.dil);
-                const bool par = !a.dgrad || ((tr % d.stride) == (a_par[i] & 255) && (tq % d.stride) == (a_par[i] >> 8));
-                mk |= (par && (unsigned)hh < (unsigned)d.H && (unsigned)ww < (unsigned)d.W) ? (1u << t) : 0u;
+                const int tr = t / nq_c, tq = t % nq_c;                  // class-local tap index (dgrad: r = ph + s*tr)
+                const int hh = a_hi0[i] + (cls ? -tr : tr * d.dil);
+                const int ww = a_wi0[i] + (cls ? -tq : tq * d.dil);
+                mk |= ((unsigned)hh < (unsigned)d.H && (unsigned)ww < (unsigned)d.W) ? (1u << t) : 0u;
             }
             a_mask[i] = mk;
             a_offb[i] = (unsigned)(a_off[i] + kc) * 4u;
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
     f32x4 ra[A_ROWS], rb[B_ROWS];
     auto fetch_tile = [&](int kt_next) {
         if constexpr (FAST) {
-            const int dpix = a.dgrad ? -((r_u / d.stride) * d.W + q_u / d.stride) : (r_u * d.W + q_u) * d.dil;
+            const int dpix = cls ? -(r_u * d.W + q_u) : (r_u * d.W + q_u) * d.dil;
             const unsigned sd = (unsigned)(dpix * d.x_cs + c0_u) * 4u, bit = 1u << tp_u;
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
@@ -161,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
                 }
                 ra[i] = v;
             }
-            const unsigned ko = (unsigned)kt_next * (BK * 4u);
+            const unsigned ko = cls ? (unsigned)(((ph + cstep * r_u) * d.kw + pw + cstep * q_u) * d.Cin + c0_u) * 4u
+                                    : (unsigned)kt_next * (BK * 4u);
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_off[i] + ko);
             return;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
             if (c0_u == d.Cin) {
                 c0_u = 0;
                 ++tp_u;
-                if (++q_u == d.kw) { q_u = 0; ++r_u; }
+                if (++q_u == nq_c) { q_u = 0; ++r_u; }
             }
             return;
         }
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[jn][i][e] = 0.f;
 
-    const int nkt = (a.K + BK - 1) / BK;
+    const int nkt = cls ? nr_c * nq_c * (d.Cin / BK) : (a.K + BK - 1) / BK;      // 0 for a class no tap reaches (k=1, s=2)
     const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
     const int aw_off = (wm * WM) * LDS_LD + frag_off;            // activation rows of this wave
     const int bw_off = (BM + wn * WN) * LDS_LD + frag_off;       // weight rows of this wave
@@ -247,8 +259,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
     if (a.stagger && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(1), __builtin_amdgcn_s_sleep(1);
     if (a.stagger && ((blockIdx.x >> 8) & 1))
         for (int z = 0; z < a.stagger; ++z) __builtin_amdgcn_s_sleep(16);
-    fetch_tile(0);
-    store_tile(lds);
+    if (nkt > 0) {
+        fetch_tile(0);
+        store_tile(lds);
+    }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const float *cur = lds + (kt & 1) * TILE;
@@ -290,9 +304,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
     const int mw = m0 + wm * WM, nw = n0 + wn * WN;
     for (int idx = lane; idx < WM * NQ; idx += 64) {
         const int ml = idx / NQ, n = nw + (idx % NQ) * 4, m = mw + ml;
-        if (m >= a.M || n >= d.Cout) continue;
+        if (m >= Mrows || n >= d.Cout) continue;
         f32x4 v = *reinterpret_cast<const f32x4 *>(&stage[ml * SLD + (idx % NQ) * 4]);
-        const size_t row = row_base + m;
+        size_t row = row_base + m;
+        if (cls && cstep > 1) {
+            const int rem = m % HoWo;
+            row = ((size_t)(m / HoWo + bz) * d.Ho + h0 + (rem / Wc) * cstep) * d.Wo + w0 + (rem % Wc) * cstep;
+        }
         float *yrow = d.y + row * d.y_cs + d.y_coff;
         const float *rrow = d.residual ? d.residual + row * d.res_cs + d.res_coff : nullptr;
         if (n + 3 < d.Cout) {
@@ -323,11 +341,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch(const ConvArgs &a, hipStream_t s) {
     ConvArgs args = a;
-    args.tiles_m = cdiv(a.M, BM);
-    args.tiles_n = cdiv(a.d.Cout, BN);
-    const dim3 grid(args.tiles_m * args.tiles_n, 1, a.d.per_sample_w ? a.d.B : 1);
     const bool mod = a.d.a_chan_scale || a.d.a_pix_scale;
     const bool fast = a.d.Cin % BK == 0 && a.d.kh * a.d.kw <= 32 && (size_t)a.K * 4 < (1u << 27);
+    args.cls = a.dgrad && fast;
+    const int st = a.d.stride, ncls = args.cls ? st * st : 1;
+    const int m_cls = args.cls ? (a.d.per_sample_w ? 1 : a.d.B) * cdiv(a.d.Ho, st) * cdiv(a.d.Wo, st) : a.M;   // largest class
+    args.tiles_m = cdiv(m_cls, BM);
+    args.tiles_n = cdiv(a.d.Cout, BN);
+    const dim3 grid(args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
     if (mod && fast)
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(256), 0, s, args);
     else if (mod)
@@ -394,6 +415,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
     static const int stagger_env = getenv("SOMI_CONV_STAGGER") ? atoi(getenv("SOMI_CONV_STAGGER")) : 0;
     a.stagger = stagger_env;
     a.dgrad = dgrad;
+    a.cls = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (pick_tile(d, a.M)) {
         case 0: return launch<128, 128, 2, 2>(a, s);

@@ -1,9 +1,11 @@
 // Weight gradient of the NHWC convolution on the fp32 matrix cores of gfx950 (autograd of F.conv2d w.r.t. its weight,
 // train.py:270 `scaler.scale(loss).backward()`):
 //   dW[co][(r*kw+q)*Cin + ci] = sum over pixels (b,ho,wo) of dy[b,ho,wo,co] * x[b, ho*s-p+r, wo*s-p+q, ci]
-// GEMM view: rows = co, columns = (tap, ci), reduction = pixels.  A workgroup (256 threads, 4 waves) owns a 128 (co) x BN (ci,
-// one tap) tile and a contiguous slice of the pixel range (split-K); every 32-pixel K-tile it stages dy[32][128] and the
-// tap-shifted x[32][BN] rows (16 B buffer loads, padding by the hardware range check) into a double-buffered LDS image
+// GEMM view: rows = co, columns = k = (tap, ci) flattened exactly as the packed weight, reduction = pixels.  A workgroup (256
+// threads, 4 waves) owns a BM (co) x BN (k) tile and a contiguous slice of the pixel range (split-K); a column tile may span
+// several taps (each thread's 16 B column quad has its own fixed tap), so narrow layers (Cin 4 / 64 / 192) still fill whole
+// tiles.  Every 32-pixel K-tile it stages dy[32][BM] and the tap-shifted x[32][BN] rows (16 B buffer loads, padding by the
+// hardware range check) into a double-buffered LDS image
 // [pixel][channel] and feeds v_mfma_f32_32x32x2_f32 with one ds_read_b32 per operand value (lanes = consecutive channels,
 // conflict-free).  Partial tiles of the splits go to a workspace and are summed in a fixed order (deterministic), optionally
 // on top of an existing gradient.
@@ -24,7 +26,8 @@ struct WgradArgs {
     float *out;                              // [splits][n_sets][Cout][K]  (workspace) or dW itself when splits == 1
     int B, H, W, Cin, x_cs, x_coff, Ho, Wo, Cout, dy_cs, dy_coff, kh, kw, stride, pad;
     int K;                                   // kh*kw*Cin
-    int tiles_co, tiles_ci, splits, pix_per_split, npix;   // npix = pixels per weight set (B*Ho*Wo, or Ho*Wo per sample)
+    int tiles_co, tiles_k, splits, pix_per_split, npix;    // npix = pixels per weight set (B*Ho*Wo, or Ho*Wo per sample)
+    int bm, bn;                              // tile variant
     int per_sample;
     unsigned x_bytes, dy_bytes;
 };
@@ -33,10 +36,10 @@ __device__ __forceinline__ f32x4 wbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned o
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
-template <int BN>   // BN in {128, 64, 32}: ci columns per tile; co rows are always 128
+template <int BM, int BN>   // co rows x k columns per tile: 128 x {128,64,32} or 64 x {128,64}
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs a) {
-    constexpr int BM = 128;
-    constexpr int WAVES_N = BN == 128 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int WAVES_N = BM == 64 ? 2 : (BN == 128 ? 2 : 1), WAVES_M = 4 / WAVES_N;
+    static_assert(BM / WAVES_M >= 32 && BN / WAVES_N >= 32, "bad wgrad tiling");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_LD = BM, B_LD = BN;
     constexpr int TILE = WG_PIX * (A_LD + B_LD);
@@ -45,15 +48,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int ntaps = a.kh * a.kw;
-    // tile decode: blockIdx.x = ((tile_co * ntaps + tap) * tiles_ci + tile_ci), blockIdx.y = split, blockIdx.z = weight set
-    int t = blockIdx.x;
-    const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
-    const int tap = t % ntaps;
-    const int tile_co = t / ntaps;
+    // tile decode: blockIdx.x = tile_co * tiles_k + tile_k, blockIdx.y = split, blockIdx.z = weight set
+    const int tile_k = blockIdx.x % a.tiles_k, tile_co = blockIdx.x / a.tiles_k;
     const int split = blockIdx.y, set = blockIdx.z;
-    const int co0 = tile_co * BM, ci0 = tile_ci * BN;
-    const int r = tap / a.kw, q = tap % a.kw;
+    const int co0 = tile_co * BM, k0 = tile_k * BN;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
@@ -67,7 +65,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
     constexpr int A_ROWS_PER_PASS = 256 / A_QUADS, B_ROWS_PER_PASS = 256 / B_QUADS;      // 8 ; 8,16,32
     const int a_quad = tid % A_QUADS, a_row0 = tid / A_QUADS;
     const int b_quad = tid % B_QUADS, b_row0 = tid / B_QUADS;
-    const bool a_col_ok = co0 + a_quad * 4 < a.Cout, b_col_ok = ci0 + b_quad * 4 < a.Cin;
+    const int b_col = k0 + b_quad * 4;                                    // this thread's column quad: one tap, 4 channels
+    const bool a_col_ok = co0 + a_quad * 4 < a.Cout, b_col_ok = b_col < a.K;
+    const int b_tap = b_col / a.Cin, b_ci = b_col % a.Cin;
+    const int r = b_tap / a.kw, q = b_tap % a.kw;
     constexpr int A_N = WG_PIX / A_ROWS_PER_PASS, B_N = WG_PIX / B_ROWS_PER_PASS;        // 4 ; 4,2,1
 
     // per B-row pixel coordinates (b, ho, wo) advanced incrementally by WG_PIX per K-tile
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
             const int pl = pt + b_row0 + i * B_ROWS_PER_PASS;
             const int hi = bho[i] * a.stride - a.pad + r, wi = bwo[i] * a.stride - a.pad + q;
             const bool ok = b_col_ok && p_lo + pl < p_hi && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const unsigned off = (unsigned)((((long)(bb[i] * a.H + hi) * a.W + wi) * a.x_cs + a.x_coff + ci0 + b_quad * 4) * 4);
+            const unsigned off = (unsigned)((((long)(bb[i] * a.H + hi) * a.W + wi) * a.x_cs + a.x_coff + b_ci) * 4);
             rb[i] = wbuf_load4(rx, ok ? off : W_OOB);
         }
     };
@@ -165,18 +166,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
         __syncthreads();
     }
 
-    // D[co][ci]: col = lane&31 -> ci, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -> co
+    // D[co][k]: col = lane&31 -> k, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -> co
     float *out = a.out + ((size_t)split * gridDim.z + set) * a.Cout * a.K;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int ci = ci0 + wn * WN + j * 32 + (lane & 31);
-        if (ci >= a.Cin) continue;
+        const int kcol = k0 + wn * WN + j * 32 + (lane & 31);
+        if (kcol >= a.K) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (co < a.Cout) out[(size_t)co * a.K + tap * a.Cin + ci] = acc[i][j][e];
+                if (co < a.Cout) out[(size_t)co * a.K + kcol] = acc[i][j][e];
             }
         }
     }
@@ -205,10 +206,12 @@ static int plan(const somi_conv_desc &f, WgradArgs &a) {
     a.K = f.kh * f.kw * f.Cin;
     a.per_sample = f.per_sample_w ? 1 : 0;
     a.npix = a.per_sample ? f.Ho * f.Wo : f.B * f.Ho * f.Wo;
-    const int bn = f.Cin > 64 ? 128 : (f.Cin > 32 ? 64 : 32);
-    a.tiles_co = cdiv(f.Cout, 128);
-    a.tiles_ci = cdiv(f.Cin, bn);
-    const long tiles = (long)a.tiles_co * a.tiles_ci * f.kh * f.kw * (a.per_sample ? f.B : 1);
+    // 64 co rows when that wastes fewer rows of the last tile (Cout 64, 192, ...); widest column tile K fills
+    a.bm = (cdiv(f.Cout, 64) * 64 < cdiv(f.Cout, 128) * 128) ? 64 : 128;
+    a.bn = a.K > 64 ? 128 : (a.K > 32 || a.bm == 64 ? 64 : 32);
+    a.tiles_co = cdiv(f.Cout, a.bm);
+    a.tiles_k = cdiv(a.K, a.bn);
+    const long tiles = (long)a.tiles_co * a.tiles_k * (a.per_sample ? f.B : 1);
     // enough splits to fill the chip a few times over, but at least 8 K-tiles of work per split
     long want = (1536 + tiles - 1) / tiles;
     const long max_splits = (a.npix + WG_PIX * 8 - 1) / (WG_PIX * 8);
@@ -249,10 +252,12 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     const bool direct = a.splits == 1 && !accumulate;
     a.out = direct ? dw : static_cast<float *>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(a.tiles_co * a.tiles_ci * a.kh * a.kw, a.splits, sets);
-    if (a.Cin > 64) hipLaunchKernelGGL(conv_wgrad_f32_kernel<128>, grid, dim3(256), 0, s, a);
-    else if (a.Cin > 32) hipLaunchKernelGGL(conv_wgrad_f32_kernel<64>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_f32_kernel<32>, grid, dim3(256), 0, s, a);
+    const dim3 grid(a.tiles_co * a.tiles_k, a.splits, sets);
+    if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, s, a);
+    else if (a.bm == 128 && a.bn == 64) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, s, a);
+    else if (a.bm == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, s, a);
+    else if (a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 128>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 64>), grid, dim3(256), 0, s, a);
     if (!direct) {
         const long n = (long)sets * a.Cout * a.K;
         long g = (n / 4 + 255) / 256;
