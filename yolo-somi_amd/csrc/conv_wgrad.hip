@@ -48,9 +48,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    // tile decode: blockIdx.x = tile_co * tiles_k + tile_k, blockIdx.y = split, blockIdx.z = weight set
-    const int tile_k = blockIdx.x % a.tiles_k, tile_co = blockIdx.x / a.tiles_k;
-    const int split = blockIdx.y, set = blockIdx.z;
+    // tile decode: logical id = split * tiles + tile_co * tiles_k + tile_k (blockIdx.z = weight set).  The XCD remap hands each
+    // XCD a contiguous run of logical ids, so all tiles of one pixel split - which read the same dy and x rows - share an L2.
+    const int ntile = a.tiles_co * a.tiles_k;
+    const int lid = xcd_remap(blockIdx.x, ntile * a.splits);
+    const int tile = lid % ntile, split = lid / ntile, set = blockIdx.z;
+    const int tile_k = tile % a.tiles_k, tile_co = tile / a.tiles_k;
     const int co0 = tile_co * BM, k0 = tile_k * BN;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
@@ -183,14 +186,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
     }
 }
 
-// dW = (accumulate ? accumulate : 0) + sum_s part[s]   (fixed order)
+// dW = (accumulate ? accumulate : 0) + sum_s part[s]   (fixed order: 4 interleaved partial sums, combined 0..3).
+// 64 float4 columns x 4 split groups per workgroup: four times the loads in flight of a one-thread-per-column sweep.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int splits, long n, const float *accumulate,
                                                            float *__restrict__ dw) {
+    __shared__ f32x4 sm[4][64];
     const long n4 = n >> 2;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 s = accumulate ? *reinterpret_cast<const f32x4 *>(accumulate + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(part + (size_t)k * n + i * 4);
-        *reinterpret_cast<f32x4 *>(dw + i * 4) = s;
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (long i0 = blockIdx.x * 64L; i0 < n4; i0 += (long)gridDim.x * 64) {
+        const long i = i0 + col;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        if (i < n4) {
+            int k = grp;
+            for (; k + 4 < splits; k += 8) {
+                s0 += *reinterpret_cast<const f32x4 *>(part + (size_t)k * n + i * 4);
+                s1 += *reinterpret_cast<const f32x4 *>(part + (size_t)(k + 4) * n + i * 4);
+            }
+            if (k < splits) s0 += *reinterpret_cast<const f32x4 *>(part + (size_t)k * n + i * 4);
+        }
+        sm[grp][col] = s0 + s1;
+        __syncthreads();
+        if (grp == 0 && i < n4) {
+            f32x4 s = accumulate ? *reinterpret_cast<const f32x4 *>(accumulate + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += sm[0][col];
+            s += sm[1][col];
+            s += sm[2][col];
+            s += sm[3][col];
+            *reinterpret_cast<f32x4 *>(dw + i * 4) = s;
+        }
+        __syncthreads();
     }
 }
 
@@ -252,7 +276,7 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     const bool direct = a.splits == 1 && !accumulate;
     a.out = direct ? dw : static_cast<float *>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(a.tiles_co * a.tiles_k, a.splits, sets);
+    const dim3 grid(a.tiles_co * a.tiles_k * a.splits, 1, sets);
     if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128 && a.bn == 64) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, s, a);
@@ -260,7 +284,7 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     else hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 64>), grid, dim3(256), 0, s, a);
     if (!direct) {
         const long n = (long)sets * a.Cout * a.K;
-        long g = (n / 4 + 255) / 256;
+        long g = (n / 4 + 63) / 64;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s,
                            static_cast<const float *>(workspace), a.splits, n, accumulate, dw);
     }
