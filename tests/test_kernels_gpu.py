@@ -42,6 +42,13 @@ CONV_CASES = [
     (2, 10, 10, 64, 64, 3, 1, 'silu', {'modulate': True}),
     (3, 12, 12, 32, 48, 3, 2, 'silu', {'per_sample': True}),
     (64, 20, 20, 64, 256, 1, 1, 'silu', {}),                # many rows -> 128x128 tiles across images
+    # stream-K schedule (tile count leaves the last round mostly idle): tiles cut several ways, ragged M / N, whole tiles
+    # between two cut ones (600 tiles over 512 workgroups), 1x1
+    (4, 40, 40, 128, 256, 3, 1, 'silu', {'residual': True}),
+    (6, 37, 41, 96, 200, 3, 1, 'silu', {'post': True}),
+    (12, 80, 80, 32, 128, 3, 1, 'silu', {}),
+    (16, 40, 40, 512, 128, 1, 1, 'none', {}),
+    (9, 40, 40, 64, 64, 3, 1, 'silu', {}),                  # 128x64 tiles
 ]
 
 
@@ -101,6 +108,29 @@ def test_conv_igemm(case):
                               per_sample_w=bool(ex.get('per_sample')), **kw)
     torch.cuda.synchronize()
     rel_close(got, nhwc(want), what='conv')
+
+
+def test_conv_streamk_matches_tile_schedule():
+    """The stream-K schedule only changes the order in which K-tiles of a cut tile are added: same result to fp32 rounding,
+    and bit-identical from run to run (fixed combination order)."""
+    from somi_amd import ops
+    from somi_amd.pack import pack_conv_weight
+    g = torch.Generator().manual_seed(77)
+    d = dev()
+    x = torch.randn(5, 40, 40, 128, generator=g).to(d)
+    w = pack_conv_weight(torch.randn(256, 128, 3, 3, generator=g) / 34).to(d)
+    b = torch.randn(256, generator=g).to(d)
+    assert ops.STREAMK
+    y1 = ops.conv2d_nhwc(x, w, b, kh=3, kw=3, pad=1, act='silu')
+    y2 = ops.conv2d_nhwc(x, w, b, kh=3, kw=3, pad=1, act='silu')
+    ops.STREAMK = False
+    try:
+        y0 = ops.conv2d_nhwc(x, w, b, kh=3, kw=3, pad=1, act='silu')
+    finally:
+        ops.STREAMK = True
+    assert torch.equal(y1, y2)
+    assert not torch.equal(y0, y1), 'the stream-K schedule was not taken for a shape it is meant for'
+    rel_close(y1, y0, rel=1e-5, what='stream-K vs one workgroup per tile')
 
 
 def test_conv_rejects_bad_arguments():
@@ -225,7 +255,8 @@ def test_detect_decode():
                                                 # stride parity classes: one with no tap at all (k=1), 3x3 taps per class
                                                 # (k=6), stride 3, and a ragged 64-row class tile
                                                 (2, 9, 12, 16, 32, 1, 2), (2, 14, 14, 16, 32, 6, 2), (2, 11, 13, 8, 32, 5, 3),
-                                                (5, 23, 19, 36, 96, 3, 2)])
+                                                (5, 23, 19, 36, 96, 3, 2),
+                                                (6, 40, 40, 128, 128, 3, 1)])                 # stream-K schedule
 def test_conv_dgrad(B, H, W, Cin, Cout, k, s):
     """dx of F.conv2d from the MFMA implicit-GEMM kernel in data-gradient geometry, against torch autograd on the CPU."""
     from somi_amd import ops

@@ -20,9 +20,14 @@
 //    m on the lane and 4 consecutive n per register quad: the epilogue (bias, activation, affine, residual) works on
 //    float4 and leaves as 16 B stores.
 //
+//  * tile scheduling: one workgroup per tile when the tile count fills the 512 workgroup slots (256 CUs x 2) in nearly whole
+//    rounds; otherwise STREAM-K: 512 persistent workgroups each take an equal contiguous run of (tile, K-tile) units, so
+//    the last round is never a mostly idle one (1600 tiles = 3.125 rounds cost 4 before).  A tile whose K range is cut
+//    between workgroups leaves raw partial accumulators in a workspace; a second small kernel adds them in ascending
+//    workgroup order (deterministic) and runs the epilogue.
+//
 // Reference being replaced: F.conv2d + BatchNorm2d(eval) + SiLU in Conv.forward (models/common.py:64-70,
 // folded as utils/torch_utils.py:202-222), ODConv2d_3rd's grouped per-sample conv (models/common.py:4602-4605).
-#include <stdlib.h>
 #include "common.h"
 
 namespace somi {
@@ -37,255 +42,41 @@ constexpr unsigned OOB = 0xFFFFFFE0u;     // byte offset beyond every descriptor
 constexpr unsigned OOB_BASE = 0xF0000000u;  // + any K offset (< 2^27) still beyond every descriptor
 constexpr unsigned MAX_BUF_BYTES = 0xE0000000u;
 
+__device__ __forceinline__ float fast_silu(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+
 struct ConvArgs {
     somi_conv_desc d;
     int M;        // rows per weight set: B*Ho*Wo, or Ho*Wo when per_sample_w (grid.z = B)
     int K;        // kh*kw*Cin
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, chan_bytes, pix_bytes;
-    int stagger;  // s_sleep units (64 clk) for every second generation of workgroups
     int dgrad;    // 1: data-gradient geometry (rows = forward-input pixels, source = dy, taps walk backwards, stride parity)
     int cls;      // dgrad on the FAST path: grid.y = stride^2 parity classes, each walks only the taps that reach it
+    int sk;       // stream-K: gridDim.x persistent workgroups share tiles_m*tiles_n*nkt units (FAST, no strided classes)
+    float *ws;    // stream-K partial accumulators: [workgroup][2][BM*BN]
 };
 
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-__device__ __forceinline__ float fast_silu(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+constexpr int SK_GRID = 512;              // 256 CUs x 2 resident workgroups
 
-// FAST: Cin % 32 == 0 (every K-tile lies inside one filter tap), kh*kw <= 32: the tap walk is wave-uniform (SALU), each
-// row's padding test is one bit of a mask built once, and a fetch costs 4 VALU per 16 B.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a) {
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
-    constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
-    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;     // 16 B loads per thread per K-tile (activations / weights)
-    constexpr int TILE = (BM + BN) * LDS_LD;
-    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tiling");
+// rows of the GEMM -> pixel rows of y (identity except for the strided dgrad classes)
+struct RowMap {
+    int Mrows, HoWo, Wc, cstep, h0, w0, bz;
+    bool strided;
+};
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
-
-    const somi_conv_desc &d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-    const int ntile = a.tiles_m * a.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, ntile);
-    const int tile_m = tile / a.tiles_n, tile_n = tile % a.tiles_n;   // n fastest: neighbours share the activation rows
-    const int bz = blockIdx.z;                                        // weight set / image (per_sample_w)
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, a.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(MODULATE && d.a_chan_scale ? d.a_chan_scale : d.x), 0,
-                                                                        MODULATE && d.a_chan_scale ? a.chan_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(MODULATE && d.a_pix_scale ? d.a_pix_scale : d.x), 0,
-                                                                        MODULATE && d.a_pix_scale ? a.pix_bytes : 0, 0x00020000);
-    const bool has_chan = MODULATE && d.a_chan_scale, has_pix = MODULATE && d.a_pix_scale;
-
-    // ---- per-thread fetch geometry: 16 B column kc of rows row0 + 32*i
-    const int kc = (tid & 7) * 4, row0 = tid >> 3;
-    int a_hi0[A_ROWS], a_wi0[A_ROWS], a_off[A_ROWS], a_pixi[A_ROWS], a_chn[A_ROWS], a_par[A_ROWS];
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) a_par[i] = 0;
-    // dgrad parity class (FAST path): rows are the pixels with (h+pad)%s == ph, (w+pad)%s == pw, i.e. h = h0 + s*hc, and
-    // only the taps r = ph + s*i, q = pw + s*j reach them - a stride-2 3x3 layer does 9/4 taps per pixel instead of 9.
-    const bool cls = FAST && a.cls;
-    const int ph = cls ? (int)blockIdx.y / d.stride : 0, pw = cls ? (int)blockIdx.y % d.stride : 0;
-    const int h0 = cls ? ((ph - d.pad) % d.stride + d.stride) % d.stride : 0;
-    const int w0 = cls ? ((pw - d.pad) % d.stride + d.stride) % d.stride : 0;
-    const int cstep = cls ? d.stride : 1;
-    const int Hc = cls ? (d.Ho - h0 + cstep - 1) / cstep : d.Ho, Wc = cls ? (d.Wo - w0 + cstep - 1) / cstep : d.Wo;
-    const int nr_c = cls ? (d.kh - ph + cstep - 1) / cstep : d.kh, nq_c = cls ? (d.kw - pw + cstep - 1) / cstep : d.kw;
-    const int HoWo = Hc * Wc;
-    const int Mrows = cls ? (d.per_sample_w ? HoWo : d.B * HoWo) : a.M;
-    if (m0 >= Mrows) return;                                              // smaller class than the grid was sized for
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-        const int m = m0 + row0 + 32 * i;
-        if (m < Mrows) {
-            const int b = m / HoWo + bz, rem = m % HoWo;
-            const int ho = h0 + (rem / Wc) * cstep, wo = w0 + (rem % Wc) * cstep;
-            if (!a.dgrad) {
-                a_hi0[i] = ho * d.stride - d.pad;
-                a_wi0[i] = wo * d.stride - d.pad;
-            } else {                                                      // source row of tap r: (ho+pad)/s - r/s, valid iff r%s == (ho+pad)%s
-                a_hi0[i] = (ho + d.pad) / d.stride;
-                a_wi0[i] = (wo + d.pad) / d.stride;
-                a_par[i] = ((ho + d.pad) % d.stride) | (((wo + d.pad) % d.stride) << 8);
-            }
-            a_pixi[i] = (b * d.H + a_hi0[i]) * d.W + a_wi0[i];           // pixel index of tap (0,0), may be "before" the image
-            a_off[i] = a_pixi[i] * d.x_cs + d.x_coff;
-            a_chn[i] = b * d.Cin;
-        } else {
-            a_hi0[i] = -(1 << 28);                                        // the bounds test fails for every tap -> zeros
-            a_wi0[i] = 0; a_pixi[i] = 0; a_off[i] = 0; a_chn[i] = 0;
-        }
-    }
-    unsigned b_off[B_ROWS];
-#pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) {
-        const int n = n0 + row0 + 32 * i;
-        b_off[i] = n < d.Cout ? (unsigned)(((size_t)bz * d.Cout + n) * a.K + kc) * 4u : (FAST ? OOB_BASE : OOB);
-    }
-    // FAST path state: per-row tap-validity masks and byte offsets with the thread's column folded in
-    unsigned a_mask[A_ROWS], a_offb[A_ROWS], a_pixb[A_ROWS], a_chnb[A_ROWS];
-    if constexpr (FAST) {
-        const int ntap = nr_c * nq_c;
-#pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) {
-            unsigned mk = 0;
-            for (int t = 0; t < ntap; ++t) {
-                const int tr = t / nq_c, tq = t % nq_c;                  // class-local tap index (dgrad: r = ph + s*tr)
-                const int hh = a_hi0[i] + (cls ? -tr : tr * d.dil);
-                const int ww = a_wi0[i] + (cls ? -tq : tq * d.dil);
-                mk |= ((unsigned)hh < (unsigned)d.H && (unsigned)ww < (unsigned)d.W) ? (1u << t) : 0u;
-            }
-            a_mask[i] = mk;
-            a_offb[i] = (unsigned)(a_off[i] + kc) * 4u;
-            a_pixb[i] = (unsigned)a_pixi[i] * 4u;
-            a_chnb[i] = (unsigned)(a_chn[i] + kc) * 4u;
-        }
-    }
-    int tp_u = 0, c0_u = 0, r_u = 0, q_u = 0;                       // wave-uniform tap walk (FAST)
-
-    // k -> (tap r,q ; channel c) for this thread's column, advanced incrementally per K-tile
-    int k = kc, c = kc % d.Cin, tap = kc / d.Cin;
-    int r = tap / d.kw, q = tap % d.kw;
-
-    f32x4 ra[A_ROWS], rb[B_ROWS];
-    auto fetch_tile = [&](int kt_next) {
-        if constexpr (FAST) {
-            const int dpix = cls ? -(r_u * d.W + q_u) : (r_u * d.W + q_u) * d.dil;
-            const unsigned sd = (unsigned)(dpix * d.x_cs + c0_u) * 4u, bit = 1u << tp_u;
-#pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const bool ok = (a_mask[i] & bit) != 0;
-                f32x4 v = buf_load4(rx, ok ? a_offb[i] + sd : OOB);
-                if constexpr (MODULATE) {
-                    if (has_chan) v *= buf_load4(rc, ok ? a_chnb[i] + (unsigned)c0_u * 4u : OOB);
-                    if (has_pix) v *= buf_load1(rp, ok ? a_pixb[i] + (unsigned)dpix * 4u : OOB);
-                }
-                ra[i] = v;
-            }
-            const unsigned ko = cls ? (unsigned)(((ph + cstep * r_u) * d.kw + pw + cstep * q_u) * d.Cin + c0_u) * 4u
-                                    : (unsigned)kt_next * (BK * 4u);
-#pragma unroll
-            for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_off[i] + ko);
-            return;
-        }
-        const bool kin = k < a.K;
-        const int dh = a.dgrad ? -(r / d.stride) : r * d.dil, dw = a.dgrad ? -(q / d.stride) : q * d.dil;
-        const int dpix = dh * d.W + dw;
-        const int delta = dpix * d.x_cs + c;
-        const int rpar = a.dgrad ? ((r % d.stride) | ((q % d.stride) << 8)) : 0;
-#pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) {
-            const bool ok = kin && a_par[i] == rpar && (unsigned)(a_hi0[i] + dh) < (unsigned)d.H &&
-                            (unsigned)(a_wi0[i] + dw) < (unsigned)d.W;
-            f32x4 v = buf_load4(rx, ok ? (unsigned)(a_off[i] + delta) * 4u : OOB);
-            if constexpr (MODULATE) {
-                if (has_chan) v *= buf_load4(rc, ok ? (unsigned)(a_chn[i] + c) * 4u : OOB);
-                if (has_pix) v *= buf_load1(rp, ok ? (unsigned)(a_pixi[i] + dpix) * 4u : OOB);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, (kin && b_off[i] != OOB) ? b_off[i] : OOB);
-    };
-    auto advance_k = [&]() {
-        if constexpr (FAST) {
-            c0_u += BK;
-            if (c0_u == d.Cin) {
-                c0_u = 0;
-                ++tp_u;
-                if (++q_u == nq_c) { q_u = 0; ++r_u; }
-            }
-            return;
-        }
-        k += BK;
-        c += BK;
-        while (c >= d.Cin) {
-            c -= d.Cin;
-            if (++q == d.kw) { q = 0; ++r; }
-        }
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) b_off[i] += (b_off[i] != OOB) ? BK * 4u : 0u;
-    };
-    auto store_tile = [&](float *buf) {
-#pragma unroll
-        for (int i = 0; i < A_ROWS; ++i)
-            *reinterpret_cast<f32x4 *>(&buf[(row0 + 32 * i) * LDS_LD + kc]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i)
-            *reinterpret_cast<f32x4 *>(&buf[(BM + row0 + 32 * i) * LDS_LD + kc]) = rb[i];
-    };
-
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[jn][i][e] = 0.f;
-
-    const int nkt = cls ? nr_c * nq_c * (d.Cin / BK) : (a.K + BK - 1) / BK;      // 0 for a class no tap reaches (k=1, s=2)
-    const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
-    const int aw_off = (wm * WM) * LDS_LD + frag_off;            // activation rows of this wave
-    const int bw_off = (BM + wn * WN) * LDS_LD + frag_off;       // weight rows of this wave
-
-    auto mma_group = [&](const float *buf, int j) {
-        f32x4 fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(buf + aw_off + i * 32 * LDS_LD + j * 8);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const f32x4 *>(buf + bw_off + i * 32 * LDS_LD + j * 8);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[jn][t], fa[i][t], acc[jn][i], 0, 0, 0);
-    };
-
-    // The two workgroups that share a CU start together and, contending for one matrix pipe per SIMD, stay in lockstep:
-    // both issue addresses / LDS stores while the pipe idles.  Delaying every second generation of workgroups by about
-    // half a K-tile keeps the pairs out of phase (one computes while the other fetches).
-    if (a.stagger && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(1), __builtin_amdgcn_s_sleep(1);
-    if (a.stagger && ((blockIdx.x >> 8) & 1))
-        for (int z = 0; z < a.stagger; ++z) __builtin_amdgcn_s_sleep(16);
-    if (nkt > 0) {
-        fetch_tile(0);
-        store_tile(lds);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const float *cur = lds + (kt & 1) * TILE;
-        float *nxt = lds + ((kt + 1) & 1) * TILE;
-        const bool more = kt + 1 < nkt;
-        mma_group(cur, 0);
-        if (more) {
-            advance_k();
-            fetch_tile(kt + 1);    // in flight behind the next two MFMA groups
-        }
-        mma_group(cur, 1);
-        mma_group(cur, 2);
-        if (more) store_tile(nxt); // the other buffer: nobody reads it during this K-tile
-        mma_group(cur, 3);
-        __syncthreads();
-    }
-
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31 (-> m), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (-> n).
-    // Each wave parks its D tile in its own LDS region as [m][n] (the operand buffers are free after the last barrier),
-    // then sweeps it with a compact loop: 16 lanes cover 64 consecutive n of one row -> bias / activation / affine /
-    // residual on float4 and full-line 16 B stores.
+// Epilogue.  C/D map of the 32x32 MFMA: col = lane&31 (-> m), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (-> n).
+// Each wave parks its D tile in its own LDS region as [m][n] (the operand buffers are free after the last barrier),
+// then sweeps it with a compact loop: 16 lanes cover 64 consecutive n of one row -> bias / activation / affine /
+// residual on float4 and full-line 16 B stores.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][BM / WAVES_M / 32], float *lds, const ConvArgs &a,
+                                              const RowMap &rm, int m0, int n0) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int SLD = WN + 4;
-    static_assert(4 * WM * SLD <= 2 * TILE, "epilogue staging does not fit the operand buffers");
+    static_assert(4 * WM * SLD <= 2 * (BM + BN) * LDS_LD, "epilogue staging does not fit the operand buffers");
+    const somi_conv_desc &d = a.d;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     float *stage = lds + wave * (WM * SLD);
     const int h4 = (lane >> 5) * 4;
 #pragma unroll
@@ -298,18 +89,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
                 *reinterpret_cast<f32x4 *>(&stage[(i * 32 + (lane & 31)) * SLD + jn * 32 + 8 * g + h4]) = v;
             }
     __syncthreads();
-    const float *bias = d.bias ? d.bias + (size_t)bz * d.Cout : nullptr;
-    const size_t row_base = (size_t)bz * a.M;
+    const float *bias = d.bias ? d.bias + (size_t)rm.bz * d.Cout : nullptr;
+    const size_t row_base = (size_t)rm.bz * a.M;
     constexpr int NQ = WN / 4;                                    // float4 per staged row
     const int mw = m0 + wm * WM, nw = n0 + wn * WN;
     for (int idx = lane; idx < WM * NQ; idx += 64) {
         const int ml = idx / NQ, n = nw + (idx % NQ) * 4, m = mw + ml;
-        if (m >= Mrows || n >= d.Cout) continue;
+        if (m >= rm.Mrows || n >= d.Cout) continue;
         f32x4 v = *reinterpret_cast<const f32x4 *>(&stage[ml * SLD + (idx % NQ) * 4]);
         size_t row = row_base + m;
-        if (cls && cstep > 1) {
-            const int rem = m % HoWo;
-            row = ((size_t)(m / HoWo + bz) * d.Ho + h0 + (rem / Wc) * cstep) * d.Wo + w0 + (rem % Wc) * cstep;
+        if (rm.strided) {
+            const int rem = m % rm.HoWo;
+            row = ((size_t)(m / rm.HoWo + rm.bz) * d.Ho + rm.h0 + (rem / rm.Wc) * rm.cstep) * d.Wo + rm.w0 + (rem % rm.Wc) * rm.cstep;
         }
         float *yrow = d.y + row * d.y_cs + d.y_coff;
         const float *rrow = d.residual ? d.residual + row * d.res_cs + d.res_coff : nullptr;
@@ -338,17 +129,353 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
     }
 }
 
+// unit range of stream-K workgroup g: [g*U/G, (g+1)*U/G)
+__device__ __forceinline__ long sk_lo(int g, long U, int G) { return (long)g * U / G; }
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+// FAST: Cin % 32 == 0 (every K-tile lies inside one filter tap), kh*kw <= 32: the tap walk is wave-uniform (SALU), each
+// row's padding test is one bit of a mask built once, and a fetch costs 4 VALU per 16 B.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
+    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;     // 16 B loads per thread per K-tile (activations / weights)
+    constexpr int TILE = (BM + BN) * LDS_LD;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tiling");
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+
+    const somi_conv_desc &d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int bz = blockIdx.z;                                        // weight set / image (per_sample_w)
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(MODULATE && d.a_chan_scale ? d.a_chan_scale : d.x), 0,
+                                                                        MODULATE && d.a_chan_scale ? a.chan_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(MODULATE && d.a_pix_scale ? d.a_pix_scale : d.x), 0,
+                                                                        MODULATE && d.a_pix_scale ? a.pix_bytes : 0, 0x00020000);
+    const bool has_chan = MODULATE && d.a_chan_scale, has_pix = MODULATE && d.a_pix_scale;
+
+    // dgrad parity class (FAST path): rows are the pixels with (h+pad)%s == ph, (w+pad)%s == pw, i.e. h = h0 + s*hc, and
+    // only the taps r = ph + s*i, q = pw + s*j reach them - a stride-2 3x3 layer does 9/4 taps per pixel instead of 9.
+    const bool cls = FAST && a.cls;
+    const int ph = cls ? (int)blockIdx.y / d.stride : 0, pw = cls ? (int)blockIdx.y % d.stride : 0;
+    const int h0 = cls ? ((ph - d.pad) % d.stride + d.stride) % d.stride : 0;
+    const int w0 = cls ? ((pw - d.pad) % d.stride + d.stride) % d.stride : 0;
+    const int cstep = cls ? d.stride : 1;
+    const int Hc = cls ? (d.Ho - h0 + cstep - 1) / cstep : d.Ho, Wc = cls ? (d.Wo - w0 + cstep - 1) / cstep : d.Wo;
+    const int nr_c = cls ? (d.kh - ph + cstep - 1) / cstep : d.kh, nq_c = cls ? (d.kw - pw + cstep - 1) / cstep : d.kw;
+    const int HoWo = Hc * Wc;
+    const int Mrows = cls ? (d.per_sample_w ? HoWo : d.B * HoWo) : a.M;
+    const int nkt = cls ? nr_c * nq_c * (d.Cin / BK) : (a.K + BK - 1) / BK;      // 0 for a class no tap reaches (k=1, s=2)
+    const RowMap rmap = {Mrows, HoWo, Wc, cstep, h0, w0, bz, cls && cstep > 1};
+
+    // ---- schedule: one tile (all of its K-tiles), or a stream-K run of (tile, K-tile) units
+    const int ntile = a.tiles_m * a.tiles_n;
+    const bool sk = FAST && a.sk;
+    const int wg = sk ? xcd_remap(blockIdx.x, gridDim.x) : 0;
+    const long U = (long)ntile * nkt;
+    long u = sk ? sk_lo(wg, U, gridDim.x) : (long)xcd_remap(blockIdx.x, ntile) * (nkt > 0 ? nkt : 1);
+    const long u_lo = u, u_hi = sk ? sk_lo(wg + 1, U, gridDim.x) : u + (nkt > 0 ? nkt : 1);
+
+    const int kc = (tid & 7) * 4, row0 = tid >> 3;                    // per-thread fetch column / first row
+    const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
+    const int aw_off = (wm * WM) * LDS_LD + frag_off;                 // activation rows of this wave
+    const int bw_off = (BM + wn * WN) * LDS_LD + frag_off;            // weight rows of this wave
+
+    while (u < u_hi) {
+        const int tile = (int)(u / (nkt > 0 ? nkt : 1));
+        const int kt0 = nkt > 0 ? (int)(u % nkt) : 0;
+        const int kt1 = sk ? (int)min((long)nkt, kt0 + (u_hi - u)) : nkt;
+        u += sk ? kt1 - kt0 : (nkt > 0 ? nkt : 1);
+        const int tile_m = tile / a.tiles_n, tile_n = tile % a.tiles_n;   // n fastest: neighbours share the activation rows
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        if (m0 >= Mrows) return;                                          // smaller class than the grid was sized for (never stream-K)
+
+        // ---- per-thread fetch geometry: 16 B column kc of rows row0 + 32*i
+        int a_hi0[A_ROWS], a_wi0[A_ROWS], a_off[A_ROWS], a_pixi[A_ROWS], a_chn[A_ROWS], a_par[A_ROWS];
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) a_par[i] = 0;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            if (m < Mrows) {
+                const int b = m / HoWo + bz, rem = m % HoWo;
+                const int ho = h0 + (rem / Wc) * cstep, wo = w0 + (rem % Wc) * cstep;
+                if (!a.dgrad) {
+                    a_hi0[i] = ho * d.stride - d.pad;
+                    a_wi0[i] = wo * d.stride - d.pad;
+                } else {                                                      // source row of tap r: (ho+pad)/s - r/s, valid iff r%s == (ho+pad)%s
+                    a_hi0[i] = (ho + d.pad) / d.stride;
+                    a_wi0[i] = (wo + d.pad) / d.stride;
+                    a_par[i] = ((ho + d.pad) % d.stride) | (((wo + d.pad) % d.stride) << 8);
+                }
+                a_pixi[i] = (b * d.H + a_hi0[i]) * d.W + a_wi0[i];           // pixel index of tap (0,0), may be "before" the image
+                a_off[i] = a_pixi[i] * d.x_cs + d.x_coff;
+                a_chn[i] = b * d.Cin;
+            } else {
+                a_hi0[i] = -(1 << 28);                                        // the bounds test fails for every tap -> zeros
+                a_wi0[i] = 0; a_pixi[i] = 0; a_off[i] = 0; a_chn[i] = 0;
+            }
+        }
+        unsigned b_off[B_ROWS];
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            const int n = n0 + row0 + 32 * i;
+            b_off[i] = n < d.Cout ? (unsigned)(((size_t)bz * d.Cout + n) * a.K + kc) * 4u : (FAST ? OOB_BASE : OOB);
+        }
+        // FAST path state: per-row tap-validity masks and byte offsets with the thread's column folded in
+        unsigned a_mask[A_ROWS], a_offb[A_ROWS], a_pixb[A_ROWS], a_chnb[A_ROWS];
+        if constexpr (FAST) {
+            const int ntap = nr_c * nq_c;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                unsigned mk = 0;
+                for (int t = 0; t < ntap; ++t) {
+                    const int tr = t / nq_c, tq = t % nq_c;                  // class-local tap index (dgrad: r = ph + s*tr)
+                    const int hh = a_hi0[i] + (cls ? -tr : tr * d.dil);
+                    const int ww = a_wi0[i] + (cls ? -tq : tq * d.dil);
+                    mk |= ((unsigned)hh < (unsigned)d.H && (unsigned)ww < (unsigned)d.W) ? (1u << t) : 0u;
+                }
+                a_mask[i] = mk;
+                a_offb[i] = (unsigned)(a_off[i] + kc) * 4u;
+                a_pixb[i] = (unsigned)a_pixi[i] * 4u;
+                a_chnb[i] = (unsigned)(a_chn[i] + kc) * 4u;
+            }
+        }
+        // wave-uniform tap walk (FAST), positioned on K-tile kt0
+        const int cpt = FAST ? d.Cin / BK : 1;                          // K-tiles per tap
+        int tp_u = FAST ? kt0 / cpt : 0, c0_u = FAST ? (kt0 % cpt) * BK : 0;
+        int r_u = tp_u / nq_c, q_u = tp_u % nq_c;
+
+        // k -> (tap r,q ; channel c) for this thread's column, advanced incrementally per K-tile (generic path: kt0 == 0)
+        int k = kc, c = kc % d.Cin, tap = kc / d.Cin;
+        int r = tap / d.kw, q = tap % d.kw;
+
+        f32x4 ra[A_ROWS], rb[B_ROWS];
+        auto fetch_tile = [&](int kt_next) {
+            if constexpr (FAST) {
+                const int dpix = cls ? -(r_u * d.W + q_u) : (r_u * d.W + q_u) * d.dil;
+                const unsigned sd = (unsigned)(dpix * d.x_cs + c0_u) * 4u, bit = 1u << tp_u;
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i) {
+                    const bool ok = (a_mask[i] & bit) != 0;
+                    f32x4 v = buf_load4(rx, ok ? a_offb[i] + sd : OOB);
+                    if constexpr (MODULATE) {
+                        if (has_chan) v *= buf_load4(rc, ok ? a_chnb[i] + (unsigned)c0_u * 4u : OOB);
+                        if (has_pix) v *= buf_load1(rp, ok ? a_pixb[i] + (unsigned)dpix * 4u : OOB);
+                    }
+                    ra[i] = v;
+                }
+                const unsigned ko = cls ? (unsigned)(((ph + cstep * r_u) * d.kw + pw + cstep * q_u) * d.Cin + c0_u) * 4u
+                                        : (unsigned)kt_next * (BK * 4u);
+#pragma unroll
+                for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_off[i] + ko);
+                return;
+            }
+            const bool kin = k < a.K;
+            const int dh = a.dgrad ? -(r / d.stride) : r * d.dil, dw = a.dgrad ? -(q / d.stride) : q * d.dil;
+            const int dpix = dh * d.W + dw;
+            const int delta = dpix * d.x_cs + c;
+            const int rpar = a.dgrad ? ((r % d.stride) | ((q % d.stride) << 8)) : 0;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const bool ok = kin && a_par[i] == rpar && (unsigned)(a_hi0[i] + dh) < (unsigned)d.H &&
+                                (unsigned)(a_wi0[i] + dw) < (unsigned)d.W;
+                f32x4 v = buf_load4(rx, ok ? (unsigned)(a_off[i] + delta) * 4u : OOB);
+                if constexpr (MODULATE) {
+                    if (has_chan) v *= buf_load4(rc, ok ? (unsigned)(a_chn[i] + c) * 4u : OOB);
+                    if (has_pix) v *= buf_load1(rp, ok ? (unsigned)(a_pixi[i] + dpix) * 4u : OOB);
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, (kin && b_off[i] != OOB) ? b_off[i] : OOB);
+        };
+        auto advance_k = [&]() {
+            if constexpr (FAST) {
+                c0_u += BK;
+                if (c0_u == d.Cin) {
+                    c0_u = 0;
+                    ++tp_u;
+                    if (++q_u == nq_c) { q_u = 0; ++r_u; }
+                }
+                return;
+            }
+            k += BK;
+            c += BK;
+            while (c >= d.Cin) {
+                c -= d.Cin;
+                if (++q == d.kw) { q = 0; ++r; }
+            }
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) b_off[i] += (b_off[i] != OOB) ? BK * 4u : 0u;
+        };
+        auto store_tile = [&](float *buf) {
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i)
+                *reinterpret_cast<f32x4 *>(&buf[(row0 + 32 * i) * LDS_LD + kc]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i)
+                *reinterpret_cast<f32x4 *>(&buf[(BM + row0 + 32 * i) * LDS_LD + kc]) = rb[i];
+        };
+
+        f32x16 acc[TN][TM];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[jn][i][e] = 0.f;
+
+        auto mma_group = [&](const float *buf, int j) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(buf + aw_off + i * 32 * LDS_LD + j * 8);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const f32x4 *>(buf + bw_off + i * 32 * LDS_LD + j * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[jn][t], fa[i][t], acc[jn][i], 0, 0, 0);
+        };
+
+        if (kt1 > kt0) {
+            fetch_tile(kt0);
+            store_tile(lds);
+        }
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const float *cur = lds + ((kt - kt0) & 1) * TILE;
+            float *nxt = lds + ((kt - kt0 + 1) & 1) * TILE;
+            const bool more = kt + 1 < kt1;
+            mma_group(cur, 0);
+            if (more) {
+                advance_k();
+                fetch_tile(kt + 1);    // in flight behind the next two MFMA groups
+            }
+            mma_group(cur, 1);
+            mma_group(cur, 2);
+            if (more) store_tile(nxt); // the other buffer: nobody reads it during this K-tile
+            mma_group(cur, 3);
+            __syncthreads();
+        }
+
+        if (!sk || (kt0 == 0 && kt1 == nkt)) {
+            conv_epilogue<BM, BN, WAVES_M, WAVES_N>(acc, lds, a, rmap, m0, n0);
+        } else {
+            // a cut tile: raw accumulators to this workgroup's slot (0: the run starts with this piece, 1: it ends with it),
+            // one coalesced float per lane per register
+            const bool first_piece = (long)tile * nkt + kt0 == u_lo;
+            float *slot = a.ws + ((size_t)wg * 2 + (first_piece ? 0 : 1)) * (BM * BN);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) slot[((jn * TM + i) * 16 + e) * 256 + tid] = acc[jn][i][e];
+        }
+        __syncthreads();                                              // the epilogue staging / LDS buffers are reused by the next piece
+    }
+}
+
+// Stream-K fix-up: workgroup j looks at the boundary between the runs of workgroups j and j+1; if it cuts a tile and is the
+// first cut inside that tile, it adds the tile's pieces in ascending workgroup order and runs the epilogue.
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch(const ConvArgs &a, hipStream_t s) {
+__global__ __launch_bounds__(256, 2) void conv_streamk_fixup_kernel(const ConvArgs a, int G) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+    const int nkt = a.K / BK, ntile = a.tiles_m * a.tiles_n;
+    const long U = (long)ntile * nkt;
+    const int g = blockIdx.x + 1;
+    const long b = sk_lo(g, U, G);
+    if (b % nkt == 0) return;                                         // the boundary coincides with a tile boundary
+    const int tile = (int)(b / nkt);
+    const long t_lo = (long)tile * nkt, t_hi = t_lo + nkt;
+    if (sk_lo(g - 1, U, G) > t_lo) return;                            // an earlier boundary inside this tile does the work
+    const int tid = threadIdx.x;
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jn][i][e] = 0.f;
+    for (int w = g - 1; w < G; ++w) {
+        const long lo = sk_lo(w, U, G), hi = sk_lo(w + 1, U, G);
+        if (lo >= t_hi) break;
+        if (hi <= t_lo || hi == lo) continue;                         // (only w = g-1 can end at or before the tile start)
+        const long seg = lo > t_lo ? lo : t_lo;
+        const float *slot = a.ws + ((size_t)w * 2 + (seg == lo ? 0 : 1)) * (BM * BN);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[jn][i][e] += slot[((jn * TM + i) * 16 + e) * 256 + tid];
+    }
+    const RowMap rmap = {a.M, a.d.Ho * a.d.Wo, a.d.Wo, 1, 0, 0, 0, false};
+    conv_epilogue<BM, BN, WAVES_M, WAVES_N>(acc, lds, a, rmap, (tile / a.tiles_n) * BM, (tile % a.tiles_n) * BN);
+}
+
+struct TilePlan {
+    int variant;   // 0: 128x128, 1: 64x128, 2: 128x64, 3: 128x32
+    bool sk;       // stream-K schedule
+};
+static const int kTileBM[4] = {128, 64, 128, 128}, kTileBN[4] = {128, 128, 64, 32};
+
+static bool fast_path(const somi_conv_desc &d) {
+    return d.Cin % BK == 0 && d.kh * d.kw <= 32 && (size_t)d.kh * d.kw * d.Cin * 4 < (1u << 27);
+}
+
+// Tile variant and schedule.  Widest N tile that Cout fills reasonably.  With a workspace the 128-row tile is kept for small
+// problems too and the K-tiles are streamed over 512 workgroups whenever whole rounds of tiles would leave >10% of the
+// slots idle; without one, small-M problems take the 64-row tile to fill the chip.
+static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
+    const bool sk_ok = d.workspace && fast_path(d) && !d.per_sample_w && !(dgrad && d.stride > 1);
+    TilePlan p{0, false};
+    const long blocks128 = (long)cdiv(M, 128) * cdiv(d.Cout, 128) * (d.per_sample_w ? d.B : 1);
+    if (d.Cout > 64) {
+        // a 64-wide N tile when it wastes much less of the last tile (e.g. Cout 192: 3 x 64 instead of 2 x 128)
+        if (cdiv(d.Cout, 64) * 64 * 5 <= cdiv(d.Cout, 128) * 128 * 4 && M >= 128 * 256) p.variant = 2;
+        else p.variant = (sk_ok || blocks128 >= 512 || M >= 128 * 256) ? 0 : 1;
+    } else {
+        p.variant = d.Cout > 32 ? 2 : 3;
+    }
+    if (sk_ok) {
+        const int bm = kTileBM[p.variant], bn = kTileBN[p.variant];
+        const long ntile = (long)cdiv(M, bm) * cdiv(d.Cout, bn), nkt = (long)d.kh * d.kw * d.Cin / BK;
+        const long rounds = (ntile + SK_GRID - 1) / SK_GRID;
+        p.sk = ntile * 10 < rounds * SK_GRID * 9 && ntile * nkt >= SK_GRID * 4L &&
+               d.workspace_bytes >= (size_t)SK_GRID * 2 * bm * bn * sizeof(float);
+    }
+    return p;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
     ConvArgs args = a;
     const bool mod = a.d.a_chan_scale || a.d.a_pix_scale;
-    const bool fast = a.d.Cin % BK == 0 && a.d.kh * a.d.kw <= 32 && (size_t)a.K * 4 < (1u << 27);
+    const bool fast = fast_path(a.d);
     args.cls = a.dgrad && fast;
+    args.sk = sk ? 1 : 0;
+    args.ws = static_cast<float *>(a.d.workspace);
     const int st = a.d.stride, ncls = args.cls ? st * st : 1;
     const int m_cls = args.cls ? (a.d.per_sample_w ? 1 : a.d.B) * cdiv(a.d.Ho, st) * cdiv(a.d.Wo, st) : a.M;   // largest class
     args.tiles_m = cdiv(m_cls, BM);
     args.tiles_n = cdiv(a.d.Cout, BN);
-    const dim3 grid(args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
+    const dim3 grid(sk ? SK_GRID : args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
     if (mod && fast)
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(256), 0, s, args);
     else if (mod)
@@ -357,19 +484,9 @@ static int launch(const ConvArgs &a, hipStream_t s) {
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, dim3(256), 0, s, args);
     else
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, dim3(256), 0, s, args);
+    if (sk)
+        hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(SK_GRID - 1), dim3(256), 0, s, args, SK_GRID);
     return launch_status("somi_conv2d_nhwc_f32");
-}
-
-// tile choice: widest N tile that Cout fills reasonably; small-M problems take the 64-row tile to fill the chip
-static int pick_tile(const somi_conv_desc &d, int M) {
-    const long blocks128 = (long)cdiv(M, 128) * cdiv(d.Cout, 128) * (d.per_sample_w ? d.B : 1);
-    if (d.Cout > 64) {
-        // a 64-wide N tile when it wastes much less of the last tile (e.g. Cout 192: 3 x 64 instead of 2 x 128)
-        if (cdiv(d.Cout, 64) * 64 * 5 <= cdiv(d.Cout, 128) * 128 * 4 && M >= 128 * 256) return 2;
-        return (blocks128 >= 512 || M >= 128 * 256) ? 0 : 1;
-    }
-    if (d.Cout > 32) return 2;
-    return 3;
 }
 
 }  // namespace somi
@@ -412,16 +529,18 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
     a.w_bytes = (unsigned)wb;
     a.chan_bytes = (unsigned)((size_t)d.B * d.Cin * 4);
     a.pix_bytes = (unsigned)((size_t)d.B * d.H * d.W * 4);
-    static const int stagger_env = getenv("SOMI_CONV_STAGGER") ? atoi(getenv("SOMI_CONV_STAGGER")) : 0;
-    a.stagger = stagger_env;
+    SOMI_REQUIRE(!d.workspace || aligned16(d.workspace), SOMI_EINVAL, "conv: workspace must be 16 B aligned");
     a.dgrad = dgrad;
     a.cls = 0;
+    a.sk = 0;
+    a.ws = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (pick_tile(d, a.M)) {
-        case 0: return launch<128, 128, 2, 2>(a, s);
-        case 1: return launch<64, 128, 1, 4>(a, s);
-        case 2: return launch<128, 64, 2, 2>(a, s);
-        default: return launch<128, 32, 4, 1>(a, s);
+    const TilePlan tp = plan_tiles(d, a.M, dgrad);
+    switch (tp.variant) {
+        case 0: return launch<128, 128, 2, 2>(a, tp.sk, s);
+        case 1: return launch<64, 128, 1, 4>(a, tp.sk, s);
+        case 2: return launch<128, 64, 2, 2>(a, tp.sk, s);
+        default: return launch<128, 32, 4, 1>(a, tp.sk, s);
     }
 }
 }  // namespace somi
@@ -446,6 +565,7 @@ extern "C" int somi_conv2d_dgrad_nhwc_f32(const somi_conv_desc *f, const float *
     g.Ho = f->H; g.Wo = f->W; g.Cout = f->Cin; g.y_cs = dx_cs; g.y_coff = dx_coff;                  // rows = forward-input pixels
     g.kh = f->kh; g.kw = f->kw; g.stride = f->stride; g.pad = f->pad; g.dil = 1;
     g.res_cs = acc_cs; g.res_coff = acc_coff; g.act = SOMI_ACT_NONE; g.per_sample_w = f->per_sample_w;
+    g.workspace = f->workspace; g.workspace_bytes = f->workspace_bytes;
     return conv_launch(&g, stream, 1);
 }
 
@@ -456,7 +576,9 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
     const int fast = (dp->Cin % somi::BK == 0 && dp->kh * dp->kw <= 32) ? 1 : 0;
     static const char *tiles[4] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1"};
     static thread_local char name[96];
-    snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::pick_tile(*dp, M)], mod ? "true" : "false",
+    snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::plan_tiles(*dp, M, 0).variant], mod ? "true" : "false",
              fast ? "true" : "false");
     return name;
 }
+
+extern "C" size_t somi_conv2d_workspace_bytes(void) { return (size_t)somi::SK_GRID * 2 * 128 * 128 * sizeof(float); }

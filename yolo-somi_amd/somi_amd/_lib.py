@@ -20,7 +20,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('x', 'w', 'bias', 'post_scale', 'post_shift', 'residual', 'a_chan_scale',
                                           'a_pix_scale', 'y')] + \
                [(n, C.c_int32) for n in ('B', 'H', 'W', 'Cin', 'x_cs', 'x_coff', 'Ho', 'Wo', 'Cout', 'y_cs', 'y_coff',
-                                         'kh', 'kw', 'stride', 'pad', 'dil', 'res_cs', 'res_coff', 'act', 'per_sample_w')]
+                                         'kh', 'kw', 'stride', 'pad', 'dil', 'res_cs', 'res_coff', 'act', 'per_sample_w')] + \
+               [('reserved_', C.c_int32 * 2), ('workspace', C.c_void_p), ('workspace_bytes', C.c_uint64)]
 
 
 class LossDesc(C.Structure):
@@ -39,6 +40,7 @@ SIGNATURES = {
     'somi_abi_version': (I, []),
     'somi_last_error': (C.c_char_p, []),
     'somi_conv2d_nhwc_f32': (I, [C.POINTER(ConvDesc), S]),
+    'somi_conv2d_workspace_bytes': (Z, []),
     'somi_conv2d_dgrad_nhwc_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, P, I, I, P, I, I, S]),
     'somi_conv2d_wgrad_workspace_bytes': (Z, [C.POINTER(ConvDesc)]),
     'somi_conv2d_wgrad_nhwc_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, I, I, P, P, P, Z, S]),
@@ -108,7 +110,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != 1:
+        if L.somi_abi_version() != 2:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -5,14 +5,53 @@ libsomi_hip.so.  Tensors must live on the GPU; anything else raises.
 """
 import ctypes as C
 
+import contextlib
+import os
+
 import torch
 
 from . import _lib
 from ._lib import ConvDesc, check
 
+SIDE = None      # TrainStep sets this to a second HIP stream: weight gradients run there, beside the data gradients
+STREAMK = os.environ.get('SOMI_CONV_STREAMK', '1') != '0'
 PROFILE = None   # bench.py sets this to a list: every conv launch appends (kernel name, algorithmic FLOPs, ev0, ev1)
 
 ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4, 'softmax': 5}
+
+
+@contextlib.contextmanager
+def side_stream(*tensors):
+    """Run the enclosed launches on the weight-gradient stream (ordered after everything already queued on the current
+    stream).  `tensors` are the current-stream tensors the side work reads: the allocator must not recycle them early."""
+    if SIDE is None:
+        yield
+        return
+    SIDE.wait_stream(torch.cuda.current_stream())
+    for t in tensors:
+        t.record_stream(SIDE)
+    with torch.cuda.stream(SIDE):
+        yield
+
+
+def join_side():
+    if SIDE is not None:
+        torch.cuda.current_stream().wait_stream(SIDE)
+
+
+_CONV_WS = {}
+
+
+def _conv_workspace(d, dev):
+    """Attach the stream-K scratch of the current stream to a conv descriptor (launches on one stream are ordered, so they
+    can share it).  SOMI_CONV_STREAMK=0 keeps the one-workgroup-per-tile schedule."""
+    if not STREAMK:
+        return
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _CONV_WS.get(key)
+    if ws is None:
+        ws = _CONV_WS[key] = torch.empty(_lib.lib().somi_conv2d_workspace_bytes(), dtype=torch.uint8, device=dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
 
 
 def _ptr(t):
@@ -54,6 +93,7 @@ def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', 
     d.B, d.H, d.W, d.Cin, d.x_cs, d.x_coff = B, H, W, cin, x_cs, x_coff
     d.Ho, d.Wo, d.Cout, d.y_cs, d.y_coff = Ho, Wo, cout, out.shape[3], y_coff
     d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
+    _conv_workspace(d, x.device)
     d.res_cs, d.res_coff = (residual.shape[3] if residual is not None else 0), res_coff
     d.act, d.per_sample_w = ACT[act], int(per_sample_w)
     if w.numel() != (B if per_sample_w else 1) * cout * kh * kw * cin:
@@ -243,6 +283,7 @@ def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cou
     d = ConvDesc()
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, cin, Ho, Wo, cout
     d.kh, d.kw, d.stride, d.pad, d.dil, d.per_sample_w = kh, kw, stride, pad, 1, int(per_sample_w)
+    _conv_workspace(d, dy.device)
     if w_dgrad.numel() != (B if per_sample_w else 1) * cin * kh * kw * cout:
         raise RuntimeError('dgrad weight has the wrong number of elements')
     prof = PROFILE is not None
