@@ -20,7 +20,7 @@ rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f'# total kernel time {tot / 1e6:.1f} ms over 4 steps (1 warm-up + 3)')
 print(f'{"kernel":100s} {"calls":>6s} {"total_ms":>10s} {"avg_us":>10s} {"pct":>6s}')
-for r in rows[:28]:
+for r in rows[:60]:
     print(f'{r["Name"][:100]:100s} {r["Calls"]:>6s} {float(r["TotalDurationNs"]) / 1e6:10.2f} {float(r["AverageNs"]) / 1e3:10.1f} '
           f'{float(r["Percentage"]):6.1f}')
 print()

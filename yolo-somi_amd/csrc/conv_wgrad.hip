@@ -9,6 +9,7 @@
 // [pixel][channel] and feeds v_mfma_f32_32x32x2_f32 with one ds_read_b32 per operand value (lanes = consecutive channels,
 // conflict-free).  Partial tiles of the splits go to a workspace and are summed in a fixed order (deterministic), optionally
 // on top of an existing gradient.
+#include <stdlib.h>
 #include "common.h"
 
 namespace somi {
@@ -237,7 +238,8 @@ static int plan(const somi_conv_desc &f, WgradArgs &a) {
     a.tiles_k = cdiv(a.K, a.bn);
     const long tiles = (long)a.tiles_co * a.tiles_k * (a.per_sample ? f.B : 1);
     // enough splits to fill the chip a few times over, but at least 8 K-tiles of work per split
-    long want = (1536 + tiles - 1) / tiles;
+    static const long target = getenv("SOMI_WGRAD_WGS") ? atol(getenv("SOMI_WGRAD_WGS")) : 1024;
+    long want = target / tiles;                                          // whole rounds of the 512 workgroup slots, never a bit more
     const long max_splits = (a.npix + WG_PIX * 8 - 1) / (WG_PIX * 8);
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;

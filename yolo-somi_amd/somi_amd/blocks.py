@@ -167,9 +167,8 @@ class Conv(_Packed):
         _acc_grad(self.bn.weight, dgam[:c2])
         _acc_grad(self.bn.bias, dbet[:c2])
         B, H, W, _ = x.shape
-        with ops.side_stream(x.t, dy):
-            dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp)
-            _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))
+        dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp)
+        _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))
         if not need_dx:
             return None
         if dx_out is None:

@@ -11,8 +11,6 @@ enough to use all links while leaving several buckets to overlap (310 MB of fp32
 """
 import torch
 
-from . import ops
-
 
 class GradBuckets:
     def __init__(self, flat_grads, layer_start_offsets, dist=None, bucket_bytes=48 << 20, use_streams=True):
@@ -50,8 +48,6 @@ class GradBuckets:
             ev = torch.cuda.Event()
             ev.record()                                           # gradients of this bucket are final on the compute stream
             self.comm_stream.wait_event(ev)
-            if ops.SIDE is not None:
-                self.comm_stream.wait_stream(ops.SIDE)          # weight gradients are accumulated on their own stream
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
         else:

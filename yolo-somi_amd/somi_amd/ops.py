@@ -4,8 +4,6 @@ PyTorch is plumbing here: it owns the HBM allocations and the stream; all arithm
 libsomi_hip.so.  Tensors must live on the GPU; anything else raises.
 """
 import ctypes as C
-
-import contextlib
 import os
 
 import torch
@@ -13,30 +11,10 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, check
 
-SIDE = None      # TrainStep sets this to a second HIP stream: weight gradients run there, beside the data gradients
 STREAMK = os.environ.get('SOMI_CONV_STREAMK', '1') != '0'
 PROFILE = None   # bench.py sets this to a list: every conv launch appends (kernel name, algorithmic FLOPs, ev0, ev1)
 
 ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4, 'softmax': 5}
-
-
-@contextlib.contextmanager
-def side_stream(*tensors):
-    """Run the enclosed launches on the weight-gradient stream (ordered after everything already queued on the current
-    stream).  `tensors` are the current-stream tensors the side work reads: the allocator must not recycle them early."""
-    if SIDE is None:
-        yield
-        return
-    SIDE.wait_stream(torch.cuda.current_stream())
-    for t in tensors:
-        t.record_stream(SIDE)
-    with torch.cuda.stream(SIDE):
-        yield
-
-
-def join_side():
-    if SIDE is not None:
-        torch.cuda.current_stream().wait_stream(SIDE)
 
 
 _CONV_WS = {}

@@ -8,11 +8,8 @@ the hand-written reverse walk (conv dgrad / wgrad on MFMA, BN / attention / ODCo
 With more than one rank the flat gradient buffers are all-reduced (SUM) in buckets on a side stream while the backward walk is
 still running (ddp.GradBuckets) - DDP's semantics without the wrapper.  fp32 throughout (no GradScaler: nothing to scale).
 """
-import os
-
 import torch
 
-from . import ops
 from .ddp import GradBuckets, layer_offsets
 from .loss import ComputeLoss
 from .optim import build_optimizer
@@ -28,8 +25,6 @@ class TrainStep:
         model.train()
         self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True)
         self.compute_loss = ComputeLoss(model)
-        if os.environ.get('SOMI_WGRAD_SIDE', '0') == '1':
-            ops.SIDE = torch.cuda.Stream()
         self.buckets = None
         if self.world > 1:
             self.buckets = GradBuckets(self.optimizer.flat_grads, layer_offsets(model, self.optimizer), dist=dist,
@@ -47,7 +42,6 @@ class TrainStep:
         if self.world > 1:
             loss = loss * self.world                              # train.py:266-267
         loss.backward()
-        ops.join_side()
         if self.buckets:
             self.buckets.finish()
         self.optimizer.step()                                     # Adam + EMA, one pass
