@@ -31,6 +31,10 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 constexpr int kNumXCD = 8;
 
+// depthwise 3x3 stencil (layers.hip); flip = taps walked backwards (the data gradient)
+void launch_dwconv3x3(bool flip, const float *x, const float *w, const float *bias, const float *ps, const float *pt, const float *res,
+                      float *y, int B, int H, int W, int C, int act, hipStream_t s);
+
 // Bijective XCD-aware remap of a 1-D block id: blocks with equal (id % 8) share an XCD (observed round-robin
 // dispatch), so give each XCD one contiguous chunk of logical tile ids.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -32,38 +32,70 @@ __global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const T *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise 3x3
-// one lane = one pixel x 4 channels; weights [9][C]; neighbours come through L1/L2 (3x3 reuse inside a workgroup row)
+// One lane owns 4 channels of one image column and walks SEG rows down it with the 3x3 window (9 float4) and the 9 weight
+// quads in registers: 3 loads per output instead of 18 (the one-output-per-lane form was bound by the L1 request rate at
+// ~1.5 TB/s).  Lanes run over (column, channel quad), so a wave reads whole contiguous lines; the column neighbours' loads
+// of the same pixels hit in L1.  FLIP walks the taps backwards: the data gradient of the same layer.
+template <bool FLIP>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ bias, const float *__restrict__ ps,
                                                         const float *__restrict__ pt, const float *__restrict__ res,
-                                                        float *__restrict__ y, int B, int H, int W, int C, int act) {
-    const int C4 = C >> 2;
-    const long items = (long)B * H * W * C4;
+                                                        float *__restrict__ y, int B, int H, int W, int C, int act, int SEG) {
+    const int C4 = C >> 2, nseg = (H + SEG - 1) / SEG;
+    const long items = (long)B * nseg * W * C4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
         const int c = (int)(it % C4) * 4;
-        const long pix = it / C4;
-        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
-        const long b = pix / ((long)W * H);
-        f32x4 acc = bias ? *reinterpret_cast<const f32x4 *>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int wv = (int)((it / C4) % W);
+        const int seg = (int)((it / ((long)C4 * W)) % nseg);
+        const long b = it / ((long)C4 * W * nseg);
+        f32x4 wk[9];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int hi = hv + r - 1;
-            if ((unsigned)hi >= (unsigned)H) continue;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int wi = wv + q - 1;
-                if ((unsigned)wi >= (unsigned)W) continue;
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + ((b * H + hi) * W + wi) * C + c);
-                const f32x4 wq = *reinterpret_cast<const f32x4 *>(w + (r * 3 + q) * C + c);
-                acc += xv * wq;
+        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4 *>(w + (FLIP ? 8 - k : k) * C + c);
+        const f32x4 bv = bias ? *reinterpret_cast<const f32x4 *>(bias + c) : zero;
+        const bool wl = wv > 0, wr = wv + 1 < W;
+        const float *xb = x + (b * H * W + wv) * C + c;              // (b, row 0, column wv)
+        auto load_row = [&](int h, f32x4 (&row)[3]) {
+            if ((unsigned)h < (unsigned)H) {
+                const float *pr = xb + (long)h * W * C;
+                row[0] = wl ? *reinterpret_cast<const f32x4 *>(pr - C) : zero;
+                row[1] = *reinterpret_cast<const f32x4 *>(pr);
+                row[2] = wr ? *reinterpret_cast<const f32x4 *>(pr + C) : zero;
+            } else {
+                row[0] = row[1] = row[2] = zero;
             }
-        }
+        };
+        const int h_lo = seg * SEG, h_hi = min(H, h_lo + SEG);
+        f32x4 top[3], mid[3], bot[3];
+        load_row(h_lo - 1, top);
+        load_row(h_lo, mid);
+        for (int h = h_lo; h < h_hi; ++h) {
+            load_row(h + 1, bot);
+            f32x4 acc = bv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = apply_act_rt(acc[e], act);
-        if (ps) acc = acc * *reinterpret_cast<const f32x4 *>(ps + c) + *reinterpret_cast<const f32x4 *>(pt + c);
-        if (res) acc += *reinterpret_cast<const f32x4 *>(res + pix * C + c);
-        *reinterpret_cast<f32x4 *>(y + pix * C + c) = acc;
+            for (int q = 0; q < 3; ++q) acc += top[q] * wk[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc += mid[q] * wk[3 + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc += bot[q] * wk[6 + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = apply_act_rt(acc[e], act);
+            if (ps) acc = acc * *reinterpret_cast<const f32x4 *>(ps + c) + *reinterpret_cast<const f32x4 *>(pt + c);
+            const long o = ((b * H + h) * W + wv) * C + c;
+            if (res) acc += *reinterpret_cast<const f32x4 *>(res + o);
+            *reinterpret_cast<f32x4 *>(y + o) = acc;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { top[q] = mid[q]; mid[q] = bot[q]; }
+        }
     }
+}
+
+void launch_dwconv3x3(bool flip, const float *x, const float *w, const float *bias, const float *ps, const float *pt, const float *res,
+                      float *y, int B, int H, int W, int C, int act, hipStream_t s) {
+    const int seg = H >= 64 ? 16 : 8;
+    const dim3 grid(ew_grid((long)B * cdiv(H, seg) * W * (C / 4)));
+    if (flip) hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, dim3(256), 0, s, x, w, bias, ps, pt, res, y, B, H, W, C, act, seg);
+    else hipLaunchKernelGGL(dwconv3x3_kernel<false>, grid, dim3(256), 0, s, x, w, bias, ps, pt, res, y, B, H, W, C, act, seg);
 }
 
 // ------------------------------------------------------------------------------------------------ SPPF pooling
@@ -570,8 +602,7 @@ extern "C" int somi_dwconv3x3_nhwc_f32(const float *x, const float *w, const flo
     SOMI_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, SOMI_EINVAL, "dwconv: bad arguments");
     SOMI_REQUIRE(C % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(y), SOMI_EINVAL, "dwconv: C %% 4 and 16 B alignment");
     SOMI_REQUIRE(!post_scale == !post_shift, SOMI_EINVAL, "dwconv: post_scale and post_shift go together");
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, w,
-                       bias, post_scale, post_shift, residual, y, B, H, W, C, act);
+    somi::launch_dwconv3x3(false, x, w, bias, post_scale, post_shift, residual, y, B, H, W, C, act, (hipStream_t)stream);
     return launch_status("somi_dwconv3x3_nhwc_f32");
 }
 

@@ -513,80 +513,85 @@ __global__ void bifpn_bwd_weight_kernel(const float *__restrict__ part, int nblk
     }
 }
 
-// ---- depthwise 3x3: data gradient (the transposed stencil) and weight / bias gradient (per-channel reduction over pixels)
-__global__ __launch_bounds__(256) void dwconv3x3_bwd_data_kernel(const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx,
-                                                                 const float *__restrict__ accumulate, int B, int H, int W, int C) {
-    const int C4 = C >> 2;
-    const long items = (long)B * H * W * C4;
-    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C4) * 4;
-        const long pix = it / C4;
-        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
-        const long b = pix / ((long)W * H);
-        f32x4 acc = accumulate ? *reinterpret_cast<const f32x4 *>(accumulate + pix * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int ho = hv - (r - 1);
-            if ((unsigned)ho >= (unsigned)H) continue;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int wo = wv - (q - 1);
-                if ((unsigned)wo >= (unsigned)W) continue;
-                acc += *reinterpret_cast<const f32x4 *>(dy + ((b * H + ho) * W + wo) * C + c) * *reinterpret_cast<const f32x4 *>(w + (r * 3 + q) * C + c);
-            }
-        }
-        *reinterpret_cast<f32x4 *>(dx + pix * C + c) = acc;
-    }
-}
-// grid (nchunk): 512-pixel chunks of the flattened batch; per chunk [10][C] partials (9 taps + bias)
+// ---- depthwise 3x3 backward.  Data gradient = the same sliding-window stencil with the taps walked backwards
+// (launch_dwconv3x3(flip)).  Weight / bias gradient: per-channel reduction over pixels of g * x(shifted); one lane owns 4
+// channels of one image column and walks it top to bottom with the 3x3 window of x in registers (4 loads per pixel instead
+// of 10), the lanes of a workgroup that share a channel quad are combined through LDS, one [10][C] partial per workgroup.
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ part,
-                                                                   long npix, int H, int W, int C) {
+                                                                   int B, int H, int W, int C) {
     __shared__ f32x4 ls[256];
     const int C4 = C >> 2;
-    const long p0 = (long)blockIdx.x * 512, p1 = min(p0 + 512, npix);
-    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
-        const int ncq = min(256, C4 - cq0);
-        const int rows_par = 256 / ncq;
-        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
-        const int c = (cq0 + cq) * 4;
-        f32x4 acc[10];
+    const long items = (long)B * W * C4;
+    const long it = blockIdx.x * 256L + threadIdx.x;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rr < rows_par)
-            for (long p = p0 + rr; p < p1; p += rows_par) {
-                const int wv = (int)(p % W), hv = (int)((p / W) % H);
-                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + p * C + c);
-                acc[9] += g;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int hi = hv + r - 1;
-                    if ((unsigned)hi >= (unsigned)H) continue;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int wi = wv + q - 1;
-                        if ((unsigned)wi >= (unsigned)W) continue;
-                        acc[r * 3 + q] += g * *reinterpret_cast<const f32x4 *>(x + (p + (long)(r - 1) * W + (q - 1)) * C + c);
-                    }
-                }
+    for (int k = 0; k < 10; ++k) acc[k] = zero;
+    const int cq = (int)(it % C4), c = cq * 4;
+    if (it < items) {
+        const int wv = (int)((it / C4) % W);
+        const long b = it / ((long)C4 * W);
+        const bool wl = wv > 0, wr = wv + 1 < W;
+        const float *xb = x + (b * H * W + wv) * C + c;
+        const float *gb = dy + (b * H * W + wv) * C + c;
+        auto load_row = [&](int h, f32x4 (&row)[3]) {
+            if ((unsigned)h < (unsigned)H) {
+                const float *pr = xb + (long)h * W * C;
+                row[0] = wl ? *reinterpret_cast<const f32x4 *>(pr - C) : zero;
+                row[1] = *reinterpret_cast<const f32x4 *>(pr);
+                row[2] = wr ? *reinterpret_cast<const f32x4 *>(pr + C) : zero;
+            } else {
+                row[0] = row[1] = row[2] = zero;
             }
-        for (int k = 0; k < 10; ++k) {
-            ls[threadIdx.x] = acc[k];
-            __syncthreads();
-            if (threadIdx.x < ncq) {
-                f32x4 s = acc[k];
-                for (int r2 = 1; r2 < rows_par; ++r2) s += ls[r2 * ncq + cq];
-                *reinterpret_cast<f32x4 *>(part + ((long)blockIdx.x * 10 + k) * C + c) = s;
+        };
+        f32x4 top[3], mid[3], bot[3];
+        load_row(-1, top);
+        load_row(0, mid);
+        for (int h = 0; h < H; ++h) {
+            load_row(h + 1, bot);
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(gb + (long)h * W * C);
+            acc[9] += g;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                acc[q] += g * top[q];
+                acc[3 + q] += g * mid[q];
+                acc[6 + q] += g * bot[q];
             }
-            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { top[q] = mid[q]; mid[q] = bot[q]; }
         }
     }
+    // lanes t, t + C4, t + 2*C4, ... of the workgroup share a channel quad (256 % C4 == 0, checked by the launcher)
+    const int rows_par = 256 / C4, cl = threadIdx.x % C4;
+    for (int k = 0; k < 10; ++k) {
+        ls[threadIdx.x] = acc[k];
+        __syncthreads();
+        if (threadIdx.x < C4) {
+            f32x4 s = ls[cl];
+            for (int r2 = 1; r2 < rows_par; ++r2) s += ls[r2 * C4 + cl];
+            *reinterpret_cast<f32x4 *>(part + ((long)blockIdx.x * 10 + k) * C + c) = s;
+        }
+        __syncthreads();
+    }
 }
+// 256 threads = 16 (tap, channel) columns x 16 groups of partial rows, combined in a fixed order
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_final(const float *__restrict__ part, int nchunk, int C, float *dw, float *dbias) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 10 * C) return;
-    const int k = i / C, c = i % C;
+    __shared__ double l[256];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < 10 * C) {
+        int j = grp;
+        for (; j + 16 < nchunk; j += 32) { s0 += part[(long)j * 10 * C + i]; s1 += part[(long)(j + 16) * 10 * C + i]; }
+        if (j < nchunk) s0 += part[(long)j * 10 * C + i];
+    }
+    l[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (grp != 0 || i >= 10 * C) return;
     double s = 0.0;
-    for (int j = 0; j < nchunk; ++j) s += part[((long)j * 10 + k) * C + c];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += l[g * 16 + col];
+    const int k = i / C, c = i % C;
     if (k == 9) { if (dbias) dbias[c] += (float)s; }
     else dw[k * C + c] += (float)s;
 }
@@ -665,16 +670,20 @@ extern "C" int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *cons
     return launch_status("somi_bifpn_bwd_nhwc_f32");
 }
 
+extern "C" size_t somi_dwconv3x3_bwd_workspace_floats(int B, int W, int C) {
+    return (size_t)cdiv((long)B * W * (C / 4), 256) * 10 * C;
+}
+
 extern "C" int somi_dwconv3x3_bwd_nhwc_f32(const float *dy, const float *x, const float *w, float *dx, const float *dx_accumulate, float *dw_accumulate,
                                            float *dbias_accumulate, float *workspace, int B, int H, int W, int C, somi_stream_t stream) {
     SOMI_REQUIRE(dy && x && w && dx && dw_accumulate && workspace && B > 0 && H > 0 && W > 0 && C % 4 == 0 && aligned16(dy) && aligned16(x) &&
                      aligned16(dx) && aligned16(w), SOMI_EINVAL, "dwconv bwd: bad arguments");
+    SOMI_REQUIRE(C / 4 <= 256 && 256 % (C / 4) == 0, SOMI_ENOTIMPL, "dwconv bwd: C/4 (%d) must divide 256", C / 4);
     hipStream_t s = (hipStream_t)stream;
-    const long npix = (long)B * H * W;
-    hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dy, w, dx, dx_accumulate, B, H, W, C);
-    const int nchunk = (int)((npix + 511) / 512);
-    hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(nchunk), dim3(256), 0, s, dy, x, workspace, npix, H, W, C);
-    hipLaunchKernelGGL(dwconv3x3_bwd_weight_final, dim3(cdiv(10L * C, 256)), dim3(256), 0, s, workspace, nchunk, C, dw_accumulate, dbias_accumulate);
+    launch_dwconv3x3(true, dy, w, nullptr, nullptr, nullptr, dx_accumulate, dx, B, H, W, C, SOMI_ACT_NONE, s);
+    const int nchunk = (int)cdiv((long)B * W * (C / 4), 256);
+    hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(nchunk), dim3(256), 0, s, dy, x, workspace, B, H, W, C);
+    hipLaunchKernelGGL(dwconv3x3_bwd_weight_final, dim3(cdiv(10L * C, 16)), dim3(256), 0, s, workspace, nchunk, C, dw_accumulate, dbias_accumulate);
     return launch_status("somi_dwconv3x3_bwd_nhwc_f32");
 }
 

@@ -60,20 +60,32 @@ __device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, fl
     }
 }
 
-// stage-2 helper: 256 threads = 64 channels x 4 chunk groups; returns (for group 0 lanes) the sums over all chunks of p1 / p2
+// stage-2 helper: 256 threads = 16 channels x 16 chunk groups (the walk over ~1024 chunk partials is latency bound: short
+// per-thread chains, 4 loads in flight); returns (for group 0 lanes) the sums over all chunks of p1 / p2, combined in a fixed order
+constexpr int S2_CH = 16, S2_GRP = 256 / S2_CH;
 __device__ __forceinline__ bool stage2_sums(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C, int &c, double &s1, double &s2) {
     __shared__ double l1[256], l2[256];
-    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    c = blockIdx.x * 64 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int k = grp; k < nchunk; k += 4) { a += p1[(long)k * C + c]; if (p2) b += p2[(long)k * C + c]; }
-    l1[threadIdx.x] = a;
-    l2[threadIdx.x] = b;
+    const int cl = threadIdx.x % S2_CH, grp = threadIdx.x / S2_CH;
+    c = blockIdx.x * S2_CH + cl;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (c < C) {
+        int k = grp;
+        for (; k + S2_GRP < nchunk; k += 2 * S2_GRP) {
+            const float v0 = p1[(long)k * C + c], v1 = p1[(long)(k + S2_GRP) * C + c];
+            const float w0 = p2 ? p2[(long)k * C + c] : 0.f, w1 = p2 ? p2[(long)(k + S2_GRP) * C + c] : 0.f;
+            a0 += v0; a1 += v1; b0 += w0; b1 += w1;
+        }
+        if (k < nchunk) { a0 += p1[(long)k * C + c]; if (p2) b0 += p2[(long)k * C + c]; }
+    }
+    l1[threadIdx.x] = a0 + a1;
+    l2[threadIdx.x] = b0 + b1;
     __syncthreads();
     if (grp != 0 || c >= C) return false;
-    s1 = (l1[cl] + l1[64 + cl]) + (l1[128 + cl] + l1[192 + cl]);
-    s2 = (l2[cl] + l2[64 + cl]) + (l2[128 + cl] + l2[192 + cl]);
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < S2_GRP; ++g) { t1 += l1[g * S2_CH + cl]; t2 += l2[g * S2_CH + cl]; }
+    s1 = t1;
+    s2 = t2;
     return true;
 }
 
@@ -262,7 +274,7 @@ extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long
     float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, p1, p2, red_chunk(npix));
-    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
                        scale, shift, running_mean, running_var);
     return launch_status("somi_bn_stats_nhwc_f32");
 }
@@ -288,7 +300,7 @@ extern "C" int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, act, order, npix, C,
                        p1, p2, red_chunk(npix));
-    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, 64)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
                        dgamma, dbeta);
     hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, cA, cB,
                        cC, act, order, dx, dx_cs, dx_coff, npix, C);
@@ -301,7 +313,7 @@ extern "C" int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long
     const int nchunk = somi_red_nchunk(npix);
     float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
     hipLaunchKernelGGL(chan_sum_stage1, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, npix, C, p1, p2, red_chunk(npix));
-    hipLaunchKernelGGL(chan_sum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, p1, nchunk, C, out_accumulate);
+    hipLaunchKernelGGL(chan_sum_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, (hipStream_t)stream, p1, nchunk, C, out_accumulate);
     return launch_status("somi_chan_sum_nhwc_f32");
 }
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     'somi_detect_raw_bwd_f32': (I, [P, P, I, P, I, I, I, I, I, I, S]),
     'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, I, I, I, I, I, I, S]),
     'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float), P, I, P, P, P, I, I, I, I, S]),
+    'somi_dwconv3x3_bwd_workspace_floats': (Z, [I, I, I]),
     'somi_dwconv3x3_bwd_nhwc_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, S]),
     'somi_scale_channels_bwd_nhwc_f32': (I, [P, P, P, P, P, P, I, I, I, S]),
     'somi_linear_f32': (I, [P, I, P, P, I, P, I, I, I, I, I, S]),

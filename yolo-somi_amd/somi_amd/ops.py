@@ -433,7 +433,7 @@ def bifpn_backward(srcs, ups, wn, w_dev, dout, dw):
 def dwconv3x3_backward(dy, x, w, dw, dbias, dx_accumulate=None):
     B, H, W, Cc = x.shape
     dx = torch.empty_like(x)
-    ws = torch.empty(((B * H * W + 511) // 512) * 10 * Cc, device=x.device, dtype=torch.float32)
+    ws = torch.empty(max(_lib.lib().somi_dwconv3x3_bwd_workspace_floats(B, W, Cc), 1), device=x.device, dtype=torch.float32)
     check(_lib.lib().somi_dwconv3x3_bwd_nhwc_f32(_ptr(_f32c(dy)), _ptr(_f32c(x)), _ptr(w), _ptr(dx), _ptr(dx_accumulate), _ptr(dw), _ptr(dbias),
                                                  _ptr(ws), B, H, W, Cc, _stream()), 'dwconv3x3_bwd')
     return dx
