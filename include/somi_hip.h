@@ -238,7 +238,8 @@ int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int 
                            const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
                            float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
 int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act,
-                                  int order, float *z, int z_cs, int z_coff, long npix, int C, somi_stream_t stream);
+                                  int order, float *z, int z_cs, int z_coff, long npix, int C, const float *residual /* or NULL: added last */,
+                                  int res_cs, int res_coff, somi_stream_t stream);
 /* gradient of z = [order 0] act(norm(x)) / [order 1] norm(act(x)) w.r.t. x (written to dx, may alias dz), and dgamma / dbeta
  * ACCUMULATED into the given arrays (may be NULL).  batch_stats = 1: statistics were computed from this batch (train);
  * 0: frozen statistics (the norm is a per-channel affine map). */
@@ -326,6 +327,9 @@ int somi_odconv_synth_bwd_f32(const float *dWb, const float *attn, const float *
 int somi_adam_ema_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, long n, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int step, float ema_decay, somi_stream_t stream);
 int somi_axpby_f32(float *y, const float *x, long n, float a, float b, somi_stream_t stream);
+/* Forward-packed conv weights [Cout][taps][Cin] -> the packing somi_conv2d_dgrad_nhwc_f32 reads, [Cin][taps][Cout].  Run once
+ * per optimizer step on the master weights (which the training path keeps in the forward packing). */
+int somi_pack_dgrad_weights_f32(const float *w_packed, float *w_dgrad, int Cout, int taps, int Cin, somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).

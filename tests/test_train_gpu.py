@@ -321,3 +321,44 @@ def test_fused_adam_ema_matches_torch():
             rel_close(esd[k], v, rel=1e-5, what=f'ema {k}')
     mine.zero_grad()
     assert all(float(q.grad.abs().max()) == 0.0 for q in net.parameters())
+
+
+def test_fused_adam_packed_conv_masters():
+    """Conv+BN blocks keep their weight master in the kernels' packing inside the flat optimizer buffer; the module parameter is
+    a strided view of it.  Adam on that storage must equal torch.optim.Adam on the reference layout, pads must stay zero, and
+    the EMA / state_dict round trip must come back in the reference layout."""
+    import copy
+    from somi_amd.blocks import Conv
+    from somi_amd.optim import FusedAdamEMA, reference_param_groups
+    from somi_amd.pack import pack_conv_weight, pad4
+    g = torch.Generator().manual_seed(11)
+    net = nn.Sequential(Conv(3, 8, 3), Conv(8, 6, 1), Conv(6, 12, 3, 2))       # Cin 3 -> 4, Cout 6 -> 8: both kinds of padding
+    ref = copy.deepcopy(net)
+    g0, g1, g2 = reference_param_groups(ref)
+    opt = torch.optim.Adam(g0, lr=1e-3, betas=(0.9, 0.999))
+    opt.add_param_group({'params': g1, 'weight_decay': 0.01})
+    opt.add_param_group({'params': g2})
+    net = net.cuda()
+    mine = FusedAdamEMA(net, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    assert all('_master' in m.__dict__ for m in net)
+    for _ in range(3):
+        grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
+        for p, q, gr in zip(ref.parameters(), net.parameters(), grads):
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        opt.step()
+        mine.step()
+    for (n, p), (_, q) in zip(ref.named_parameters(), net.named_parameters()):
+        rel_close(q, p, rel=1e-5, what=f'param {n}')
+    for m in net:
+        c2, c1, k = m.conv.weight.shape[:3]
+        want = pack_conv_weight(m.conv.weight.detach().cpu().contiguous(), cout_pad=pad4(c2))
+        assert torch.equal(m.__dict__['_master'][0].cpu(), want), 'master storage is not the packed weight (or a pad moved)'
+    sd = {k_: v.cpu() for k_, v in net.state_dict().items()}
+    for k_, v in ref.state_dict().items():
+        if v.dtype.is_floating_point:
+            rel_close(sd[k_], v, rel=1e-5, what=f'state_dict {k_}')
+    esd = mine.ema_state_dict()
+    assert esd['0.conv.weight'].shape == ref[0].conv.weight.shape
+    mine.zero_grad()
+    assert all(float(q.grad.abs().max()) == 0.0 for q in net.parameters())

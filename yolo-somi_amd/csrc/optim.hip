@@ -44,6 +44,22 @@ static inline int grid_for(long n) {
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// forward packing [Cout][T][Cin] -> data-gradient packing [Cin][T][Cout], one 32x32 LDS-transposed tile per workgroup and tap
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cout, int T, int Cin) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + t) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((size_t)ci * T + t) * Cout + co] = tile[tx][r];
+    }
+}
+
 }  // namespace somi
 
 using namespace somi;
@@ -63,4 +79,12 @@ extern "C" int somi_axpby_f32(float *y, const float *x, long n, float a, float b
     SOMI_REQUIRE(y && x && n > 0, SOMI_EINVAL, "axpby: bad arguments");
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n * 4)), dim3(256), 0, (hipStream_t)stream, y, x, n, a, b);
     return launch_status("somi_axpby_f32");
+}
+
+extern "C" int somi_pack_dgrad_weights_f32(const float *w_packed, float *w_dgrad, int Cout, int taps, int Cin, somi_stream_t stream) {
+    using namespace somi;
+    SOMI_REQUIRE(w_packed && w_dgrad && Cout > 0 && taps > 0 && Cin > 0 && taps < 65536, SOMI_EINVAL, "pack dgrad: bad arguments");
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, (hipStream_t)stream, w_packed, w_dgrad,
+                       Cout, taps, Cin);
+    return launch_status("somi_pack_dgrad_weights_f32");
 }

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const float *__restrict__
 // order 0: z = act(x*scale + shift) ; order 1: z = act(x)*scale + shift        (x, z: channel slices; in place allowed)
 __global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__restrict__ x, int x_cs, int x_coff,
                                                               const float *__restrict__ scale, const float *__restrict__ shift, int act,
-                                                              int order, float *__restrict__ z, int z_cs, int z_coff, long npix, int C) {
+                                                              int order, float *__restrict__ z, int z_cs, int z_coff, long npix, int C,
+                                                              const float *__restrict__ res, int res_cs, int res_coff) {
     const int C4 = C >> 2;
     const long items = npix * C4;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__res
             for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
             v = v * sc + sh;
         }
+        if (res) v += *reinterpret_cast<const f32x4 *>(res + p * res_cs + res_coff + c);
         *reinterpret_cast<f32x4 *>(z + p * z_cs + z_coff + c) = v;
     }
 }
@@ -280,11 +282,13 @@ extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long
 }
 
 extern "C" int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act,
-                                             int order, float *z, int z_cs, int z_coff, long npix, int C, somi_stream_t stream) {
+                                             int order, float *z, int z_cs, int z_coff, long npix, int C, const float *residual,
+                                             int res_cs, int res_coff, somi_stream_t stream) {
     SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && slice_ok(z, z_cs, z_coff, C) && scale && shift && npix > 0 && C % 4 == 0 &&
                      (order == 0 || order == 1) && aligned16(scale) && aligned16(shift), SOMI_EINVAL, "chan affine act: bad arguments");
+    SOMI_REQUIRE(!residual || slice_ok(residual, res_cs, res_coff, C), SOMI_EINVAL, "chan affine act: bad residual slice");
     hipLaunchKernelGGL(chan_affine_act_kernel, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, scale, shift,
-                       act, order, z, z_cs, z_coff, npix, C);
+                       act, order, z, z_cs, z_coff, npix, C, residual, res_cs, res_coff);
     return launch_status("somi_chan_affine_act_nhwc_f32");
 }
 

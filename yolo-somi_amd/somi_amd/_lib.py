@@ -66,7 +66,7 @@ SIGNATURES = {
     'somi_detect_decode_f32': (I, [P, I, P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
     'somi_red_nchunk': (I, [C.c_long]),
     'somi_bn_stats_nhwc_f32': (I, [P, I, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
-    'somi_chan_affine_act_nhwc_f32': (I, [P, I, I, P, P, I, I, P, I, I, C.c_long, I, S]),
+    'somi_chan_affine_act_nhwc_f32': (I, [P, I, I, P, P, I, I, P, I, I, C.c_long, I, P, I, I, S]),
     'somi_bn_act_backward_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, P, I, I, P, P, C.c_long, I, P, S]),
     'somi_add_nhwc_f32': (I, [P, I, I, P, I, I, P, I, I, C.c_long, I, S]),
     'somi_chan_sum_nhwc_f32': (I, [P, I, I, C.c_long, I, P, P, S]),
@@ -88,6 +88,7 @@ SIGNATURES = {
     'somi_odconv_synth_f32': (I, [P, P, P, P, P, I, I, I, I, I, I, S]),
     'somi_odconv_synth_bwd_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, S]),
     'somi_adam_ema_step_f32': (I, [P, P, P, P, P, C.c_long, F, F, F, F, F, I, F, S]),
+    'somi_pack_dgrad_weights_f32': (I, [P, P, I, I, I, S]),
     'somi_axpby_f32': (I, [P, P, C.c_long, F, F, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),

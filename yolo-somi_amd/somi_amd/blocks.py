@@ -49,10 +49,13 @@ class _Packed(nn.Module):
     """Mixin: device-side packed parameters are rebuilt lazily after any parameter change."""
 
     def _packed(self, dev):
+        # in-place edits through torch (load_state_dict, copy_) bump the version counters; the fused optimizer writes through
+        # raw pointers and calls Model.invalidate() itself
+        key = (dev, self.training, tuple(p._version for p in self.parameters()))
         cache = self.__dict__.get('_pk')
-        if cache is None or cache[0] != (dev, self.training):
+        if cache is None or cache[0] != key:
             with torch.no_grad():
-                cache = ((dev, self.training), self._pack(dev))
+                cache = (key, self._pack(dev))
             self.__dict__['_pk'] = cache
         return cache[1]
 
@@ -115,19 +118,30 @@ class Conv(_Packed):
 
     def _pack(self, dev):
         if self.training:                                        # raw weights, batch-norm applied from batch statistics
-            w = self.conv.weight.detach().float()
-            c2 = w.shape[0]
-            padv = lambda t, fill: torch.cat([t.detach().float().to(dev), torch.full((pad4(c2) - c2,), fill, device=dev)])   # noqa: E731
-            return dict(wp=pack_conv_weight(w, cout_pad=pad4(c2)).to(dev), wt=pack_dgrad_weight(w).to(dev),
-                        gamma=padv(self.bn.weight, 0.), beta=padv(self.bn.bias, 0.), rm=padv(self.bn.running_mean, 0.),
-                        rv=padv(self.bn.running_var, 1.))
+            w = self.conv.weight
+            c2, c1, k = w.shape[0], w.shape[1], w.shape[2]
+            cp, c1p = pad4(c2), pad4(c1)
+            master = self.__dict__.get('_master')               # (weights, gradients) [cp][k*k*c1p] inside the optimizer's flat buffers
+            if master is not None and master[0].device == dev:
+                wp, gp = master
+                wt = ops.pack_dgrad_weights(wp, cp, k * k, c1p)
+            else:
+                wf = w.detach().float()
+                wp, gp, wt = pack_conv_weight(wf, cout_pad=cp).to(dev), None, pack_dgrad_weight(wf).to(dev)
+            bn = self.bn
+            if cp == c2 and bn.weight.device == dev:             # no padding: the module's own tensors, running statistics in place
+                vec = dict(gamma=bn.weight.detach(), beta=bn.bias.detach(), rm=bn.running_mean, rv=bn.running_var, inplace=True)
+            else:
+                padv = lambda t, fill: torch.cat([t.detach().float().to(dev), torch.full((cp - c2,), fill, device=dev)])   # noqa: E731
+                vec = dict(gamma=padv(bn.weight, 0.), beta=padv(bn.bias, 0.), rm=padv(bn.running_mean, 0.), rv=padv(bn.running_var, 1.),
+                           inplace=False)
+            return dict(wp=wp, gp=gp, wt=wt, **vec)
         return _pack_wb(*_fold_conv_bn(self.conv, getattr(self, 'bn', None)), dev)
 
     # ------------------------------------------------------------------------------------------ training mode
     def _forward_train(self, x, out, residual):
         """y = conv(x) (raw) -> batch statistics -> z = act(y*scale+shift) [+ residual]; keeps what backward needs."""
-        self.invalidate()                                        # parameters change every step: repack
-        pk = self._packed(x.t.device)
+        pk = self._packed(x.t.device)                            # rebuilt after every optimizer step (Model.invalidate)
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         c2, cp = self.conv.out_channels, pad4(self.conv.out_channels)
         B, H, W, _ = x.shape
@@ -137,17 +151,21 @@ class Conv(_Packed):
                         alg_cin=x.c, alg_cout=c2)
         mean, rstd, scale, shift = ops.bn_stats(y, cp, 0, pk['gamma'], pk['beta'], self.bn.eps, self.bn.momentum, pk['rm'], pk['rv'])
         with torch.no_grad():                                    # running statistics back into the module buffers
-            self.bn.running_mean.copy_(pk['rm'][:c2])
-            self.bn.running_var.copy_(pk['rv'][:c2])
+            if not pk['inplace']:
+                self.bn.running_mean.copy_(pk['rm'][:c2])
+                self.bn.running_var.copy_(pk['rv'][:c2])
             self.bn.num_batches_tracked += 1
         if out is None:
             out = new_act(x.t, Ho, Wo, c2)
         elif c2 % 4:
             raise NotImplementedError('writing into a channel slice needs c2 % 4 == 0')
         cw = cp if out.coff == 0 and out.t.shape[3] == cp else c2
-        ops.chan_affine_act(y, cw, 0, scale, shift, _act_name(self.act), 0, out.t, out.coff)
-        if residual is not None:
+        if residual is not None and cw != c2:
+            ops.chan_affine_act(y, cw, 0, scale, shift, _act_name(self.act), 0, out.t, out.coff)
             ops.add_(out.t, out.coff, residual.t, residual.coff, c2)
+        else:
+            ops.chan_affine_act(y, cw, 0, scale, shift, _act_name(self.act), 0, out.t, out.coff,
+                                residual=None if residual is None else residual.t, res_coff=0 if residual is None else residual.coff)
         self.__dict__['_ctx'] = (x, y, mean, rstd, scale, shift, pk)
         return Act(out.t, out.coff, c2)
 
@@ -159,16 +177,25 @@ class Conv(_Packed):
         c1, c2, cp = self.conv.in_channels, self.conv.out_channels, pad4(self.conv.out_channels)
         dev = y.device
         dy = torch.zeros_like(y) if cp != c2 else torch.empty_like(y)
-        dgam, dbet = torch.zeros(cp, device=dev), torch.zeros(cp, device=dev)
         cw = cp if (dz.coff == 0 and dz.t.shape[3] == cp) else c2     # whole padded tensor, or an aligned slice
         if cw % 4:
             raise NotImplementedError('training backward on a channel slice needs out_channels % 4 == 0')
-        ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, dgam, dbet)
-        _acc_grad(self.bn.weight, dgam[:c2])
-        _acc_grad(self.bn.bias, dbet[:c2])
+        gw, gb = self.bn.weight.grad, self.bn.bias.grad
+        direct = cp == c2 and gw is not None and gb is not None and gw.is_contiguous() and gb.is_contiguous() and gw.device == dev
+        if direct:                                                # the kernel accumulates straight into the gradient buffers
+            ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, gw, gb)
+        else:
+            dgam, dbet = torch.zeros(cp, device=dev), torch.zeros(cp, device=dev)
+            ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, dgam, dbet)
+            _acc_grad(self.bn.weight, dgam[:c2])
+            _acc_grad(self.bn.bias, dbet[:c2])
         B, H, W, _ = x.shape
-        dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp)
-        _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))
+        if pk['gp'] is not None:                                  # accumulate into the packed gradient master
+            ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp, out=pk['gp'],
+                                  accumulate=pk['gp'])
+        else:
+            dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp)
+            _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))
         if not need_dx:
             return None
         if dx_out is None:

@@ -323,9 +323,18 @@ def bn_stats(x, c, x_coff, gamma, beta, eps, momentum, running_mean=None, runnin
     return mean, rstd, scale, shift
 
 
-def chan_affine_act(x, c, x_coff, scale, shift, act, order, out, out_coff=0):
+def chan_affine_act(x, c, x_coff, scale, shift, act, order, out, out_coff=0, residual=None, res_coff=0):
     check(_lib.lib().somi_chan_affine_act_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, _ptr(scale), _ptr(shift), ACT[act], order,
-                                                   _ptr(_f32c(out)), out.shape[3], out_coff, _npix(x), c, _stream()), 'chan_affine_act')
+                                                   _ptr(_f32c(out)), out.shape[3], out_coff, _npix(x), c,
+                                                   _ptr(residual), residual.shape[3] if residual is not None else 0, res_coff,
+                                                   _stream()), 'chan_affine_act')
+    return out
+
+
+def pack_dgrad_weights(w_packed, cout, taps, cin):
+    """[cout][taps][cin] (forward packing) -> [cin][taps][cout] (operand of conv2d_dgrad_nhwc)."""
+    out = torch.empty(cin, taps * cout, device=w_packed.device, dtype=torch.float32)
+    check(_lib.lib().somi_pack_dgrad_weights_f32(_ptr(_f32c(w_packed)), _ptr(out), cout, taps, cin, _stream()), 'pack_dgrad_weights')
     return out
 
 

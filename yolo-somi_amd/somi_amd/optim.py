@@ -30,9 +30,14 @@ def reference_param_groups(model):
 
 
 class _Flat:
-    def __init__(self, tensors, dev):
+    """Flat fp32 storage for a list of parameters.  `packed` maps id(param) -> (cout_pad, kh, kw, cin_pad) for the conv weights
+    that are stored in the kernels' forward packing [cout_pad][kh][kw][cin_pad] (pads zero, never touched by Adam: their
+    gradient is 0); the module parameter is then a strided (Cout,Cin,kh,kw) view of that storage."""
+
+    def __init__(self, tensors, dev, packed=None):
         self.tensors = tensors
-        self.sizes = [t.numel() for t in tensors]
+        self.packed = [(packed or {}).get(id(t)) for t in tensors]
+        self.sizes = [t.numel() if pk is None else pk[0] * pk[1] * pk[2] * pk[3] for t, pk in zip(tensors, self.packed)]
         self.offsets, o = [], 0
         for n in self.sizes:                                      # every tensor starts 16 B aligned (kernels take float4)
             self.offsets.append(o)
@@ -40,9 +45,24 @@ class _Flat:
         self.n = self.n_pad = o
         self.data = torch.zeros(max(o, 4), device=dev, dtype=torch.float32)
 
+    def view_of(self, i, buf=None):
+        """Parameter-shaped (reference layout) view of entry i inside `buf` (default: this buffer)."""
+        buf = self.data if buf is None else buf
+        t, n, o, pk = self.tensors[i], self.sizes[i], self.offsets[i], self.packed[i]
+        if pk is None:
+            return buf[o:o + n].view_as(t)
+        cout, cin = t.shape[0], t.shape[1]
+        return buf[o:o + n].view(*pk)[:cout, :, :, :cin].permute(0, 3, 1, 2)
+
+    def storage_of(self, i, buf=None):
+        """The kernels' view of a packed entry: [cout_pad][kh*kw*cin_pad]."""
+        buf = self.data if buf is None else buf
+        pk = self.packed[i]
+        return buf[self.offsets[i]:self.offsets[i] + self.sizes[i]].view(pk[0], pk[1] * pk[2] * pk[3])
+
     def views(self):
-        for t, n, o in zip(self.tensors, self.sizes, self.offsets):
-            yield t, self.data[o:o + n].view_as(t)
+        for i, t in enumerate(self.tensors):
+            yield t, self.view_of(i)
 
 
 class FusedAdamEMA:
@@ -60,14 +80,23 @@ class FusedAdamEMA:
         for plist, wd in ((g0, 0.0), (g1, weight_decay), (g2, 0.0)):
             plist = [p for p in plist if id(p) not in seen and not seen.add(id(p))]
             groups.append((plist, wd))
+        # Conv+BN blocks keep their weight master in the kernels' forward packing: nothing to repack per step, and the
+        # weight gradient is accumulated into the gradient buffer by the wgrad kernel itself
+        from .blocks import Conv
+        from .pack import pad4
+        owners = {id(m.conv.weight): m for m in model.modules() if isinstance(m, Conv)}
+        packed = {k: (pad4(m.conv.out_channels), m.conv.kernel_size[0], m.conv.kernel_size[1], pad4(m.conv.in_channels))
+                  for k, m in owners.items()}
         self.param_groups, self._flat = [], []
         for plist, wd in groups:
-            fp, fg = _Flat(plist, dev), _Flat(plist, dev)
+            fp, fg = _Flat(plist, dev, packed), _Flat(plist, dev, packed)
             with torch.no_grad():
-                for (p, v), (_, gv) in zip(fp.views(), fg.views()):
+                for i, ((p, v), (_, gv)) in enumerate(zip(fp.views(), fg.views())):
                     v.copy_(p.data)
                     p.data = v                                   # the module parameter now lives inside the flat buffer
                     p.grad = gv                                  # and so does its gradient
+                    if fp.packed[i] is not None:
+                        owners[id(p)].__dict__['_master'] = (fp.storage_of(i), fg.storage_of(i))
             st = dict(p=fp, g=fg, m=torch.zeros_like(fp.data), v=torch.zeros_like(fp.data),
                       ema=fp.data.clone() if ema else None)
             self._flat.append(st)
@@ -78,6 +107,17 @@ class FusedAdamEMA:
         self.ema_decay, self.updates, self.steps = ema_decay, 0, 0
         if hasattr(model, 'invalidate'):
             model.invalidate()
+
+    @property
+    def flat_params(self):
+        """The flat parameter buffers (one per group)."""
+        return [st['p'].data for st in self._flat]
+
+    def reset_ema(self):
+        """Restart the EMA shadow from the current weights (after the initial weights were broadcast)."""
+        for st in self._flat:
+            if st['ema'] is not None:
+                st['ema'].copy_(st['p'].data)
 
     @property
     def flat_grads(self):
@@ -114,8 +154,8 @@ class FusedAdamEMA:
         for st in self._flat:
             if st['ema'] is None:
                 continue
-            for p, n, o in zip(st['p'].tensors, st['p'].sizes, st['p'].offsets):
-                sd[name_of[id(p)]] = st['ema'][o:o + n].view_as(p).clone()
+            for i, p in enumerate(st['p'].tensors):
+                sd[name_of[id(p)]] = st['p'].view_of(i, st['ema']).clone()
         bname = {id(b): n for n, b in self.model.named_buffers()}
         for b, e in zip(self._bufs, self._buf_ema):
             sd[bname[id(b)]] = e.clone()

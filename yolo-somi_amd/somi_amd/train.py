@@ -30,8 +30,10 @@ class TrainStep:
             self.buckets = GradBuckets(self.optimizer.flat_grads, layer_offsets(model, self.optimizer), dist=dist,
                                        bucket_bytes=bucket_mb << 20)
             model.__dict__['_grad_hook'] = self.buckets.layer_done
-            for p in model.parameters():                          # one set of initial weights (DDP broadcasts from rank 0)
-                dist.broadcast(p.data, src=0)
+            for buf in self.optimizer.flat_params:                # one set of initial weights (DDP broadcasts from rank 0)
+                dist.broadcast(buf, src=0)
+            self.optimizer.reset_ema()
+            model.invalidate()
 
     def step(self, imgs, targets):
         """imgs: (B,3,H,W) uint8 on the GPU; targets (nt,6).  Returns (loss, loss_items) like train.py:265."""
