@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
+    ap.add_argument('--no-infer', action='store_true', help='skip the side measurement of the inference rate (profiling runs)')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
                     help='train: forward(train)+loss+backward+Adam+EMA step (BASELINE configs[1]); infer: forward+NMS')
     args = ap.parse_args()
@@ -146,15 +147,17 @@ def main():
                 return None
             return non_max_suppression(z, 0.001, 0.6, multi_label=True)
 
-    # inference throughput (eval mode) is always measured: a few steps, reported next to the training number
-    for _ in range(2):
-        infer_step()
-    torch.cuda.synchronize()
-    t_inf = time.time()
-    for _ in range(3):
-        infer_step()
-    torch.cuda.synchronize()
-    infer_ips = args.batch * 3 / (time.time() - t_inf)
+    # inference throughput (eval mode) is measured beside the training number: a few steps
+    infer_ips = None
+    if not (args.no_infer and args.mode == 'train'):
+        for _ in range(2):
+            infer_step()
+        torch.cuda.synchronize()
+        t_inf = time.time()
+        for _ in range(3):
+            infer_step()
+        torch.cuda.synchronize()
+        infer_ips = args.batch * 3 / (time.time() - t_inf)
 
     if args.mode == 'train':
         from somi_amd.configs import HYP_VISDRONE, synthetic_batch
@@ -200,7 +203,7 @@ def main():
                                    f'{args.size}x{args.size}, batch {args.batch}/GPU (BASELINE configs[1] shape)',
                        'batch_per_gpu': args.batch, 'imgsz': args.size, 'params': 77537610,
                        'parallelism': (f'dp{world}' if args.mode == 'train' else f'replicas x{world}')},
-            'infer_images_per_s_per_gpu': round(infer_ips, 2),
+            'infer_images_per_s_per_gpu': None if infer_ips is None else round(infer_ips, 2),
             'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                          'launches': cnt, 'avg_launch_us': round(secs / cnt * 1e6, 2),

@@ -274,7 +274,13 @@ def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cou
           'conv2d_dgrad_nhwc')
     if prof:
         e1.record()
-        PROFILE.append(('conv_igemm_f32_kernel<dgrad>', 2.0 * B * Ho * Wo * cout * cin * kh * kw, e0, e1, (B, H, W, cin, cout, kh, stride, 2)))
+        g = ConvDesc()                                           # the geometry the kernel runs in: rows = forward-input pixels
+        g.B, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout = B, Ho, Wo, cout, H, W, cin
+        g.kh, g.kw, g.stride, g.per_sample_w = kh, kw, stride, int(per_sample_w)
+        if stride == 1:
+            g.workspace, g.workspace_bytes = d.workspace, d.workspace_bytes
+        name = _lib.lib().somi_conv2d_kernel_name(C.byref(g)).decode()
+        PROFILE.append((name, 2.0 * B * Ho * Wo * cout * cin * kh * kw, e0, e1, (B, H, W, cin, cout, kh, stride, 2)))
     return out
 
 
@@ -302,7 +308,11 @@ def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cou
                                        _ptr(accumulate), _ptr(ws), nbytes, _stream()), 'conv2d_wgrad_nhwc')
     if prof:
         e1.record()
-        PROFILE.append(('conv_wgrad_f32_kernel', 2.0 * B * Ho * Wo * cout * cin * kh * kw, e0, e1, (B, H, W, cin, cout, kh, stride, 3)))
+        bm = 64 if -(-cout // 64) * 64 < -(-cout // 128) * 128 else 128            # conv_wgrad.hip plan()
+        K = kh * kw * cin
+        bn = 128 if K > 64 else (64 if (K > 32 or bm == 64) else 32)
+        PROFILE.append((f'conv_wgrad_f32_kernel<{bm},{bn}>', 2.0 * B * Ho * Wo * cout * cin * kh * kw, e0, e1,
+                        (B, H, W, cin, cout, kh, stride, 3)))
     return out
 
 
