@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Launch one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: conv_probe.py B H Cin Cout k s [reps] [modulate]"""
+"""Launch one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: conv_probe.py B H Cin Cout k s [reps] [modulate]
+PROBE_MODE=wgrad probes the weight-gradient kernel of the same layer instead."""
 import os
 import sys
 
@@ -16,6 +17,21 @@ d = torch.device('cuda')
 x = torch.randn(B, H, H, Cin, device=d)
 w = torch.randn(Cout, k * k * Cin, device=d) * 0.05
 b = torch.randn(Cout, device=d)
+if os.environ.get('PROBE_MODE') == 'wgrad':
+    Ho = ops.conv_out_size(H, k, s, k // 2)
+    dy = torch.randn(B, Ho, Ho, Cout, device=d)
+    for _ in range(reps):
+        ops.conv2d_wgrad_nhwc(x, dy, kh=k, kw=k, stride=s, pad=k // 2)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv2d_wgrad_nhwc(x, dy, kh=k, kw=k, stride=s, pad=k // 2)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / reps * 1e-3
+    print(f'wgrad B{B} {H}x{H} {Cin}->{Cout} k{k}s{s}: {t*1e6:.1f} us  {2.0 * B * Ho * Ho * Cout * Cin * k * k / t / 1e12:.1f} TFLOP/s')
+    sys.exit(0)
 kw = dict(a_chan_scale=torch.rand(B, Cin, device=d), a_pix_scale=torch.rand(B, H, H, device=d)) if mod else {}
 for _ in range(reps):
     y = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, stride=s, pad=k // 2, act='silu', **kw)

@@ -28,6 +28,7 @@
 //
 // Reference being replaced: F.conv2d + BatchNorm2d(eval) + SiLU in Conv.forward (models/common.py:64-70,
 // folded as utils/torch_utils.py:202-222), ODConv2d_3rd's grouped per-sample conv (models/common.py:4602-4605).
+#include <stdlib.h>
 #include "common.h"
 
 namespace somi {
@@ -73,7 +74,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
                                               const RowMap &rm, int m0, int n0) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int SLD = WN + 4;
-    static_assert(4 * WM * SLD <= 2 * (BM + BN) * LDS_LD, "epilogue staging does not fit the operand buffers");
+    static_assert(WAVES_M * WAVES_N * WM * SLD <= 2 * (BM + BN) * LDS_LD, "epilogue staging does not fit the operand buffers");
     const somi_conv_desc &d = a.d;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -141,12 +142,13 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned of
 // FAST: Cin % 32 == 0 (every K-tile lies inside one filter tap), kh*kw <= 32: the tap walk is wave-uniform (SALU), each
 // row's padding test is one bit of a mask built once, and a fetch costs 4 VALU per 16 B.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N / 2) void conv_igemm_f32_kernel(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
-    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;     // 16 B loads per thread per K-tile (activations / weights)
+    constexpr int NT = WAVES_M * WAVES_N * 64, RPP = NT / 8;   // threads; rows fetched per pass (8 threads x 16 B cover a row's K-tile)
+    constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;   // 16 B loads per thread per K-tile (activations / weights)
     constexpr int TILE = (BM + BN) * LDS_LD;
-    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tiling");
+    static_assert((WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8) && TM >= 1 && TN >= 1 && A_ROWS >= 1 && B_ROWS >= 1, "bad tiling");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
 
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
         for (int i = 0; i < A_ROWS; ++i) a_par[i] = 0;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const int m = m0 + row0 + 32 * i;
+            const int m = m0 + row0 + RPP * i;
             if (m < Mrows) {
                 const int b = m / HoWo + bz, rem = m % HoWo;
                 const int ho = h0 + (rem / Wc) * cstep, wo = w0 + (rem % Wc) * cstep;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
         unsigned b_off[B_ROWS];
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
-            const int n = n0 + row0 + 32 * i;
+            const int n = n0 + row0 + RPP * i;
             b_off[i] = n < d.Cout ? (unsigned)(((size_t)bz * d.Cout + n) * a.K + kc) * 4u : (FAST ? OOB_BASE : OOB);
         }
         // FAST path state: per-row tap-validity masks and byte offsets with the thread's column folded in
@@ -322,10 +324,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
         auto store_tile = [&](float *buf) {
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i)
-                *reinterpret_cast<f32x4 *>(&buf[(row0 + 32 * i) * LDS_LD + kc]) = ra[i];
+                *reinterpret_cast<f32x4 *>(&buf[(row0 + RPP * i) * LDS_LD + kc]) = ra[i];
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i)
-                *reinterpret_cast<f32x4 *>(&buf[(BM + row0 + 32 * i) * LDS_LD + kc]) = rb[i];
+                *reinterpret_cast<f32x4 *>(&buf[(BM + row0 + RPP * i) * LDS_LD + kc]) = rb[i];
         };
 
         f32x16 acc[TN][TM];
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) slot[((jn * TM + i) * 16 + e) * 256 + tid] = acc[jn][i][e];
+                    for (int e = 0; e < 16; ++e) slot[((jn * TM + i) * 16 + e) * NT + tid] = acc[jn][i][e];
         }
         __syncthreads();                                              // the epilogue staging / LDS buffers are reused by the next piece
     }
@@ -393,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvArgs a
 // Stream-K fix-up: workgroup j looks at the boundary between the runs of workgroups j and j+1; if it cuts a tile and is the
 // first cut inside that tile, it adds the tile's pieces in ascending workgroup order and runs the epilogue.
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void conv_streamk_fixup_kernel(const ConvArgs a, int G) {
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N / 2) void conv_streamk_fixup_kernel(const ConvArgs a, int G) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32, NT = WAVES_M * WAVES_N * 64;
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
     const int nkt = a.K / BK, ntile = a.tiles_m * a.tiles_n;
     const long U = (long)ntile * nkt;
@@ -423,17 +425,17 @@ __global__ __launch_bounds__(256, 2) void conv_streamk_fixup_kernel(const ConvAr
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[jn][i][e] += slot[((jn * TM + i) * 16 + e) * 256 + tid];
+                for (int e = 0; e < 16; ++e) acc[jn][i][e] += slot[((jn * TM + i) * 16 + e) * NT + tid];
     }
     const RowMap rmap = {a.M, a.d.Ho * a.d.Wo, a.d.Wo, 1, 0, 0, 0, false};
     conv_epilogue<BM, BN, WAVES_M, WAVES_N>(acc, lds, a, rmap, (tile / a.tiles_n) * BM, (tile % a.tiles_n) * BN);
 }
 
 struct TilePlan {
-    int variant;   // 0: 128x128, 1: 64x128, 2: 128x64, 3: 128x32
+    int variant;   // 0: 128x128, 1: 64x128, 2: 128x64, 3: 128x32, 4: 128x128 with 8 waves (2 per SIMD and workgroup)
     bool sk;       // stream-K schedule
 };
-static const int kTileBM[4] = {128, 64, 128, 128}, kTileBN[4] = {128, 128, 64, 32};
+static const int kTileBM[5] = {128, 64, 128, 128, 128}, kTileBN[5] = {128, 128, 64, 32, 128};
 
 static bool fast_path(const somi_conv_desc &d) {
     return d.Cin % BK == 0 && d.kh * d.kw <= 32 && (size_t)d.kh * d.kw * d.Cin * 4 < (1u << 27);
@@ -453,6 +455,8 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
     } else {
         p.variant = d.Cout > 32 ? 2 : 3;
     }
+    static const int eight = getenv("SOMI_CONV_8WAVE") ? atoi(getenv("SOMI_CONV_8WAVE")) : 1;
+    if (eight && p.variant == 0) p.variant = 4;
     if (sk_ok) {
         const int bm = kTileBM[p.variant], bn = kTileBN[p.variant];
         const long ntile = (long)cdiv(M, bm) * cdiv(d.Cout, bn), nkt = (long)d.kh * d.kw * d.Cin / BK;
@@ -477,15 +481,15 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
     args.tiles_n = cdiv(a.d.Cout, BN);
     const dim3 grid(sk ? SK_GRID : args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
     if (mod && fast)
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(256), 0, s, args);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     else if (mod)
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, false>), grid, dim3(256), 0, s, args);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, false>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     else if (fast)
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, dim3(256), 0, s, args);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     else
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, dim3(256), 0, s, args);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     if (sk)
-        hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(SK_GRID - 1), dim3(256), 0, s, args, SK_GRID);
+        hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(SK_GRID - 1), dim3(WAVES_M * WAVES_N * 64), 0, s, args, SK_GRID);
     return launch_status("somi_conv2d_nhwc_f32");
 }
 
@@ -540,6 +544,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
         case 0: return launch<128, 128, 2, 2>(a, tp.sk, s);
         case 1: return launch<64, 128, 1, 4>(a, tp.sk, s);
         case 2: return launch<128, 64, 2, 2>(a, tp.sk, s);
+        case 4: return launch<128, 128, 2, 4>(a, tp.sk, s);
         default: return launch<128, 32, 4, 1>(a, tp.sk, s);
     }
 }
@@ -574,7 +579,7 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
     const int M = dp->per_sample_w ? dp->Ho * dp->Wo : dp->B * dp->Ho * dp->Wo;
     const int mod = (dp->a_chan_scale || dp->a_pix_scale) ? 1 : 0;
     const int fast = (dp->Cin % somi::BK == 0 && dp->kh * dp->kw <= 32) ? 1 : 0;
-    static const char *tiles[4] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1"};
+    static const char *tiles[5] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1", "128,128,2,4"};
     static thread_local char name[96];
     snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::plan_tiles(*dp, M, 0).variant], mod ? "true" : "false",
              fast ? "true" : "false");

@@ -37,9 +37,10 @@ __device__ __forceinline__ f32x4 wbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned o
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
-template <int BM, int BN>   // co rows x k columns per tile: 128 x {128,64,32} or 64 x {128,64}
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs a) {
-    constexpr int WAVES_N = BM == 64 ? 2 : (BN == 128 ? 2 : 1), WAVES_M = 4 / WAVES_N;
+template <int BM, int BN, int NW = 4>   // co rows x k columns per tile: 128 x {128,64,32} or 64 x {128,64}; NW waves (8: 128 x 128 only)
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const WgradArgs a) {
+    constexpr int NT = NW * 64;
+    constexpr int WAVES_N = NW == 8 ? 4 : (BM == 64 ? 2 : (BN == 128 ? 2 : 1)), WAVES_M = NW / WAVES_N;
     static_assert(BM / WAVES_M >= 32 && BN / WAVES_N >= 32, "bad wgrad tiling");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_LD = BM, B_LD = BN;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
 
     // fetch geometry.  A (dy): 32 pixels x BM floats = BM/4 quads per pixel.  thread -> (pixel row, quad), rows strided.
     constexpr int A_QUADS = BM / 4, B_QUADS = BN / 4;
-    constexpr int A_ROWS_PER_PASS = 256 / A_QUADS, B_ROWS_PER_PASS = 256 / B_QUADS;      // 8 ; 8,16,32
+    constexpr int A_ROWS_PER_PASS = NT / A_QUADS, B_ROWS_PER_PASS = NT / B_QUADS;        // 8 ; 8,16,32 (4 waves)
     const int a_quad = tid % A_QUADS, a_row0 = tid / A_QUADS;
     const int b_quad = tid % B_QUADS, b_row0 = tid / B_QUADS;
     const int b_col = k0 + b_quad * 4;                                    // this thread's column quad: one tap, 4 channels
@@ -87,20 +88,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradArgs 
         bwo[i] = rem % a.Wo;
     }
     f32x4 ra[A_N], rb[B_N];
+    // all offsets are 32-bit: both tensors fit their 4 GiB buffer descriptors (checked by the launcher)
+    const unsigned set_p0 = (unsigned)(set_pix0 + p_lo);                  // first pixel of this split in the flattened order
+    const unsigned a_col = (unsigned)(a.dy_coff + co0 + a_quad * 4), b_colo = (unsigned)(a.x_coff + b_ci);
+    const int npl = p_hi - p_lo;
     auto fetch = [&](int pt) {                                            // pt = first pixel (inside the split) of the K-tile
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
             const int pl = pt + a_row0 + i * A_ROWS_PER_PASS;
-            const bool ok = a_col_ok && p_lo + pl < p_hi;
-            const unsigned off = (unsigned)(((set_pix0 + p_lo + pl) * a.dy_cs + a.dy_coff + co0 + a_quad * 4) * 4);
+            const bool ok = a_col_ok && pl < npl;
+            const unsigned off = ((set_p0 + (unsigned)pl) * (unsigned)a.dy_cs + a_col) * 4u;
             ra[i] = wbuf_load4(rdy, ok ? off : W_OOB);
         }
 #pragma unroll
         for (int i = 0; i < B_N; ++i) {
             const int pl = pt + b_row0 + i * B_ROWS_PER_PASS;
             const int hi = bho[i] * a.stride - a.pad + r, wi = bwo[i] * a.stride - a.pad + q;
-            const bool ok = b_col_ok && p_lo + pl < p_hi && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const unsigned off = (unsigned)((((long)(bb[i] * a.H + hi) * a.W + wi) * a.x_cs + a.x_coff + b_ci) * 4);
+            const bool ok = b_col_ok && pl < npl && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const unsigned off = ((unsigned)((bb[i] * a.H + hi) * a.W + wi) * (unsigned)a.x_cs + b_colo) * 4u;
             rb[i] = wbuf_load4(rx, ok ? off : W_OOB);
         }
     };
@@ -279,7 +284,9 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     a.out = direct ? dw : static_cast<float *>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid(a.tiles_co * a.tiles_k * a.splits, 1, sets);
-    if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, s, a);
+    static const int eight = getenv("SOMI_WGRAD_8WAVE") ? atoi(getenv("SOMI_WGRAD_8WAVE")) : 1;
+    if (a.bm == 128 && a.bn == 128 && eight) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8>), grid, dim3(512), 0, s, a);
+    else if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128 && a.bn == 64) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, s, a);
     else if (a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 128>), grid, dim3(256), 0, s, a);
