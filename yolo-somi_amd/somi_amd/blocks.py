@@ -72,6 +72,41 @@ def _acc_grad(param, g):
         param.grad.add_(g)
 
 
+def _grad_target(param):
+    """Buffer a backward kernel may accumulate into directly: the parameter's gradient when it is a contiguous fp32 tensor
+    (the optimizer's flat views are), else a zero scratch that the caller adds with _acc_grad.  -> (buffer, is_scratch)"""
+    g = param.grad
+    if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+        return g, False
+    return torch.zeros_like(param, dtype=torch.float32), True
+
+
+_NBT_PENDING = None      # Model.forward collects the BatchNorm step counters here and bumps them with one multi-tensor add
+
+
+def _bump_batches_tracked(bn):
+    if _NBT_PENDING is not None:
+        _NBT_PENDING.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
+class collect_batches_tracked:
+    """Context manager: BatchNorm step counters touched inside are incremented together on exit."""
+
+    def __enter__(self):
+        global _NBT_PENDING
+        self.outer, _NBT_PENDING = _NBT_PENDING, []
+        return self
+
+    def __exit__(self, *exc):
+        global _NBT_PENDING
+        pending, _NBT_PENDING = _NBT_PENDING, self.outer
+        if pending and exc[0] is None:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
 def _act_name(m):
     if isinstance(m, nn.SiLU):
         return 'silu'
@@ -154,7 +189,7 @@ class Conv(_Packed):
             if not pk['inplace']:
                 self.bn.running_mean.copy_(pk['rm'][:c2])
                 self.bn.running_var.copy_(pk['rv'][:c2])
-            self.bn.num_batches_tracked += 1
+            _bump_batches_tracked(self.bn)
         if out is None:
             out = new_act(x.t, Ho, Wo, c2)
         elif c2 % 4:
@@ -293,11 +328,13 @@ class ChannelAttentionModule(_Packed):
     def backward(self, dca, dt):
         """dca (B,C): gradient w.r.t. the attention vector; adds the pooled-input gradient into dt (Act) in place."""
         x, avg, mx, ca, (W1, b1, W2, b2) = self.__dict__.pop('_ctx')
-        g = [torch.zeros_like(t) for t in (W1, b1, W2, b2)]
-        davg, dmax = ops.attn_mlp_backward(0, dca, ca, avg, mx, W1, b1, W2, g[0], g[1], g[2], g[3])
         l1, l2 = self.shared_MLP[0], self.shared_MLP[2]
-        for prm, gr in zip((l1.weight, l1.bias, l2.weight, l2.bias), g):
-            _acc_grad(prm, gr)
+        prms = (l1.weight, l1.bias, l2.weight, l2.bias)
+        g = [_grad_target(prm) for prm in prms]                  # the kernel accumulates; same layout as the parameters
+        davg, dmax = ops.attn_mlp_backward(0, dca, ca, avg, mx, W1, b1, W2, g[0][0], g[1][0], g[2][0], g[3][0])
+        for prm, (gr, scratch) in zip(prms, g):
+            if scratch:
+                _acc_grad(prm, gr)
         amaxp = ops.pool_argmax(x.t, x.c, x.coff)
         ops.pool_backward_add_(dt.t, dt.coff, x.c, davg, dmax, amaxp)
 
@@ -550,7 +587,7 @@ class ODConv_3rd(_Packed):
             with torch.no_grad():
                 cv.bn.running_mean.copy_(rm)
                 cv.bn.running_var.copy_(rv)
-                cv.bn.num_batches_tracked += 1
+                _bump_batches_tracked(cv.bn)
         else:
             st = (zero, one, one, zero)
         z = ops.chan_affine_act(zpre.view(B, 1, 1, hid), hid, 0, st[2], st[3], 'relu', 0, torch.empty(B, 1, 1, hid, device=dev)).view(B, hid)
@@ -570,7 +607,7 @@ class ODConv_3rd(_Packed):
         with torch.no_grad():
             self.bn.running_mean.copy_(rm)
             self.bn.running_var.copy_(rv)
-            self.bn.num_batches_tracked += 1
+            _bump_batches_tracked(self.bn)
         out = torch.empty_like(y)
         ops.chan_affine_act(y, cout, 0, so[2], so[3], _act_name(self.act), 0, out)
         self.__dict__['_ctx'] = (x, gap, fcw, zpre, st, z, attn, heads, Wk, biask, wout, y, so)
@@ -720,7 +757,7 @@ class SEAM(_Packed):
         with torch.no_grad():
             bn.running_mean.copy_(rm)
             bn.running_var.copy_(rv)
-            bn.num_batches_tracked += 1
+            _bump_batches_tracked(bn)
         z = ops.chan_affine_act(g, c, 0, scale, shift, 'none', 0, g)
         return z, (mean, rstd, scale, shift)
 

@@ -216,11 +216,12 @@ class Model(nn.Module):
             raise RuntimeError(f'expected a (B,3,H,W) batch, got {tuple(x.shape)}')
         a = B.Act(ops.image_to_nhwc4(x.contiguous(), scale=1.0 / 255.0 if x.dtype == torch.uint8 else 1.0), 0, 3)
         y = []
-        for m in self.model:
-            if m.f != -1:
-                a = y[m.f] if isinstance(m.f, int) else [a if j == -1 else y[j] for j in m.f]
-            a = m(a)
-            y.append(a if m.i in self.save else None)
+        with B.collect_batches_tracked():                         # one multi-tensor add for all BatchNorm step counters
+            for m in self.model:
+                if m.f != -1:
+                    a = y[m.f] if isinstance(m.f, int) else [a if j == -1 else y[j] for j in m.f]
+                a = m(a)
+                y.append(a if m.i in self.save else None)
         if self.training:
             return list(_ModelGraph.apply(self._anchor(x.device), self, *a))
         return a

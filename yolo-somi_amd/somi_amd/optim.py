@@ -101,9 +101,21 @@ class FusedAdamEMA:
                       ema=fp.data.clone() if ema else None)
             self._flat.append(st)
             self.param_groups.append(dict(params=plist, lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=wd))
-        # float buffers (BN running statistics) for the EMA of non-parameter state
-        self._bufs = [b for b in model.buffers() if b.dtype.is_floating_point and b.numel() > 0 and 'anchor' not in ''] if ema else []
-        self._buf_ema = [b.detach().clone() for b in self._bufs]
+        # float buffers (BN running statistics): re-homed into one flat buffer as well, so their EMA is one launch
+        self._buf_owner = []
+        for mod in model.modules():
+            for name, b in mod._buffers.items():
+                if b is not None and b.dtype.is_floating_point and b.numel() > 0 and b.device == dev:
+                    self._buf_owner.append((mod, name))
+        bufs = [getattr(mod, name) for mod, name in self._buf_owner]
+        self._bflat = _Flat(bufs, dev)
+        with torch.no_grad():
+            for i, (mod, name) in enumerate(self._buf_owner):
+                v = self._bflat.view_of(i)
+                v.copy_(bufs[i])
+                setattr(mod, name, v)                             # still a registered buffer, now a view of the flat storage
+        self._bflat.tensors = [getattr(mod, name) for mod, name in self._buf_owner]
+        self._buf_ema = self._bflat.data.clone() if ema else None
         self.ema_decay, self.updates, self.steps = ema_decay, 0, 0
         if hasattr(model, 'invalidate'):
             model.invalidate()
@@ -118,6 +130,8 @@ class FusedAdamEMA:
         for st in self._flat:
             if st['ema'] is not None:
                 st['ema'].copy_(st['p'].data)
+        if self._buf_ema is not None:
+            self._buf_ema.copy_(self._bflat.data)
 
     @property
     def flat_grads(self):
@@ -141,9 +155,9 @@ class FusedAdamEMA:
             check(L.somi_adam_ema_step_f32(_ptr(st['p'].data), _ptr(st['g'].data), _ptr(st['m']), _ptr(st['v']), _ptr(st['ema']), st['p'].n_pad,
                                            float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']),
                                            float(grp['weight_decay']), self.steps, float(d if d is not None else 0.0), _stream()), 'adam_ema_step')
-        if d is not None:
-            for b, e in zip(self._bufs, self._buf_ema):
-                check(L.somi_axpby_f32(_ptr(e), _ptr(b.detach().float().contiguous()), e.numel(), float(d), float(1 - d), _stream()), 'ema buffers')
+        if d is not None and self._buf_ema is not None and self._bflat.n > 0:
+            check(L.somi_axpby_f32(_ptr(self._buf_ema), _ptr(self._bflat.data), self._bflat.n_pad, float(d), float(1 - d), _stream()),
+                  'ema buffers')
         if hasattr(self.model, 'invalidate'):
             self.model.invalidate()
 
@@ -156,9 +170,11 @@ class FusedAdamEMA:
                 continue
             for i, p in enumerate(st['p'].tensors):
                 sd[name_of[id(p)]] = st['p'].view_of(i, st['ema']).clone()
-        bname = {id(b): n for n, b in self.model.named_buffers()}
-        for b, e in zip(self._bufs, self._buf_ema):
-            sd[bname[id(b)]] = e.clone()
+        if self._buf_ema is not None:
+            mname = {id(m): n for n, m in self.model.named_modules()}
+            for i, (mod, name) in enumerate(self._buf_owner):
+                prefix = mname[id(mod)]
+                sd[(prefix + '.' if prefix else '') + name] = self._bflat.view_of(i, self._buf_ema).clone()
         return sd
 
 
