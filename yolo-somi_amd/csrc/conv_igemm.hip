@@ -435,7 +435,7 @@ struct TilePlan {
     int variant;   // 0: 128x128, 1: 64x128, 2: 128x64, 3: 128x32, 4: 128x128 with 8 waves (2 per SIMD and workgroup)
     bool sk;       // stream-K schedule
 };
-static const int kTileBM[5] = {128, 64, 128, 128, 128}, kTileBN[5] = {128, 128, 64, 32, 128};
+static const int kTileBM[6] = {128, 64, 128, 128, 128, 128}, kTileBN[6] = {128, 128, 64, 32, 128, 64};
 
 static bool fast_path(const somi_conv_desc &d) {
     return d.Cin % BK == 0 && d.kh * d.kw <= 32 && (size_t)d.kh * d.kw * d.Cin * 4 < (1u << 27);
@@ -455,8 +455,9 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
     } else {
         p.variant = d.Cout > 32 ? 2 : 3;
     }
-    static const int eight = getenv("SOMI_CONV_8WAVE") ? atoi(getenv("SOMI_CONV_8WAVE")) : 1;
+    static const int eight = getenv("SOMI_CONV_8WAVE") ? atoi(getenv("SOMI_CONV_8WAVE")) : 2;
     if (eight && p.variant == 0) p.variant = 4;
+    if (eight > 1 && p.variant == 2) p.variant = 5;
     if (sk_ok) {
         const int bm = kTileBM[p.variant], bn = kTileBN[p.variant];
         const long ntile = (long)cdiv(M, bm) * cdiv(d.Cout, bn), nkt = (long)d.kh * d.kw * d.Cin / BK;
@@ -545,6 +546,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
         case 1: return launch<64, 128, 1, 4>(a, tp.sk, s);
         case 2: return launch<128, 64, 2, 2>(a, tp.sk, s);
         case 4: return launch<128, 128, 2, 4>(a, tp.sk, s);
+        case 5: return launch<128, 64, 4, 2>(a, tp.sk, s);
         default: return launch<128, 32, 4, 1>(a, tp.sk, s);
     }
 }
@@ -579,7 +581,7 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
     const int M = dp->per_sample_w ? dp->Ho * dp->Wo : dp->B * dp->Ho * dp->Wo;
     const int mod = (dp->a_chan_scale || dp->a_pix_scale) ? 1 : 0;
     const int fast = (dp->Cin % somi::BK == 0 && dp->kh * dp->kw <= 32) ? 1 : 0;
-    static const char *tiles[5] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1", "128,128,2,4"};
+    static const char *tiles[6] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1", "128,128,2,4", "128,64,4,2"};
     static thread_local char name[96];
     snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::plan_tiles(*dp, M, 0).variant], mod ? "true" : "false",
              fast ? "true" : "false");

@@ -284,11 +284,12 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     a.out = direct ? dw : static_cast<float *>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid(a.tiles_co * a.tiles_k * a.splits, 1, sets);
-    static const int eight = getenv("SOMI_WGRAD_8WAVE") ? atoi(getenv("SOMI_WGRAD_8WAVE")) : 1;
+    static const int eight = getenv("SOMI_WGRAD_8WAVE") ? atoi(getenv("SOMI_WGRAD_8WAVE")) : 2;
     if (a.bm == 128 && a.bn == 128 && eight) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8>), grid, dim3(512), 0, s, a);
     else if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128 && a.bn == 64) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, s, a);
+    else if (a.bn == 128 && eight > 1) hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 128, 8>), grid, dim3(512), 0, s, a);
     else if (a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 128>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 64>), grid, dim3(256), 0, s, a);
     if (!direct) {

@@ -311,7 +311,8 @@ def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cou
         bm = 64 if -(-cout // 64) * 64 < -(-cout // 128) * 128 else 128            # conv_wgrad.hip plan()
         K = kh * kw * cin
         bn = 128 if K > 64 else (64 if (K > 32 or bm == 64) else 32)
-        nw = 8 if (bm, bn) == (128, 128) and os.environ.get('SOMI_WGRAD_8WAVE', '1') != '0' else 4
+        eight = int(os.environ.get('SOMI_WGRAD_8WAVE', '2'))
+        nw = 8 if ((bm, bn) == (128, 128) and eight >= 1) or ((bm, bn) == (64, 128) and eight >= 2) else 4
         PROFILE.append((f'conv_wgrad_f32_kernel<{bm},{bn},{nw}>', 2.0 * B * Ho * Wo * cout * cin * kh * kw, e0, e1,
                         (B, H, W, cin, cout, kh, stride, 3)))
     return out
