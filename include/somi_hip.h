@@ -366,6 +366,15 @@ size_t somi_loss_workspace_bytes(const somi_loss_desc *d);
 int somi_yolo_loss_f32(const somi_loss_desc *d, float *out4, void *workspace, size_t workspace_bytes,
                        somi_stream_t stream);
 
+/* Repulsion loss, RepGT + RepBox (utils/RepulsionLoss.py:47-95; imported by utils/loss.py:8 but never called by ComputeLoss,
+ * so it is an optional term and off by default).  pbox, gtbox: (B,A,4) xyxy; fg_mask: (B,A) bytes (non-zero = foreground).
+ * Value only - the reference detaches both box sets.  out2 = {rep_gt, rep_box}, each the mean over the images that have
+ * foreground anchors (0/0 = NaN when none has, like the reference). */
+size_t somi_repulsion_workspace_bytes(int B, int A);
+int somi_repulsion_loss_f32(const float *pbox, const float *gtbox, const uint8_t *fg_mask, int B, int A, float sigma_repgt,
+                            float sigma_repbox, float pnms, float gtnms, float *out2, void *workspace, size_t workspace_bytes,
+                            somi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Weighted boxes fusion (wbf.py:68 -> ensemble_boxes.weighted_boxes_fusion, conf_type 'avg').
  * boxes (n,4) xyxy in [0,1], scores (n), labels (n) int32, model (n) int32, already concatenated over models

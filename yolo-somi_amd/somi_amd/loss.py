@@ -91,3 +91,23 @@ class ComputeLoss:
         if need_grad:
             loss = _AttachGrad.apply(loss, grads, *p)
         return loss, out[1:4].detach()
+
+
+def repulsion_loss(pbox, gtbox, fg_mask, sigma_repgt=0.9, sigma_repbox=0, pnms=0, gtnms=0):
+    """RepGT + RepBox with the signature of utils/RepulsionLoss.py:47 -> (rep_gt, rep_box) 0-d GPU tensors.  The reference
+    imports this term but never adds it to the loss (utils/loss.py:8); it is provided the same way: optional, value only."""
+    if not (pbox.is_cuda and gtbox.is_cuda and fg_mask.is_cuda):
+        raise RuntimeError('repulsion_loss runs on GPU tensors only (no CPU fallback)')
+    if pbox.dim() != 3 or pbox.shape[-1] != 4 or gtbox.shape != pbox.shape or fg_mask.shape != pbox.shape[:2]:
+        raise RuntimeError('repulsion_loss expects pbox, gtbox (B,A,4) and fg_mask (B,A)')
+    Bn, A = fg_mask.shape
+    pb, gb = pbox.detach().float().contiguous(), gtbox.detach().float().contiguous()
+    fg = fg_mask.to(torch.uint8).contiguous()
+    out = torch.empty(2, device=pbox.device, dtype=torch.float32)
+    L = _lib.lib()
+    nbytes = L.somi_repulsion_workspace_bytes(Bn, A)
+    ws = torch.empty(nbytes, device=pbox.device, dtype=torch.uint8)
+    check(L.somi_repulsion_loss_f32(pb.data_ptr(), gb.data_ptr(), fg.data_ptr(), Bn, A, float(sigma_repgt), float(sigma_repbox),
+                                    float(pnms), float(gtnms), out.data_ptr(), ws.data_ptr(), nbytes,
+                                    torch.cuda.current_stream().cuda_stream), 'repulsion_loss')
+    return out[0], out[1]
