@@ -108,3 +108,25 @@ def test_dcnv3_module_helpers():
     a, b, lg = torch.randn(2, 9, 7, 64, generator=g), torch.randn(2, 9, 7, 64, generator=g), torch.randn(2, 9, 7, 4, generator=g)
     s = torch.sigmoid(lg)[..., None].repeat(1, 1, 1, 1, 16).flatten(-2)
     rel_close(ops.cfs_blend(a.cuda(), b.cuda(), lg.cuda(), 4, 16), a * (1 - s) + b * s, rel=1e-5, what='cfs blend')
+
+
+@pytest.mark.parametrize('N,H,W,G,Gc,k,s,p,d,spread', [(2, 40, 40, 8, 32, 3, 1, 1, 1, 1.0),      # SOMI-like
+                                                       (2, 37, 29, 4, 16, 3, 1, 1, 1, 12.0),     # offsets far beyond the kernel footprint / the image
+                                                       (3, 21, 17, 4, 24, 3, 2, 1, 1, 3.0),      # stride 2, ragged tiles
+                                                       (1, 16, 16, 16, 4, 3, 1, 2, 2, 2.0),      # dilation 2, one lane per group
+                                                       (2, 19, 23, 2, 64, 5, 1, 2, 1, 2.5)])     # 5x5
+def test_dcnv3_forward_wide_offsets(N, H, W, G, Gc, k, s, p, d, spread):
+    """Forward against the CPU oracle at 1e-5 with offsets from well inside one pixel to far outside the image (most taps
+    clipped), stride 2 with ragged tiles, dilation 2 with one lane per group, and a 5x5 kernel."""
+    from oracle.somi_ref import dcnv3 as O
+    from somi_amd.dcnv3 import dcnv3_forward
+    g = torch.Generator().manual_seed(H * 31 + W)
+    Ho, Wo = O.dcnv3_out_size(H, k, s, p, d), O.dcnv3_out_size(W, k, s, p, d)
+    K = k * k
+    x = torch.randn(N, H, W, G * Gc, generator=g)
+    off = torch.randn(N, Ho, Wo, G * K * 2, generator=g) * spread
+    m = torch.softmax(torch.randn(N, Ho, Wo, G, K, generator=g), -1).reshape(N, Ho, Wo, G * K)
+    want = O.dcnv3_core(x, off, m, k, k, s, s, p, p, d, d, G, Gc, 1.7)
+    dev = torch.device('cuda:0')
+    got = dcnv3_forward(x.to(dev), off.to(dev), m.to(dev), k, k, s, s, p, p, d, d, G, Gc, 1.7, 256)
+    rel_close(got, want, rel=1e-5, what='forward')

@@ -108,7 +108,22 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const DcnArgs a) {
         const Rec *rr = recs + (pl * a.G + g) * a.K;
         if constexpr (VEC == 4) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < a.K; ++k) {
+            int k = 0;
+            for (; k + 3 <= a.K; k += 3) {                                 // 3 points = 12 gathers in flight; summation order unchanged
+                const i32x4 o0 = rr[k].off, o1 = rr[k + 1].off, o2 = rr[k + 2].off;
+                const f32x4 f0 = rr[k].f, f1 = rr[k + 1].f, f2 = rr[k + 2].f;
+                f32x4 u[12];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    u[t] = *reinterpret_cast<const f32x4 *>(src + o0[t]);
+                    u[4 + t] = *reinterpret_cast<const f32x4 *>(src + o1[t]);
+                    u[8 + t] = *reinterpret_cast<const f32x4 *>(src + o2[t]);
+                }
+                acc += f0[0] * u[0] + f0[1] * u[1] + f0[2] * u[2] + f0[3] * u[3];
+                acc += f1[0] * u[4] + f1[1] * u[5] + f1[2] * u[6] + f1[3] * u[7];
+                acc += f2[0] * u[8] + f2[1] * u[9] + f2[2] * u[10] + f2[3] * u[11];
+            }
+            for (; k < a.K; ++k) {
                 const i32x4 o = rr[k].off;
                 const f32x4 f = rr[k].f;
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + o[0]);
