@@ -121,13 +121,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the product path has no CPU fallback)')
+    backend = os.environ.get('SOMI_DIST_BACKEND', 'nccl')     # 'gloo' + several ranks on one GPU = rehearsal on a 1-GPU box only
+    if backend != 'nccl':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)          # RCCL
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI, one GPU per rank
+        else:
+            dist.init_process_group(backend)
 
     from somi_amd import ops
     from somi_amd.model import Model

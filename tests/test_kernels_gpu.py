@@ -133,6 +133,28 @@ def test_conv_streamk_matches_tile_schedule():
     rel_close(y1, y0, rel=1e-5, what='stream-K vs one workgroup per tile')
 
 
+def test_conv_wgrad_accumulates_with_a_single_split():
+    """Tiny layers run the weight gradient as one pixel split; accumulating into an existing gradient then still goes through the
+    workspace (regression: the workspace query used to return 256 bytes for that case)."""
+    from somi_amd import ops
+    g = torch.Generator().manual_seed(3)
+    d = dev()
+    B, H, W, Cin, Cout, k = 2, 8, 8, 16, 32, 3
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g, requires_grad=True)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    from somi_amd.pack import pack_conv_weight
+    want = pack_conv_weight(w.grad, cin_pad=Cin)
+    base = torch.randn(Cout, k * k * Cin, generator=g)
+    acc = base.clone().to(d)
+    guard = torch.full((1 << 20,), 7.0, device=d)              # allocated right after: an overrun of a short workspace lands here
+    ops.conv2d_wgrad_nhwc(nhwc(x.detach()).to(d), nhwc(dy).to(d), kh=k, kw=k, stride=1, pad=1, out=acc, accumulate=acc)
+    torch.cuda.synchronize()
+    rel_close(acc, want + base, what='wgrad accumulate, one split')
+    assert (guard == 7.0).all()
+
+
 def test_conv_rejects_bad_arguments():
     from somi_amd import ops
     d = dev()

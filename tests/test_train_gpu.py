@@ -362,3 +362,64 @@ def test_fused_adam_packed_conv_masters():
     assert esd['0.conv.weight'].shape == ref[0].conv.weight.shape
     mine.zero_grad()
     assert all(float(q.grad.abs().max()) == 0.0 for q in net.parameters())
+
+
+def test_train_step_with_optimizer_matches_oracle_adam():
+    """Two whole TrainStep.step() calls on the small SOMI graph (tiny layers: single-split weight gradients accumulated into the
+    packed gradient masters) against the CPU oracle driven by torch.optim.Adam with the reference's parameter groups.
+    Adam's first updates are lr*sign(g) for every weight, so a weight whose gradient is rounding noise may move the other
+    way: the bar is 2 steps x 2 lr absolute plus 1e-3 relative - layout or packing mistakes are orders of magnitude above it."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.loss import ComputeLoss as OLoss
+    from oracle.somi_ref.testing import fill_state, synthetic_batch, HYP_VISDRONE
+    from somi_amd.model import Model
+    from somi_amd.optim import reference_param_groups
+    from somi_amd.train import TrainStep
+    cfg = _train_cfg(False)
+    ref = fill_state(OModel(cfg), 4)
+    mine = Model(cfg)
+    mine.load_state_dict(ref.state_dict())
+    hyp = dict(HYP_VISDRONE)
+    ref.hyp = hyp
+    ref.train()
+    imgs, targets = synthetic_batch(2, 64, seed=5)
+    g0, g1, g2 = reference_param_groups(ref)
+    wd = hyp['weight_decay'] * 2 * 32 / 64                       # train.py:121-123 at batch 2: accumulate = 32
+    opt = torch.optim.Adam(g0, lr=3e-4, betas=(hyp['momentum'], 0.999))
+    opt.add_param_group({'params': g1, 'weight_decay': wd})
+    opt.add_param_group({'params': g2})
+    tr = TrainStep(mine.cuda(), hyp, 2)
+    crit = OLoss(ref)
+    losses = []
+    for _ in range(2):
+        lr_, _ = crit(ref(imgs.float() / 255), targets)
+        opt.zero_grad()
+        lr_.backward()
+        opt.step()
+        lm, _ = tr.step(imgs.cuda(), targets.cuda())
+        losses.append((float(lm), float(lr_.detach())))
+    assert abs(losses[0][0] - losses[0][1]) <= 1e-4 * abs(losses[0][1]), losses
+    assert abs(losses[1][0] - losses[1][1]) <= 1e-2 * abs(losses[1][1]), losses
+    bad = []
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        err = (p.detach().cpu() - q.detach()).abs().max().item()
+        if err > 4 * 3e-4 + 1e-3 * q.detach().abs().max().item():
+            bad.append((n, err))
+    assert not bad, bad[:8]
+    for (n, p), (_, q) in zip(mine.named_buffers(), ref.named_buffers()):
+        if 'running' in n:
+            rel_close(p, q, rel=2e-2, what=n)
+
+
+def test_data_parallel_rehearsal_two_ranks_one_gpu():
+    """tools/ddp_rehearsal.py: two ranks share this GPU (gloo), bucketed + stream-overlapped gradient exchange must equal the
+    per-parameter all-reduce of the rank-local gradients and leave identical weights on both ranks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29541', os.path.join(root, 'tools', 'ddp_rehearsal.py')], capture_output=True, text=True,
+                       timeout=420, env=env, cwd=root)
+    assert r.returncode == 0 and 'ddp rehearsal ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -260,8 +260,8 @@ using namespace somi;
 extern "C" size_t somi_conv2d_wgrad_workspace_bytes(const somi_conv_desc *fwd) {
     WgradArgs a{};
     if (!fwd || plan(*fwd, a)) return 0;
-    if (a.splits <= 1) return 256;
-    return (size_t)a.splits * (a.per_sample ? a.B : 1) * a.Cout * a.K * 4 + 256;
+    // also with a single split: accumulating on top of an existing gradient goes through the workspace + reduce pass
+    return (size_t)(a.splits < 1 ? 1 : a.splits) * (a.per_sample ? a.B : 1) * a.Cout * a.K * 4 + 256;
 }
 
 extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float *x, int x_cs, int x_coff, const float *dy, int dy_cs,

@@ -2,7 +2,7 @@
 
 Inference / NMS / WBF shard by image with no data-path collective ("replicas only"): each rank takes a
 contiguous slice of the global batch; the only communication is the barrier + max-over-ranks of the timed region that
-bench.py's contract asks for.  The gradient all-reduce (train.py:208-209) belongs to the training path (not built yet).
+bench.py's contract asks for.  The gradient all-reduce of the training path (train.py:208-209) is ddp.GradBuckets.
 """
 import time
 
