@@ -423,3 +423,21 @@ def test_data_parallel_rehearsal_two_ranks_one_gpu():
                         '--master-port', '29541', os.path.join(root, 'tools', 'ddp_rehearsal.py')], capture_output=True, text=True,
                        timeout=420, env=env, cwd=root)
     assert r.returncode == 0 and 'ddp rehearsal ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_train_step_gradient_accumulation():
+    """accumulate=2 (train.py:121,272): the first batch only accumulates gradients, the second steps the optimizer on the sum."""
+    from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch
+    from somi_amd.model import Model
+    from somi_amd.train import TrainStep
+    model = fill_state(Model(somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS)), 3).cuda()
+    tr = TrainStep(model, dict(HYP_VISDRONE), 2, accumulate=2)
+    imgs, targets = synthetic_batch(2, 64, seed=8)
+    w0 = [b.clone() for b in tr.optimizer.flat_params]
+    tr.step(imgs.cuda(), targets.cuda())
+    assert all(torch.equal(a, b) for a, b in zip(w0, tr.optimizer.flat_params)), 'weights moved before the accumulation was complete'
+    g1 = [g.clone() for g in tr.optimizer.flat_grads]
+    assert any(float(g.abs().max()) > 0 for g in g1)
+    tr.step(imgs.cuda(), targets.cuda())
+    assert any(not torch.equal(a, b) for a, b in zip(w0, tr.optimizer.flat_params)), 'no optimizer step after two batches'
+    assert all(float(g.abs().max()) == 0 for g in tr.optimizer.flat_grads)

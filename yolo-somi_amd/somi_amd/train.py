@@ -16,7 +16,9 @@ from .optim import build_optimizer
 
 
 class TrainStep:
-    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48):
+    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1):
+        """accumulate: optimizer step every `accumulate` batches (train.py:121,252,272: max(round(nbs / total_batch), 1) in the
+        reference loop; gradients simply keep accumulating in the flat buffers in between).  Default 1: every batch."""
         if not next(model.parameters()).is_cuda:
             raise RuntimeError('TrainStep runs on the MI355X only (no CPU fallback)')
         self.model, self.dist = model, dist
@@ -25,6 +27,7 @@ class TrainStep:
         model.train()
         self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True)
         self.compute_loss = ComputeLoss(model)
+        self.accumulate, self._since_step = max(int(accumulate), 1), 0
         self.buckets = None
         if self.world > 1:
             self.buckets = GradBuckets(self.optimizer.flat_grads, layer_offsets(model, self.optimizer), dist=dist,
@@ -46,6 +49,9 @@ class TrainStep:
         loss.backward()
         if self.buckets:
             self.buckets.finish()
-        self.optimizer.step()                                     # Adam + EMA, one pass
-        self.optimizer.zero_grad()
+        self._since_step += 1
+        if self._since_step >= self.accumulate:
+            self.optimizer.step()                                 # Adam + EMA, one pass
+            self.optimizer.zero_grad()
+            self._since_step = 0
         return loss.detach(), items
