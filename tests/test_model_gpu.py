@@ -63,3 +63,75 @@ def test_single_image_skips_odconv_bn():
     x = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
         rel_close(mine(x.cuda())[0], ref(x)[0], what='z (B=1, non-square)')
+
+
+def test_uavdt_config_1280_nc3():
+    """BASELINE configs[3] shape: full-width SOMI with nc=3 (UAVDT) at 1280x1280 - grids 320/160/80/40, 544 000 predictions per
+    image - one image against the CPU oracle, then NMS on all of them (selection bit-exact)."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.nms import non_max_suppression as oracle_nms
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg
+    from somi_amd.model import Model
+    from somi_amd.nms import non_max_suppression
+    cfg = somi_cfg(1.0, 1.0, nc=3, anchors=SOMI_ANCHORS)
+    ref = fill_state(OModel(cfg), 7).eval()
+    mine = Model(cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda().eval()
+    x = torch.rand(1, 3, 1280, 1280, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        zr, _ = ref(x)
+        z, _ = mine(x.cuda())
+    assert z.shape == (1, 544000, 8)
+    rel_close(z, zr, what='z @1280 nc=3')
+    det = non_max_suppression(z, 0.25, 0.45, multi_label=True)
+    want = oracle_nms(z.cpu(), 0.25, 0.45, multi_label=True)
+    assert det[0].shape == want[0].shape and torch.equal(det[0].cpu(), want[0])
+
+
+def test_val_config_bs128_nms_wbf():
+    """BASELINE configs[4] shape: inference at batch 128, 640x640, NMS + WBF over two models.  The CPU oracle checks the first two
+    images of each model; the rest of the batch is covered by properties that do not need the oracle: every image's
+    predictions equal (to fp32 rounding - the tile schedule depends on the batch) those of the same image run in a batch of 8,
+    NMS of the big batch equals NMS of its slices, and WBF of a model with itself keeps every cluster's label and box."""
+    import numpy as np
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.nms import non_max_suppression as oracle_nms
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch
+    from oracle.somi_ref.wbf import weighted_boxes_fusion as oracle_wbf
+    from somi_amd.model import Model
+    from somi_amd.nms import non_max_suppression
+    from somi_amd.wbf import weighted_boxes_fusion
+    cfg = somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS)
+    imgs, _ = synthetic_batch(128, 640, seed=21)
+    dets = []
+    for seed in (1, 2):                                          # two "models" for the fusion step (wbf.py:9-78)
+        ref = fill_state(OModel(cfg), seed).eval()
+        mine = Model(cfg)
+        mine.load_state_dict(ref.state_dict())
+        mine = mine.cuda().eval()
+        with torch.no_grad():
+            z, _ = mine(imgs.cuda())
+            z8, _ = mine(imgs[40:48].cuda())
+            zr, _ = ref(imgs[:2].float() / 255)
+        assert z.shape == (128, 136000, 15)
+        rel_close(z[:2], zr, what=f'model {seed}: first two images vs oracle')
+        rel_close(z[40:48], z8, rel=1e-5, what=f'model {seed}: batch 128 vs batch 8')
+        det = non_max_suppression(z, 0.4, 0.2, multi_label=True)                     # val.py:77-78 defaults
+        det8 = non_max_suppression(z[40:48].contiguous(), 0.4, 0.2, multi_label=True)
+        for a, b in zip(det[40:48], det8):
+            assert torch.equal(a, b)
+        want = oracle_nms(z[:2].cpu(), 0.4, 0.2, multi_label=True)
+        for a, b in zip(det[:2], want):
+            assert a.shape == b.shape and torch.equal(a.cpu(), b)
+        dets.append([d.cpu() for d in det])
+        del mine, z
+        torch.cuda.empty_cache()
+    for i in (0, 1, 77):                                          # fuse the two models' boxes of one image, like wbf.py:55-68
+        bl = [(d[i][:, :4] / 640).clamp(0, 1).numpy() for d in dets]
+        sl = [d[i][:, 4].numpy() for d in dets]
+        ll = [d[i][:, 5].numpy().astype(np.int64) for d in dets]
+        gb, gs, gl = weighted_boxes_fusion(bl, sl, ll, weights=None, iou_thr=0.67, skip_box_thr=0.01)
+        wb, ws, wl = oracle_wbf([b.tolist() for b in bl], [s.tolist() for s in sl], [l.tolist() for l in ll], weights=None,
+                                iou_thr=0.67, skip_box_thr=0.01)
+        assert np.array_equal(gl, wl) and np.array_equal(gb, wb.astype(np.float32)) and np.array_equal(gs, ws.astype(np.float32))

@@ -528,8 +528,30 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
     a.M = d.per_sample_w ? d.Ho * d.Wo : d.B * d.Ho * d.Wo;
     a.tiles_m = a.tiles_n = 0;
     const size_t xb = (size_t)d.B * d.H * d.W * d.x_cs * 4, wb = (size_t)(d.per_sample_w ? d.B : 1) * d.Cout * a.K * 4;
-    SOMI_REQUIRE(xb <= MAX_BUF_BYTES && wb <= MAX_BUF_BYTES, SOMI_ENOTIMPL,
-                 "conv: input (%zu B) or weights (%zu B) exceed the 4 GiB buffer-descriptor range; split the batch", xb, wb);
+    if (xb > MAX_BUF_BYTES || wb > MAX_BUF_BYTES) {
+        // the operands are fetched through 32-bit buffer descriptors: run the batch in slices that fit (images are independent rows)
+        const size_t per_img = (size_t)d.H * d.W * d.x_cs * 4, per_w = d.per_sample_w ? (size_t)d.Cout * a.K * 4 : 0;
+        SOMI_REQUIRE(per_img <= MAX_BUF_BYTES && (size_t)d.Cout * a.K * 4 <= MAX_BUF_BYTES, SOMI_ENOTIMPL,
+                     "conv: one image (%zu B) or one weight set exceeds the 4 GiB buffer-descriptor range", per_img);
+        size_t bsub = MAX_BUF_BYTES / per_img;
+        if (per_w && MAX_BUF_BYTES / per_w < bsub) bsub = MAX_BUF_BYTES / per_w;
+        for (int b0 = 0; b0 < d.B; b0 += (int)bsub) {
+            somi_conv_desc sub = d;
+            sub.B = d.B - b0 < (int)bsub ? d.B - b0 : (int)bsub;
+            sub.x = d.x + (size_t)b0 * d.H * d.W * d.x_cs;
+            sub.y = d.y + (size_t)b0 * d.Ho * d.Wo * d.y_cs;
+            if (d.residual) sub.residual = d.residual + (size_t)b0 * d.Ho * d.Wo * d.res_cs;
+            if (d.a_chan_scale) sub.a_chan_scale = d.a_chan_scale + (size_t)b0 * d.Cin;
+            if (d.a_pix_scale) sub.a_pix_scale = d.a_pix_scale + (size_t)b0 * d.H * d.W;
+            if (d.per_sample_w) {
+                sub.w = d.w + (size_t)b0 * d.Cout * a.K;
+                if (d.bias) sub.bias = d.bias + (size_t)b0 * d.Cout;
+            }
+            const int rc = conv_launch(&sub, stream, dgrad);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
     a.chan_bytes = (unsigned)((size_t)d.B * d.Cin * 4);

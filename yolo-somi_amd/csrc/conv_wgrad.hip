@@ -276,7 +276,21 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     SOMI_REQUIRE(x_coff + a.Cin <= x_cs && dy_coff + a.Cout <= dy_cs, SOMI_EINVAL, "conv wgrad: channel slice out of range");
     SOMI_REQUIRE(workspace_bytes >= somi_conv2d_wgrad_workspace_bytes(fwd), SOMI_EWORKSPACE, "conv wgrad: workspace too small");
     const size_t xb = (size_t)a.B * a.H * a.W * x_cs * 4, yb = (size_t)a.B * a.Ho * a.Wo * dy_cs * 4;
-    SOMI_REQUIRE(xb <= W_MAX_BUF && yb <= W_MAX_BUF, SOMI_ENOTIMPL, "conv wgrad: tensors exceed the 4 GiB descriptor range; split the batch");
+    if (xb > W_MAX_BUF || yb > W_MAX_BUF) {
+        // 32-bit buffer descriptors: reduce the batch in slices that fit, each accumulating on top of the previous ones
+        SOMI_REQUIRE(!a.per_sample, SOMI_ENOTIMPL, "conv wgrad: per-sample gradients of tensors beyond the 4 GiB descriptor range");
+        const size_t per_img = (xb > yb ? xb : yb) / a.B;
+        SOMI_REQUIRE(per_img <= W_MAX_BUF, SOMI_ENOTIMPL, "conv wgrad: one image exceeds the 4 GiB descriptor range");
+        const int bsub = (int)(W_MAX_BUF / per_img);
+        for (int b0 = 0; b0 < a.B; b0 += bsub) {
+            somi_conv_desc sub = *fwd;
+            sub.B = a.B - b0 < bsub ? a.B - b0 : bsub;
+            rc = somi_conv2d_wgrad_nhwc_f32(&sub, x + (size_t)b0 * a.H * a.W * x_cs, x_cs, x_coff, dy + (size_t)b0 * a.Ho * a.Wo * dy_cs, dy_cs,
+                                            dy_coff, dw, b0 == 0 ? accumulate : dw, workspace, workspace_bytes, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     a.x = x; a.dy = dy; a.x_cs = x_cs; a.x_coff = x_coff; a.dy_cs = dy_cs; a.dy_coff = dy_coff;
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     const int sets = a.per_sample ? a.B : 1;
