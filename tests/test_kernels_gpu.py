@@ -332,3 +332,29 @@ def test_conv_wgrad(B, H, W, Cin, Cout, k, s, ps):
     acc = prev.to(d)
     ops.conv2d_wgrad_nhwc(nhwc(x).to(d), nhwc(dy).to(d), kh=k, kw=k, stride=s, pad=p, per_sample_w=ps, out=acc, accumulate=acc)
     rel_close(acc, want + prev, what='wgrad accumulate')
+
+
+def test_conv_tensors_beyond_the_descriptor_range():
+    """An activation tensor of 3.9 GB does not fit one 32-bit buffer descriptor: the launchers run the batch in slices.  Forward,
+    data gradient and weight gradient of the whole batch must equal the two halves run on their own (fp32 rounding: the tile
+    schedule depends on the row count)."""
+    from somi_amd import ops
+    d = dev()
+    B, H, Cin, Cout = 60, 160, 640, 32
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = torch.randn(B, H, H, Cin, device=d, generator=g)
+    assert x.numel() * 4 > 0xE0000000
+    w = torch.randn(Cout, Cin, device=d, generator=g) / 25
+    y = ops.conv2d_nhwc(x, w, None, kh=1, kw=1)
+    h = B // 2
+    rel_close(y[:h], ops.conv2d_nhwc(x[:h], w, None, kh=1, kw=1), rel=1e-5, what='forward, first half')
+    rel_close(y[h:], ops.conv2d_nhwc(x[h:], w, None, kh=1, kw=1), rel=1e-5, what='forward, second half')
+    dy = torch.randn(B, H, H, Cout, device=d, generator=g)
+    dw = ops.conv2d_wgrad_nhwc(x, dy, kh=1, kw=1)
+    dw2 = ops.conv2d_wgrad_nhwc(x[:h], dy[:h], kh=1, kw=1) + ops.conv2d_wgrad_nhwc(x[h:], dy[h:], kh=1, kw=1)
+    rel_close(dw, dw2, rel=1e-5, what='weight gradient')
+    # data gradient of a layer whose dy is the big tensor: Cout 640 -> Cin 32
+    wt = torch.randn(32, 640, device=d, generator=g) / 25        # [Cin][Cout] dgrad packing of a 1x1 layer
+    dx = ops.conv2d_dgrad_nhwc(x, wt, B=B, H=H, W=H, cin=32, kh=1, kw=1)
+    rel_close(dx[:h], ops.conv2d_dgrad_nhwc(x[:h], wt, B=h, H=H, W=H, cin=32, kh=1, kw=1), rel=1e-5, what='dgrad, first half')
+    rel_close(dx[h:], ops.conv2d_dgrad_nhwc(x[h:], wt, B=B - h, H=H, W=H, cin=32, kh=1, kw=1), rel=1e-5, what='dgrad, second half')
