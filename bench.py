@@ -197,8 +197,8 @@ def main():
         all_flops, all_secs = sum(v[1] for v in by.values()), sum(v[2] for v in by.values())
         achieved = flops / secs / 1e12
         out = {
-            'metric': ('images/sec train (forward+loss+backward+Adam+EMA) @640, VisDrone-shaped synthetic, yolov5l-SOMI' if args.mode == 'train'
-                       else 'images/sec infer (forward+NMS) @640, VisDrone-shaped synthetic, yolov5l-SOMI'),
+            'metric': (f'images/sec train (forward+loss+backward+Adam+EMA) @{args.size}, VisDrone-shaped synthetic, yolov5l-SOMI' if args.mode == 'train'
+                       else f'images/sec infer (forward+NMS) @{args.size}, VisDrone-shaped synthetic, yolov5l-SOMI'),
             'value': round(whole_job_rate(args.batch, args.steps, world, dt), 2), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
