@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 2
+#define SOMI_ABI_VERSION 3
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -73,12 +73,13 @@ typedef struct somi_conv_desc {
     int32_t res_cs, res_coff;
     int32_t act;              /* enum somi_act */
     int32_t per_sample_w;
-    int32_t reserved_[2];     /* keep 0 */
+    int32_t res2_cs, res2_coff; /* channel stride / offset of residual2 */
     void *workspace;          /* optional scratch (16 B aligned, somi_conv2d_workspace_bytes()); with it, layers whose tile
                                * count leaves workgroup slots idle in the last round are scheduled stream-K: the K range of
                                * some tiles is cut between workgroups and the pieces are added in a fixed order (results
                                * then differ from the unsplit sum by fp32 rounding only).  NULL: one workgroup per tile. */
     uint64_t workspace_bytes;
+    const float *residual2;   /* optional second tensor added after the activation (NHWC (B,Ho,Wo,*)), or NULL */
 } somi_conv_desc;
 
 int somi_conv2d_nhwc_f32(const somi_conv_desc *d, somi_stream_t stream);
@@ -90,7 +91,8 @@ size_t somi_conv2d_workspace_bytes(void);
  * over the taps for which the divisions are exact and in range (autograd of F.conv2d, train.py:270 `backward()`).
  * Runs the same MFMA implicit-GEMM kernel with rows = forward-input pixels.  `w_dgrad` is packed [Cin][kh*kw*Cout],
  * k = (r*kw+q)*Cout + co.  `accumulate` (optional, may alias dx) is added to the result (skip connections).
- * fwd->workspace / workspace_bytes are honoured as in somi_conv2d_nhwc_f32.
+ * fwd->workspace / workspace_bytes are honoured as in somi_conv2d_nhwc_f32; fwd->residual2 (with res2_cs / res2_coff), if set,
+ * is a second tensor of dx's shape added to the result (a shortcut branch's gradient).
  * per_sample_w in `fwd` selects per-image weight sets [B][Cin][kh*kw*Cout]. */
 int somi_conv2d_dgrad_nhwc_f32(const somi_conv_desc *fwd, const float *dy, int dy_cs, int dy_coff, const float *w_dgrad,
                                float *dx, int dx_cs, int dx_coff, const float *accumulate, int acc_cs, int acc_coff,

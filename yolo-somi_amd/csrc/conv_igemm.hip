@@ -105,6 +105,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
         }
         float *yrow = d.y + row * d.y_cs + d.y_coff;
         const float *rrow = d.residual ? d.residual + row * d.res_cs + d.res_coff : nullptr;
+        const float *rrow2 = d.residual2 ? d.residual2 + row * d.res2_cs + d.res2_coff : nullptr;
         if (n + 3 < d.Cout) {
             if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);
             if (d.act == SOMI_ACT_SILU) {
@@ -117,6 +118,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
             if (d.post_scale)
                 v = v * *reinterpret_cast<const f32x4 *>(d.post_scale + n) + *reinterpret_cast<const f32x4 *>(d.post_shift + n);
             if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + n);
+            if (rrow2) v += *reinterpret_cast<const f32x4 *>(rrow2 + n);
             *reinterpret_cast<f32x4 *>(yrow + n) = v;
         } else {
             for (int e = 0; e < 4 && n + e < d.Cout; ++e) {          // ragged Cout tail
@@ -124,6 +126,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
                 t = apply_act_rt(t, d.act);
                 if (d.post_scale) t = t * d.post_scale[n + e] + d.post_shift[n + e];
                 if (rrow) t += rrow[n + e];
+                if (rrow2) t += rrow2[n + e];
                 yrow[n + e] = t;
             }
         }
@@ -520,6 +523,8 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
                  "conv: y_cs (%d), y_coff (%d) must be multiples of 4 and y 16 B aligned", d.y_cs, d.y_coff);
     SOMI_REQUIRE(!d.residual || (d.res_cs % 4 == 0 && d.res_coff % 4 == 0 && aligned16(d.residual)), SOMI_EINVAL,
                  "conv: residual stride / offset must be multiples of 4 and 16 B aligned");
+    SOMI_REQUIRE(!d.residual2 || (d.res2_cs % 4 == 0 && d.res2_coff % 4 == 0 && aligned16(d.residual2) && d.res2_coff + d.Cout <= d.res2_cs),
+                 SOMI_EINVAL, "conv: residual2 slice must be 16 B aligned and inside its channel stride");
     SOMI_REQUIRE((!d.bias || aligned16(d.bias)) && (!d.post_scale || (aligned16(d.post_scale) && aligned16(d.post_shift))),
                  SOMI_EINVAL, "conv: bias / post_scale / post_shift must be 16 B aligned");
     ConvArgs a;
@@ -541,6 +546,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
             sub.x = d.x + (size_t)b0 * d.H * d.W * d.x_cs;
             sub.y = d.y + (size_t)b0 * d.Ho * d.Wo * d.y_cs;
             if (d.residual) sub.residual = d.residual + (size_t)b0 * d.Ho * d.Wo * d.res_cs;
+            if (d.residual2) sub.residual2 = d.residual2 + (size_t)b0 * d.Ho * d.Wo * d.res2_cs;
             if (d.a_chan_scale) sub.a_chan_scale = d.a_chan_scale + (size_t)b0 * d.Cin;
             if (d.a_pix_scale) sub.a_pix_scale = d.a_pix_scale + (size_t)b0 * d.H * d.W;
             if (d.per_sample_w) {
@@ -595,6 +601,7 @@ extern "C" int somi_conv2d_dgrad_nhwc_f32(const somi_conv_desc *f, const float *
     g.kh = f->kh; g.kw = f->kw; g.stride = f->stride; g.pad = f->pad; g.dil = 1;
     g.res_cs = acc_cs; g.res_coff = acc_coff; g.act = SOMI_ACT_NONE; g.per_sample_w = f->per_sample_w;
     g.workspace = f->workspace; g.workspace_bytes = f->workspace_bytes;
+    g.residual2 = f->residual2; g.res2_cs = f->res2_cs; g.res2_coff = f->res2_coff;
     return conv_launch(&g, stream, 1);
 }
 

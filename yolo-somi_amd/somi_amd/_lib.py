@@ -21,7 +21,8 @@ class ConvDesc(C.Structure):
                                           'a_pix_scale', 'y')] + \
                [(n, C.c_int32) for n in ('B', 'H', 'W', 'Cin', 'x_cs', 'x_coff', 'Ho', 'Wo', 'Cout', 'y_cs', 'y_coff',
                                          'kh', 'kw', 'stride', 'pad', 'dil', 'res_cs', 'res_coff', 'act', 'per_sample_w')] + \
-               [('reserved_', C.c_int32 * 2), ('workspace', C.c_void_p), ('workspace_bytes', C.c_uint64)]
+               [('res2_cs', C.c_int32), ('res2_coff', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_uint64),
+                ('residual2', C.c_void_p)]
 
 
 class LossDesc(C.Structure):
@@ -114,7 +115,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != 2:
+        if L.somi_abi_version() != 3:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib

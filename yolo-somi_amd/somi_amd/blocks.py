@@ -204,9 +204,10 @@ class Conv(_Packed):
         self.__dict__['_ctx'] = (x, y, mean, rstd, scale, shift, pk)
         return Act(out.t, out.coff, c2)
 
-    def backward(self, dz, dx_out=None, accumulate=False, need_dx=True):
+    def backward(self, dz, dx_out=None, accumulate=False, need_dx=True, also_add=None):
         """dz: gradient w.r.t. this block's output (Act).  Returns the gradient w.r.t. the input as an Act (written into
-        dx_out if given, added to it if accumulate).  Parameter gradients are accumulated into .grad (reference layout)."""
+        dx_out if given, added to it if accumulate; `also_add` is a further Act added in the same pass - a shortcut's
+        gradient).  Parameter gradients are accumulated into .grad (reference layout)."""
         x, y, mean, rstd, scale, shift, pk = self.__dict__.pop('_ctx')
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         c1, c2, cp = self.conv.in_channels, self.conv.out_channels, pad4(self.conv.out_channels)
@@ -236,7 +237,9 @@ class Conv(_Packed):
         if dx_out is None:
             dx_out = Act(torch.empty(B, H, W, pad4(c1), device=dev, dtype=torch.float32), 0, c1)
         ops.conv2d_dgrad_nhwc(dy, pk['wt'], B=B, H=H, W=W, cin=pad4(c1), kh=k, kw=k, stride=s, pad=p, cout=cp, out=dx_out.t,
-                              dx_coff=dx_out.coff, accumulate=dx_out.t if accumulate else None, acc_coff=dx_out.coff)
+                              dx_coff=dx_out.coff, accumulate=dx_out.t if accumulate else None, acc_coff=dx_out.coff,
+                              accumulate2=None if also_add is None else also_add.t,
+                              acc2_coff=0 if also_add is None else also_add.coff)
         return dx_out
 
     def forward(self, x, out=None, residual=None, a_chan=None, a_pix=None):
@@ -410,8 +413,10 @@ class CBAMBottleneck(nn.Module):
         d = self.cv2.backward(dout)                               # d(t*ca*sa)
         dca = self.spatial_attention.backward(d.t)                # d.t now holds the direct part of dt
         self.channel_attention.backward(dca, d)                   # + pooled paths
-        self.cv1.backward(d, dx_out=dx_out, accumulate=True)
-        if self.add:
+        c1 = self.cv1.conv.in_channels
+        fuse = self.add and pad4(c1) == c1 and dout.coff % 4 == 0  # the shortcut's gradient rides the dgrad epilogue
+        self.cv1.backward(d, dx_out=dx_out, accumulate=True, also_add=dout if fuse else None)
+        if self.add and not fuse:
             ops.add_(dx_out.t, dx_out.coff, dout.t, dout.coff, x.c)
         return dx_out
 

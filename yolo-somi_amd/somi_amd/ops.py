@@ -252,7 +252,7 @@ def cfs_blend(x, xproj, logit, G, Gc):
 
 
 def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cout=None, dy_coff=0, out=None, dx_coff=0,
-                      accumulate=None, acc_coff=0, per_sample_w=False):
+                      accumulate=None, acc_coff=0, per_sample_w=False, accumulate2=None, acc2_coff=0):
     """dx of the conv x (B,H,W,cin) -> y (B,Ho,Wo,cout); dy is (B,Ho,Wo,dy_cs); w_dgrad packed [cin][kh*kw*cout]."""
     _, Ho, Wo, dy_cs = dy.shape
     cout = dy_cs - dy_coff if cout is None else cout
@@ -262,6 +262,8 @@ def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cou
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, cin, Ho, Wo, cout
     d.kh, d.kw, d.stride, d.pad, d.dil, d.per_sample_w = kh, kw, stride, pad, 1, int(per_sample_w)
     _conv_workspace(d, dy.device)
+    if accumulate2 is not None:                                   # second added tensor (e.g. the shortcut branch's gradient)
+        d.residual2, d.res2_cs, d.res2_coff = _ptr(_f32c(accumulate2)), accumulate2.shape[3], acc2_coff
     if w_dgrad.numel() != (B if per_sample_w else 1) * cin * kh * kw * cout:
         raise RuntimeError('dgrad weight has the wrong number of elements')
     prof = PROFILE is not None
