@@ -465,7 +465,8 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
         const int bm = kTileBM[p.variant], bn = kTileBN[p.variant];
         const long ntile = (long)cdiv(M, bm) * cdiv(d.Cout, bn), nkt = (long)d.kh * d.kw * d.Cin / BK;
         const long rounds = (ntile + SK_GRID - 1) / SK_GRID;
-        p.sk = ntile * 10 < rounds * SK_GRID * 9 && ntile * nkt >= SK_GRID * 4L &&
+        static const int sk_pct = getenv("SOMI_SK_PCT") ? atoi(getenv("SOMI_SK_PCT")) : 90;   // stream-K below this slot efficiency (%)
+        p.sk = ntile * 100 < rounds * SK_GRID * sk_pct && ntile * nkt >= SK_GRID * 4L &&
                d.workspace_bytes >= (size_t)SK_GRID * 2 * bm * bn * sizeof(float);
     }
     return p;
