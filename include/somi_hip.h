@@ -388,6 +388,24 @@ int somi_wbf_f32(const float *boxes, const float *scores, const int32_t *labels,
                  float *out_scores, int32_t *out_labels, int32_t *out_count, void *workspace, size_t workspace_bytes,
                  somi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Validation metrics after NMS.
+ * somi_val_match_f32 = val.py:50-71 `process_batch` for a batch of images: det (sum N_b, 6) x1,y1,x2,y2,conf,cls and
+ * labels (sum M_b, 5) cls,x1,y1,x2,y2 are concatenated per image, det_off / lab_off (B+1 ints, device) delimit the images;
+ * iouv: T <= 16 ascending IoU levels (device); correct: (sum N_b, T) bytes.  max_det / max_labels: largest per-image counts
+ * (host values; they size the LDS tables).  Exact IoU ties are broken by lowest label index (the reference's sort is
+ * unstable there).
+ * somi_ap_per_class_f64 = utils/metrics.py:21-95 `ap_per_class`: tp (N,T) bytes, conf / pred_cls (N), target_cls (M) with
+ * integer-valued class ids in [0, ncap).  Outputs for the classes present among the targets, ascending: out_classes,
+ * *out_n, ap (n,T), and p / r / f1 at the confidence of best mean F1 - all in fp64 like numpy.  Equal confidences keep
+ * their input order. */
+int somi_val_match_f32(const float *det, const int *det_off, const float *labels, const int *lab_off, const float *iouv, int T,
+                       int B, int max_det, int max_labels, uint8_t *correct, somi_stream_t stream);
+size_t somi_ap_per_class_workspace_bytes(long N, int T, int ncap);
+int somi_ap_per_class_f64(const uint8_t *tp, const float *conf, const float *pred_cls, const float *target_cls, long N, long M,
+                          int T, int ncap, int *out_classes, int *out_n, double *out_ap, double *out_p, double *out_r,
+                          double *out_f1, void *workspace, size_t workspace_bytes, somi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -279,7 +279,60 @@ def gen_nms():
     save('box_iou', box1=b1, box2=b2, iou=ref_box_iou(b1, b2))
 
 
+# ------------------------------------------------------------------------------------------------ validation metrics
+def gen_val():
+    """process_batch (val.py:50-71, executed from the reference's own source text) and ap_per_class
+    (utils/metrics.py:21-74) on seeded detections / labels of 24 synthetic images."""
+    from utils.metrics import ap_per_class as ref_ap
+    src = open(f'{REF}/val.py').read().split('\n')
+    lo = next(i for i, l in enumerate(src) if l.startswith('def process_batch'))
+    hi = next(i for i in range(lo + 1, len(src)) if src[i].startswith('@torch.no_grad') or src[i].startswith('def '))
+    ns = {'np': np, 'torch': torch, 'box_iou': ref_box_iou}
+    exec('\n'.join(src[lo:hi]), ns)
+    ref_process_batch = ns['process_batch']
+    g = torch.Generator().manual_seed(500)
+    iouv = torch.linspace(0.5, 0.95, 10)
+    rec = dict(iouv=iouv)
+    stats = []
+    nimg = 24
+    for b in range(nimg):
+        M = int(torch.randint(0, 40, (1,), generator=g)) if b != 3 else 0          # image 3 has no labels
+        N = int(torch.randint(0, 120, (1,), generator=g)) if b != 5 else 0         # image 5 has no detections
+        lc = torch.rand(M, 2, generator=g) * 500 + 50
+        lwh = torch.rand(M, 2, generator=g) * 80 + 8
+        labels = torch.cat((torch.randint(0, 6, (M, 1), generator=g).float(), lc - lwh / 2, lc + lwh / 2), 1)
+        # detections: jittered copies of labels (so many IoU levels are exercised) plus clutter
+        if M and N:
+            pick = torch.randint(0, M, (N,), generator=g)
+            jit = (torch.rand(N, 4, generator=g) - 0.5) * lwh[pick].repeat(1, 2) * torch.rand(N, 1, generator=g) * 0.9
+            boxes = labels[pick, 1:] + jit
+            cls = labels[pick, 0].clone()
+            flip = torch.rand(N, generator=g) < 0.25
+            cls[flip] = torch.randint(0, 7, (int(flip.sum()),), generator=g).float()
+            clutter = torch.rand(N, generator=g) < 0.3
+            cc = torch.rand(N, 2, generator=g) * 500 + 50
+            cw = torch.rand(N, 2, generator=g) * 80 + 8
+            boxes[clutter] = torch.cat((cc - cw / 2, cc + cw / 2), 1)[clutter]
+        else:
+            cc = torch.rand(N, 2, generator=g) * 500 + 50
+            cw = torch.rand(N, 2, generator=g) * 80 + 8
+            boxes = torch.cat((cc - cw / 2, cc + cw / 2), 1)
+            cls = torch.randint(0, 7, (N,), generator=g).float()
+        conf = torch.rand(N, generator=g)
+        det = torch.cat((boxes, conf[:, None], cls[:, None]), 1)
+        if N and M:
+            correct = ref_process_batch(det, labels, iouv)
+        else:
+            correct = torch.zeros(N, 10, dtype=torch.bool)                          # val.py:174,188
+        rec[f'det{b}'], rec[f'lab{b}'], rec[f'correct{b}'] = det, labels, correct
+        stats.append((correct, det[:, 4], det[:, 5], labels[:, 0]))
+    tp, conf, pcls, tcls = [torch.cat(x, 0).numpy() for x in zip(*stats)]            # val.py:200
+    p, r, ap, f1, cls_ = ref_ap(tp, conf, pcls, tcls, plot=False, names={})
+    rec.update(nimg=nimg, tp=tp, conf=conf, pred_cls=pcls, target_cls=tcls, p=p, r=r, ap=ap, f1=f1, ap_class=cls_)
+    save('val_metrics', **rec)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'loss', 'nms']
+    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'loss', 'nms', 'val']
     for w in which:
         globals()[f'gen_{w}']()

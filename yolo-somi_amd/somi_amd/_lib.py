@@ -95,6 +95,9 @@ SIGNATURES = {
     'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),
     'somi_yolo_loss_f32': (I, [C.POINTER(LossDesc), P, P, Z, S]),
+    'somi_val_match_f32': (I, [P, P, P, P, P, I, I, I, I, P, S]),
+    'somi_ap_per_class_workspace_bytes': (Z, [C.c_long, I, I]),
+    'somi_ap_per_class_f64': (I, [P, P, P, P, C.c_long, C.c_long, I, I, P, P, P, P, P, P, P, Z, S]),
     'somi_repulsion_workspace_bytes': (Z, [I, I]),
     'somi_repulsion_loss_f32': (I, [P, P, P, I, I, F, F, F, F, P, P, Z, S]),
     'somi_wbf_workspace_bytes': (Z, [I]),
