@@ -441,3 +441,20 @@ def test_train_step_gradient_accumulation():
     tr.step(imgs.cuda(), targets.cuda())
     assert any(not torch.equal(a, b) for a, b in zip(w0, tr.optimizer.flat_params)), 'no optimizer step after two batches'
     assert all(float(g.abs().max()) == 0 for g in tr.optimizer.flat_grads)
+
+
+def test_end_to_end_training_reaches_map_and_matches_oracle():
+    """tools/e2e_map.py: 300 product-path training steps on the synthetic rectangles task must actually learn it (mAP@0.5 > 0.8),
+    and the product validation pipeline (HIP forward, NMS, matching, AP) must give the same mAP as the CPU oracle evaluating the
+    same trained weights (BASELINE.json: mAP@0.5 parity, +-0.1 points)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('e2e_map', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                          'tools', 'e2e_map.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.main(300)
+    assert res['loss_last'] < 0.2 * res['loss_first'], res
+    assert res['product']['mAP50'] > 0.8, res
+    assert res['abs_diff_mAP50'] <= 1e-3 and res['abs_diff_mAP50_95'] <= 1e-3, res
+    assert abs(res['product']['P'] - res['oracle']['P']) <= 1e-3 and abs(res['product']['R'] - res['oracle']['R']) <= 1e-3, res
