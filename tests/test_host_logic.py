@@ -81,3 +81,24 @@ def test_product_config_data_matches_oracle_copy():
     ia, ta = O.synthetic_batch(2, 32, seed=4)
     ib, tb = P.synthetic_batch(2, 32, seed=4)
     assert torch.equal(ia, ib) and torch.equal(ta, tb)
+
+
+def test_read_checkpoint_without_the_checkpoints_code_base():
+    """A reference-style checkpoint (train.py:310-317: whole modules pickled, fp16) is read back with stand-in classes for
+    every class of the code base that wrote it; the oracle's module tree plays the reference's here."""
+    import copy
+    import io
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg
+    from somi_amd.checkpoint import ForeignModule, read_checkpoint
+    ref = fill_state(OModel(somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS)), 3)
+    buf = io.BytesIO()
+    torch.save({'epoch': 7, 'model': copy.deepcopy(ref).half(), 'ema': copy.deepcopy(ref).half(), 'updates': 11, 'optimizer': None}, buf)
+    ck = read_checkpoint(buf.getvalue(), foreign_prefixes=('oracle',))
+    assert ck['epoch'] == 7 and ck['updates'] == 11
+    m = ck['ema']
+    assert isinstance(m, ForeignModule) and all(isinstance(x, (ForeignModule, torch.nn.Module)) for x in m.modules())
+    assert not any(type(x).__module__.startswith('oracle') and not isinstance(x, ForeignModule) for x in m.modules())
+    sd, want = m.state_dict(), ref.half().state_dict()
+    assert list(sd) == list(want) and all(torch.equal(sd[k], want[k]) for k in sd)
+    assert isinstance(m.yaml, dict) and m.yaml['nc'] == 10

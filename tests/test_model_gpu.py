@@ -135,3 +135,24 @@ def test_val_config_bs128_nms_wbf():
         wb, ws, wl = oracle_wbf([b.tolist() for b in bl], [s.tolist() for s in sl], [l.tolist() for l in ll], weights=None,
                                 iou_thr=0.67, skip_box_thr=0.01)
         assert np.array_equal(gl, wl) and np.array_equal(gb, wb.astype(np.float32)) and np.array_equal(gs, ws.astype(np.float32))
+
+
+def test_attempt_load_reference_style_checkpoint():
+    """somi_amd.checkpoint.attempt_load: a pickled fp16 module tree (train.py:310-317) -> somi_amd.Model with the EMA weights,
+    without importing the code base that pickled it; predictions equal the oracle run with the same fp16-rounded weights."""
+    import copy
+    import io
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg
+    from somi_amd.checkpoint import attempt_load
+    cfg = somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS)
+    ema, raw = fill_state(OModel(cfg), 5), fill_state(OModel(cfg), 6)
+    ema.names = [f'c{i}' for i in range(10)]
+    buf = io.BytesIO()
+    torch.save({'epoch': 3, 'best_fitness': 0.5, 'model': copy.deepcopy(raw).half(), 'ema': copy.deepcopy(ema).half(), 'updates': 40}, buf)
+    model, info = attempt_load(buf.getvalue(), foreign_prefixes=('oracle',))
+    assert info['used'] == 'ema' and info['epoch'] == 3 and model.names == ema.names and not model.training
+    want_model = copy.deepcopy(ema).half().float().eval()
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        rel_close(model(x.cuda())[0], want_model(x)[0], what='z from the loaded checkpoint')
