@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 3
+#define SOMI_ABI_VERSION 4
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -166,9 +166,10 @@ int somi_dwconv3x3_nhwc_f32(const float *x, const float *w, const float *bias, c
 int somi_sppf_pool_nhwc_f32(float *buf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream);
 
 /* BiFPN fusion (models/common.py:3695-3704) with the preceding nn.Upsample(2,'nearest') folded in:
- * y = sum_i wn[i] * src_i, where source i is read at (h>>up[i], w>>up[i]).  wn = w / (sum swish(w) + 1e-4) is
- * computed on the host.  n_in in {2,3}; all sources C channels, contiguous NHWC. */
-int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const float *wn_host, int n_in, float *y,
+ * y = sum_i wn[i] * src_i, where source i is read at (h>>up[i], w>>up[i]).  wn = w / (sum swish(w) + eps) is computed
+ * inside the kernel from the raw parameter w_dev (n_in floats on the device; no host copy of it is needed).
+ * n_in in {2,3}; all sources C channels, contiguous NHWC.  src_host / up_host are host arrays of n_in entries. */
+int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const float *w_dev, float eps, int n_in, float *y,
                         int B, int H, int W, int C, somi_stream_t stream);
 
 /* Global average + max pool over H*W of a channel slice: out_avg[b][c], out_max[b][c]
@@ -192,13 +193,13 @@ int somi_chan_stats_nhwc_f32(const float *x, int x_cs, int x_coff, const float *
                              somi_stream_t stream);
 
 /* k x k conv 2->1 channels + bias + sigmoid on the stats map -> sa[b,h,w] (models/common.py:396,403). w is [k][k][2]. */
-int somi_spatial_attn_f32(const float *stats, const float *w, float bias, float *sa, int B, int H, int W, int k,
+int somi_spatial_attn_f32(const float *stats, const float *w, const float *bias /* device, 1 value */, float *sa, int B, int H, int W, int k,
                           somi_stream_t stream);
 
 /* CBAM apply in one pass: sa = sigmoid(conv_kxk(stats) + bias); y = x * ca[b][c] * sa[b,h,w] (models/common.py:686-688:
  * `out = channel_attention(x2) * x2; out = spatial_attention(out) * out`).  x / y are channel slices; in place allowed. */
 int somi_cbam_apply_nhwc_f32(const float *x, int x_cs, int x_coff, const float *ca, const float *stats, const float *w,
-                             float bias, float *y, int y_cs, int y_coff, int B, int H, int W, int C, int k,
+                             const float *bias /* device, 1 value */, float *y, int y_cs, int y_coff, int B, int H, int W, int C, int k,
                              somi_stream_t stream);
 
 /* y = x * s[b][c] (SEAM output x*exp(fc), models/common.py:8489-8490; also materialised CBAM scaling). In place allowed. */
@@ -294,8 +295,8 @@ int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff, const floa
 int somi_detect_raw_bwd_f32(const float *draw, float *dbox, int box_cs, float *dcls, int cls_cs, int B, int ny, int nx, int na,
                             int nc, somi_stream_t stream);
 int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream);
-int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *wn_host,
-                            const float *w_dev, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
+int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *w_dev,
+                            float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
                             int W, int C, somi_stream_t stream);
 size_t somi_dwconv3x3_bwd_workspace_floats(int B, int W, int C);   /* floats of `workspace` below; C/4 must divide 256 */
 int somi_dwconv3x3_bwd_nhwc_f32(const float *dy, const float *x, const float *w, float *dx, const float *dx_accumulate,

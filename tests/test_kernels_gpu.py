@@ -205,9 +205,10 @@ def test_dwconv_sppf_bifpn():
     a = torch.randn(B, C, 4, 6, generator=g)
     c2 = torch.randn(B, C, 8, 12, generator=g)
     c3 = torch.randn(B, C, 8, 12, generator=g)
-    wn = [0.3, 0.5, 0.7]
+    w = torch.tensor([0.3, 1.5, -0.7])                       # raw fusion parameter; normalised on the device (models/common.py:3696)
+    wn = w / ((w * torch.sigmoid(w)).sum() + 1e-4)
     want = wn[0] * F.interpolate(a, scale_factor=2, mode='nearest') + wn[1] * c2 + wn[2] * c3
-    got = ops.bifpn([nhwc(a).to(d), nhwc(c2).to(d), nhwc(c3).to(d)], [1, 0, 0], wn)
+    got = ops.bifpn([nhwc(a).to(d), nhwc(c2).to(d), nhwc(c3).to(d)], [1, 0, 0], w.to(d))
     rel_close(got, nhwc(want), rel=1e-6, what='bifpn')
 
 
@@ -237,12 +238,13 @@ def test_attention_pieces():
     w7, b7 = torch.randn(1, 2, 7, 7, generator=g) * 0.1, 0.05
     want_sa = torch.sigmoid(F.conv2d(torch.cat([xs.mean(1, keepdim=True), xs.amax(1, keepdim=True)], 1), w7,
                                      torch.tensor([b7]), padding=3))[:, 0]
-    sa = ops.spatial_attn(stats, w7[0].permute(1, 2, 0).contiguous().to(d), b7, 7)
+    b7d = torch.tensor([b7], device=d)                        # the bias stays a device value
+    sa = ops.spatial_attn(stats, w7[0].permute(1, 2, 0).contiguous().to(d), b7d, 7)
     rel_close(sa, want_sa, rel=1e-5, what='spatial attention')
     got = ops.scale_channels(nhwc(x).to(d), ca, sa)
     rel_close(got, nhwc(xs * want_sa[:, None]), rel=1e-5, what='scale')
     wd = wide.to(d)                                          # fused stats->sigmoid(conv7x7)->scale, in place on a channel slice
-    ops.cbam_apply_(wd, ca, stats, w7[0].permute(1, 2, 0).contiguous().to(d), b7, 7, c=C, x_coff=16)
+    ops.cbam_apply_(wd, ca, stats, w7[0].permute(1, 2, 0).contiguous().to(d), b7d, 7, c=C, x_coff=16)
     rel_close(wd[..., 16:16 + C], nhwc(xs * want_sa[:, None]), rel=1e-5, what='cbam apply')
     assert torch.equal(wd[..., :16].cpu(), wide[..., :16]) and torch.equal(wd[..., 16 + C:].cpu(), wide[..., 16 + C:])
 

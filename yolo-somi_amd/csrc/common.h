@@ -46,6 +46,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
+// BiFPN fusion weights w_i / (sum_j swish(w_j) + eps) (models/common.py:3696, Swish :8210) from the raw parameter on the device
+__device__ __forceinline__ void bifpn_norm(const float *__restrict__ w, int n_in, float eps, float (&wn)[3]) {
+    float s = 0.f;
+    for (int i = 0; i < n_in; ++i) s += w[i] * (1.0f / (1.0f + expf(-w[i])));
+    for (int i = 0; i < 3; ++i) wn[i] = i < n_in ? w[i] / (s + eps) : 0.f;
+}
+
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
     if constexpr (ACT == SOMI_ACT_SILU) return v / (1.0f + expf(-v));

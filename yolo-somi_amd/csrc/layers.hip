@@ -140,10 +140,13 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(float *__restrict__ buf,
 struct BifpnArgs {
     const float *src[3];
     int up[3];
-    float wn[3];
+    const float *w;      // raw fusion parameter (device), normalised in the kernel: no host round trip per step
+    float eps;
     int n_in;
 };
 __global__ __launch_bounds__(256) void bifpn_kernel(BifpnArgs a, float *__restrict__ y, int B, int H, int W, int C) {
+    float wn[3];
+    bifpn_norm(a.w, a.n_in, a.eps, wn);
     const int C4 = C >> 2;
     const long items = (long)B * H * W * C4;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void bifpn_kernel(BifpnArgs a, float *__restri
             if (i >= a.n_in) break;
             const int u = a.up[i];
             const long sp = (b * (H >> u) + (hv >> u)) * (W >> u) + (wv >> u);
-            acc += a.wn[i] * *reinterpret_cast<const f32x4 *>(a.src[i] + sp * C + c);
+            acc += wn[i] * *reinterpret_cast<const f32x4 *>(a.src[i] + sp * C + c);
         }
         *reinterpret_cast<f32x4 *>(y + pix * C + c) = acc;
     }
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float *__restrict
 }
 
 __global__ __launch_bounds__(256) void spatial_attn_kernel(const float *__restrict__ stats, const float *__restrict__ w,
-                                                           float bias, float *__restrict__ sa, int B, int H, int W, int k) {
+                                                           const float *__restrict__ bias_p, float *__restrict__ sa, int B, int H, int W, int k) {
+    const float bias = bias_p[0];
     const long npix = (long)B * H * W;
     const int pad = k >> 1;
     for (long p = blockIdx.x * 256L + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
@@ -320,8 +324,9 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const float *__restri
 // for the tile's 64 x C elements (float4 per lane).  In place allowed.  Replaces materialising `spatial_attention(out) * out`
 // with `out = channel_attention(x2) * x2` (models/common.py:686-688) in two passes.
 __global__ __launch_bounds__(256) void cbam_apply_kernel(const float *__restrict__ x, int x_cs, int x_coff, const float *__restrict__ ca,
-                                                         const float *__restrict__ stats, const float *__restrict__ w, float bias,
+                                                         const float *__restrict__ stats, const float *__restrict__ w, const float *__restrict__ bias_p,
                                                          float *__restrict__ y, int y_cs, int y_coff, int B, int H, int W, int C, int k) {
+    const float bias = bias_p[0];
     __shared__ float sa[64];
     const long npix = (long)B * H * W;
     const int pad = k >> 1, C4 = C >> 2;
@@ -615,21 +620,22 @@ extern "C" int somi_sppf_pool_nhwc_f32(float *buf, int B, int H, int W, int C, i
     return launch_status("somi_sppf_pool_nhwc_f32");
 }
 
-extern "C" int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const float *wn_host, int n_in, float *y,
+extern "C" int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const float *w_dev, float eps, int n_in, float *y,
                                    int B, int H, int W, int C, somi_stream_t stream) {
-    SOMI_REQUIRE(src_host && up_host && wn_host && y && (n_in == 2 || n_in == 3), SOMI_EINVAL, "bifpn: bad arguments");
+    SOMI_REQUIRE(src_host && up_host && w_dev && y && (n_in == 2 || n_in == 3), SOMI_EINVAL, "bifpn: bad arguments");
     SOMI_REQUIRE(C % 4 == 0 && aligned16(y), SOMI_EINVAL, "bifpn: C %% 4 and alignment");
     BifpnArgs a;
     for (int i = 0; i < 3; ++i) {
         a.src[i] = i < n_in ? src_host[i] : nullptr;
         a.up[i] = i < n_in ? up_host[i] : 0;
-        a.wn[i] = i < n_in ? wn_host[i] : 0.f;
         if (i < n_in) {
             SOMI_REQUIRE(a.src[i] && aligned16(a.src[i]) && (a.up[i] == 0 || a.up[i] == 1), SOMI_EINVAL, "bifpn: bad source %d", i);
             SOMI_REQUIRE(a.up[i] == 0 || (H % 2 == 0 && W % 2 == 0), SOMI_EINVAL, "bifpn: upsampled source needs even H, W");
         }
     }
     a.n_in = n_in;
+    a.w = w_dev;
+    a.eps = eps;
     hipLaunchKernelGGL(bifpn_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, y, B, H, W, C);
     return launch_status("somi_bifpn_nhwc_f32");
 }
@@ -669,9 +675,9 @@ extern "C" int somi_chan_stats_nhwc_f32(const float *x, int x_cs, int x_coff, co
     return launch_status("somi_chan_stats_nhwc_f32");
 }
 
-extern "C" int somi_spatial_attn_f32(const float *stats, const float *w, float bias, float *sa, int B, int H, int W, int k,
+extern "C" int somi_spatial_attn_f32(const float *stats, const float *w, const float *bias, float *sa, int B, int H, int W, int k,
                                      somi_stream_t stream) {
-    SOMI_REQUIRE(stats && w && sa && B > 0 && H > 0 && W > 0 && (k == 3 || k == 5 || k == 7), SOMI_EINVAL,
+    SOMI_REQUIRE(stats && w && bias && sa && B > 0 && H > 0 && W > 0 && (k == 3 || k == 5 || k == 7), SOMI_EINVAL,
                  "spatial attn: bad arguments (k in 3,5,7)");
     hipLaunchKernelGGL(spatial_attn_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, stats, w, bias, sa, B,
                        H, W, k);
@@ -679,9 +685,9 @@ extern "C" int somi_spatial_attn_f32(const float *stats, const float *w, float b
 }
 
 extern "C" int somi_cbam_apply_nhwc_f32(const float *x, int x_cs, int x_coff, const float *ca, const float *stats, const float *w,
-                                        float bias, float *y, int y_cs, int y_coff, int B, int H, int W, int C, int k,
+                                        const float *bias, float *y, int y_cs, int y_coff, int B, int H, int W, int C, int k,
                                         somi_stream_t stream) {
-    SOMI_REQUIRE(x && ca && stats && w && y && B > 0 && H > 0 && W > 0 && C > 0 && (k == 3 || k == 5 || k == 7), SOMI_EINVAL,
+    SOMI_REQUIRE(x && ca && stats && w && bias && y && B > 0 && H > 0 && W > 0 && C > 0 && (k == 3 || k == 5 || k == 7), SOMI_EINVAL,
                  "cbam apply: bad arguments (k in 3,5,7)");
     SOMI_REQUIRE(C % 4 == 0 && x_cs % 4 == 0 && x_coff % 4 == 0 && y_cs % 4 == 0 && y_coff % 4 == 0 && aligned16(x) && aligned16(y) &&
                      aligned16(ca), SOMI_EINVAL, "cbam apply: C, strides, offsets %% 4 and 16 B alignment");

@@ -446,12 +446,15 @@ struct BifpnBwdArgs {
     const float *src[3];
     float *dsrc[3];
     int up[3];
-    float wn[3];
+    const float *w;      // raw fusion parameter (device)
+    float eps;
     int n_in;
 };
 __global__ __launch_bounds__(256) void bifpn_bwd_kernel(BifpnBwdArgs a, const float *__restrict__ dout, float *__restrict__ part, int B, int H,
                                                         int W, int C) {
     __shared__ float red[3][4];
+    float wn[3];
+    bifpn_norm(a.w, a.n_in, a.eps, wn);
     const int C4 = C >> 2;
     const long items = (long)B * H * W * C4;
     float acc[3] = {0.f, 0.f, 0.f};
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256) void bifpn_bwd_kernel(BifpnBwdArgs a, const fl
             const long sp = (b * (H >> u) + (hv >> u)) * (W >> u) + (wv >> u);
             const f32x4 sv = *reinterpret_cast<const f32x4 *>(a.src[i] + sp * C + c);
             acc[i] += (g[0] * sv[0] + g[1] * sv[1]) + (g[2] * sv[2] + g[3] * sv[3]);
-            if (!u) *reinterpret_cast<f32x4 *>(a.dsrc[i] + pix * C + c) = g * a.wn[i];
+            if (!u) *reinterpret_cast<f32x4 *>(a.dsrc[i] + pix * C + c) = g * wn[i];
         }
     }
     for (int i = 0; i < 3; ++i) {
@@ -479,8 +482,11 @@ __global__ __launch_bounds__(256) void bifpn_bwd_kernel(BifpnBwdArgs a, const fl
     __syncthreads();
     if (threadIdx.x < 3) part[(long)blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
-__global__ __launch_bounds__(256) void bifpn_bwd_up_kernel(const float *__restrict__ dout, float *__restrict__ dsrc, float wn, int B, int Hl, int Wl,
-                                                           int C) {
+__global__ __launch_bounds__(256) void bifpn_bwd_up_kernel(const float *__restrict__ dout, float *__restrict__ dsrc, const float *__restrict__ w,
+                                                           int n_in, float eps, int which, int B, int Hl, int Wl, int C) {
+    float wn3[3];
+    bifpn_norm(w, n_in, eps, wn3);
+    const float wn = wn3[which];
     const int C4 = C >> 2;
     const long items = (long)B * Hl * Wl * C4;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
@@ -645,28 +651,29 @@ extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, int B,
     return launch_status("somi_sppf_pool_bwd_nhwc_f32");
 }
 
-extern "C" int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *wn_host,
-                                       const float *w_dev, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
+extern "C" int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *w_dev,
+                                       float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
                                        int W, int C, somi_stream_t stream) {
-    SOMI_REQUIRE(src_host && dsrc_host && up_host && wn_host && w_dev && dout && dw_accumulate && workspace && (n_in == 2 || n_in == 3) &&
+    SOMI_REQUIRE(src_host && dsrc_host && up_host && w_dev && dout && dw_accumulate && workspace && (n_in == 2 || n_in == 3) &&
                      C % 4 == 0, SOMI_EINVAL, "bifpn bwd: bad arguments");
     BifpnBwdArgs a;
     for (int i = 0; i < 3; ++i) {
         a.src[i] = i < n_in ? src_host[i] : nullptr;
         a.dsrc[i] = i < n_in ? dsrc_host[i] : nullptr;
         a.up[i] = i < n_in ? up_host[i] : 0;
-        a.wn[i] = i < n_in ? wn_host[i] : 0.f;
         SOMI_REQUIRE(i >= n_in || (a.src[i] && a.dsrc[i] && (a.up[i] == 0 || a.up[i] == 1)), SOMI_EINVAL, "bifpn bwd: bad source %d", i);
     }
     a.n_in = n_in;
+    a.w = w_dev;
+    a.eps = eps;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ew_grid((long)B * H * W * (C / 4));
     hipLaunchKernelGGL(bifpn_bwd_kernel, dim3(nblk), dim3(256), 0, s, a, dout, workspace, B, H, W, C);
     for (int i = 0; i < n_in; ++i)
         if (a.up[i])
-            hipLaunchKernelGGL(bifpn_bwd_up_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, dout, a.dsrc[i], a.wn[i], B,
+            hipLaunchKernelGGL(bifpn_bwd_up_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, dout, a.dsrc[i], w_dev, n_in, eps, i, B,
                                H / 2, W / 2, C);
-    hipLaunchKernelGGL(bifpn_bwd_weight_kernel, dim3(1), dim3(64), 0, s, workspace, nblk, w_dev, n_in, 1e-4f, dw_accumulate);
+    hipLaunchKernelGGL(bifpn_bwd_weight_kernel, dim3(1), dim3(64), 0, s, workspace, nblk, w_dev, n_in, eps, dw_accumulate);
     return launch_status("somi_bifpn_bwd_nhwc_f32");
 }
 

@@ -55,13 +55,13 @@ SIGNATURES = {
     'somi_image_f32_to_nhwc4': (I, [P, P, I, I, I, I, F, S]),
     'somi_dwconv3x3_nhwc_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, I, S]),
     'somi_sppf_pool_nhwc_f32': (I, [P, I, I, I, I, I, I, S]),
-    'somi_bifpn_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float), I, P, I, I, I, I, S]),
+    'somi_bifpn_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), P, F, I, P, I, I, I, I, S]),
     'somi_pool_nchunk': (I, [I]),
     'somi_global_pool_nhwc_f32': (I, [P, I, I, I, I, I, P, P, P, S]),
     'somi_attn_mlp_f32': (I, [I, P, P, P, P, P, P, P, I, I, I, S]),
     'somi_chan_stats_nhwc_f32': (I, [P, I, I, P, P, I, I, I, S]),
-    'somi_spatial_attn_f32': (I, [P, P, F, P, I, I, I, I, S]),
-    'somi_cbam_apply_nhwc_f32': (I, [P, I, I, P, P, P, F, P, I, I, I, I, I, I, I, S]),
+    'somi_spatial_attn_f32': (I, [P, P, P, P, I, I, I, I, S]),
+    'somi_cbam_apply_nhwc_f32': (I, [P, I, I, P, P, P, P, P, I, I, I, I, I, I, I, S]),
     'somi_scale_channels_nhwc_f32': (I, [P, P, P, P, I, I, I, S]),
     'somi_odconv_weights_f32': (I, [P] * 18 + [I] * 7 + [S]),
     'somi_detect_decode_f32': (I, [P, I, P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
@@ -80,7 +80,7 @@ SIGNATURES = {
     'somi_pool_bwd_add_nhwc_f32': (I, [P, I, I, P, P, P, I, I, I, S]),
     'somi_detect_raw_bwd_f32': (I, [P, P, I, P, I, I, I, I, I, I, S]),
     'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, I, I, I, I, I, I, S]),
-    'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_float), P, I, P, P, P, I, I, I, I, S]),
+    'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), P, F, I, P, P, P, I, I, I, I, S]),
     'somi_dwconv3x3_bwd_workspace_floats': (Z, [I, I, I]),
     'somi_dwconv3x3_bwd_nhwc_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, S]),
     'somi_scale_channels_bwd_nhwc_f32': (I, [P, P, P, P, P, P, I, I, I, S]),
@@ -118,7 +118,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != 3:
+        if L.somi_abi_version() != 4:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -352,7 +352,7 @@ class SpatialAttentionModule(_Packed):
 
     def _pack(self, dev):
         w = self.cv1.weight.detach().float()[0].permute(1, 2, 0).contiguous().to(dev)     # [k][k][2]
-        return w, float(self.cv1.bias.detach()[0])
+        return w, self.cv1.bias.detach().float().contiguous().to(dev)     # stays on the device: no host sync per repack
 
     def forward(self, x, ca):
         """Applies both attentions: x <- x * ca * sa.  Eval: in place (one stats pass + one apply pass).  Train: x is kept
@@ -488,7 +488,7 @@ class Swish(nn.Module):
 
 class BiFPN(_Packed):
     """w_i / (sum_j swish(w_j) + 1e-4) weighted sum (models/common.py:3688-3704); inputs may be virtual 2x-upsampled.
-    The normalised weights are host scalars computed once per parameter change (no device sync in the forward)."""
+    The weights are normalised inside the kernels from the raw parameter on the device."""
 
     def __init__(self, length):
         super().__init__()
@@ -496,27 +496,25 @@ class BiFPN(_Packed):
         self.swish = Swish()
         self.epsilon = 0.0001
 
-    def _pack(self, dev):
-        w = self.weight.detach().float().cpu()
-        return (w / (self.swish(w).sum(dim=0) + self.epsilon)).tolist()
-
     def forward(self, xs):
-        wn = self._packed(xs[0].t.device)
         for a in xs:
             if a.coff != 0 or a.t.shape[3] != xs[0].t.shape[3]:
                 raise NotImplementedError('BiFPN inputs must be whole tensors of equal width')
-        out = ops.bifpn([a.t for a in xs], [a.up for a in xs], wn)
+        w = self.weight.detach()
+        if not w.is_cuda:
+            raise RuntimeError('somi_amd BiFPN runs on the MI355X only (no CPU fallback)')
+        out = ops.bifpn([a.t for a in xs], [a.up for a in xs], w, self.epsilon)      # normalised inside the kernel
         if self.training:
-            self.__dict__['_ctx'] = (xs, wn)
+            self.__dict__['_ctx'] = xs
         return Act(out, 0, xs[0].c)
 
     def backward(self, dout):
         """Returns the list of input gradients (low-resolution for the virtually upsampled inputs)."""
-        xs, wn = self.__dict__.pop('_ctx')
-        dw = torch.zeros_like(self.weight.data)
-        ds = ops.bifpn_backward([a.t for a in xs], [a.up for a in xs], wn, self.weight.detach(), dout.t, dw)
-        _acc_grad(self.weight, dw)
-        self.invalidate()
+        xs = self.__dict__.pop('_ctx')
+        dw, scratch = _grad_target(self.weight)
+        ds = ops.bifpn_backward([a.t for a in xs], [a.up for a in xs], self.weight.detach(), dout.t, dw, self.epsilon)
+        if scratch:
+            _acc_grad(self.weight, dw)
         return [Act(d, 0, a.c) for d, a in zip(ds, xs)]
 
 

@@ -144,13 +144,14 @@ def sppf_pool_(buf, c, x_coff=0):
     return buf
 
 
-def bifpn(srcs, ups, wn, out=None):
+def bifpn(srcs, ups, w_dev, eps=1e-4, out=None):
+    """y = sum_i w_i / (sum_j swish(w_j) + eps) * src_i; `w_dev` is the raw fusion parameter on the device."""
     n = len(srcs)
     B, H, W, Cc = srcs[0].shape
     H, W = H << ups[0], W << ups[0]
     out = torch.empty(B, H, W, Cc, device=srcs[0].device, dtype=torch.float32) if out is None else out
     ptrs = (C.c_void_p * n)(*[_ptr(_f32c(s)) for s in srcs])
-    check(_lib.lib().somi_bifpn_nhwc_f32(ptrs, (C.c_int * n)(*ups), (C.c_float * n)(*[float(v) for v in wn]), n, _ptr(out),
+    check(_lib.lib().somi_bifpn_nhwc_f32(ptrs, (C.c_int * n)(*ups), _ptr(_f32c(w_dev)), float(eps), n, _ptr(out),
                                          B, H, W, Cc, _stream()), 'bifpn')
     return out
 
@@ -187,7 +188,7 @@ def chan_stats(x, ca, c=None, x_coff=0):
 def spatial_attn(stats, w, bias, k):
     B, H, W, _ = stats.shape
     sa = torch.empty(B, H, W, device=stats.device, dtype=torch.float32)
-    check(_lib.lib().somi_spatial_attn_f32(_ptr(stats), _ptr(w), float(bias), _ptr(sa), B, H, W, k, _stream()), 'spatial_attn')
+    check(_lib.lib().somi_spatial_attn_f32(_ptr(stats), _ptr(w), _ptr(_f32c(bias)), _ptr(sa), B, H, W, k, _stream()), 'spatial_attn')
     return sa
 
 
@@ -195,7 +196,7 @@ def cbam_apply_(x, ca, stats, w, bias, k, c=None, x_coff=0):
     """In place: x[..., slice] *= ca[b,c] * sigmoid(conv_kxk(stats)+bias)  (CBAM, models/common.py:686-688)."""
     B, H, W, cs = x.shape
     c = cs - x_coff if c is None else c
-    check(_lib.lib().somi_cbam_apply_nhwc_f32(_ptr(_f32c(x)), cs, x_coff, _ptr(ca), _ptr(stats), _ptr(w), float(bias), _ptr(x), cs,
+    check(_lib.lib().somi_cbam_apply_nhwc_f32(_ptr(_f32c(x)), cs, x_coff, _ptr(ca), _ptr(stats), _ptr(w), _ptr(_f32c(bias)), _ptr(x), cs,
                                               x_coff, B, H, W, c, k, _stream()), 'cbam_apply')
     return x
 
@@ -441,14 +442,14 @@ def sppf_pool_backward_(buf, dbuf, c, x_coff=0):
     return dbuf
 
 
-def bifpn_backward(srcs, ups, wn, w_dev, dout, dw):
+def bifpn_backward(srcs, ups, w_dev, dout, dw, eps=1e-4):
     n = len(srcs)
     B, H, W, Cc = dout.shape
     dsrcs = [torch.empty_like(s) for s in srcs]
     sp = (C.c_void_p * n)(*[_ptr(_f32c(s)) for s in srcs])
     dp = (C.c_void_p * n)(*[_ptr(d) for d in dsrcs])
     ws = torch.empty(3 * 2048, device=dout.device, dtype=torch.float32)
-    check(_lib.lib().somi_bifpn_bwd_nhwc_f32(sp, dp, (C.c_int * n)(*ups), (C.c_float * n)(*[float(v) for v in wn]), _ptr(w_dev), n,
+    check(_lib.lib().somi_bifpn_bwd_nhwc_f32(sp, dp, (C.c_int * n)(*ups), _ptr(_f32c(w_dev)), float(eps), n,
                                              _ptr(_f32c(dout)), _ptr(dw), _ptr(ws), B, H, W, Cc, _stream()), 'bifpn_bwd')
     return dsrcs
 
