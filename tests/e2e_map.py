@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""End-to-end check on the MI355X: TRAIN the small SOMI graph with the product path on a synthetic rectangles task until it
+"""Test infrastructure (uses the CPU oracle).  End-to-end check on the MI355X: TRAIN the small SOMI graph with the product path on a synthetic rectangles task until it
 detects them, then evaluate the trained weights twice - product path (HIP forward, NMS, matching, AP) and CPU oracle (reference
 restatement of the same steps) - and compare mAP@0.5 / mAP@0.5:0.95 (BASELINE.json: "mAP@0.5 parity")."""
 import json

@@ -444,13 +444,12 @@ def test_train_step_gradient_accumulation():
 
 
 def test_end_to_end_training_reaches_map_and_matches_oracle():
-    """tools/e2e_map.py: 300 product-path training steps on the synthetic rectangles task must actually learn it (mAP@0.5 > 0.8),
+    """tests/e2e_map.py: 300 product-path training steps on the synthetic rectangles task must actually learn it (mAP@0.5 > 0.8),
     and the product validation pipeline (HIP forward, NMS, matching, AP) must give the same mAP as the CPU oracle evaluating the
     same trained weights (BASELINE.json: mAP@0.5 parity, +-0.1 points)."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location('e2e_map', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                          'tools', 'e2e_map.py'))
+    spec = importlib.util.spec_from_file_location('e2e_map', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'e2e_map.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     res = mod.main(300)
