@@ -156,3 +156,22 @@ def test_attempt_load_reference_style_checkpoint():
     x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         rel_close(model(x.cuda())[0], want_model(x)[0], what='z from the loaded checkpoint')
+
+
+def test_hipgraph_replay_matches_eager():
+    """somi_amd.graph.GraphedModel: one captured inference forward replayed as a hipGraph gives bit-identical predictions, also
+    for new inputs copied into its static buffer."""
+    from oracle.somi_ref.testing import SOMI_ANCHORS
+    from somi_amd.graph import GraphedModel
+    _, mine = build(0.25, 0.33, SOMI_ANCHORS, seed=4)
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randint(0, 256, (2, 3, 96, 96), generator=g, dtype=torch.uint8).cuda()
+    x1 = torch.randint(0, 256, (2, 3, 96, 96), generator=g, dtype=torch.uint8).cuda()
+    fast = GraphedModel(mine, x0)
+    with torch.no_grad():
+        for x in (x0, x1, x0):
+            z, raws = fast(x)
+            ze, rawe = mine(x)
+            assert torch.equal(z, ze) and all(torch.equal(a, b) for a, b in zip(raws, rawe))
+    with pytest.raises(RuntimeError, match='captured for'):
+        fast(x0[:1])
