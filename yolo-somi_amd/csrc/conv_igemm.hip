@@ -484,7 +484,16 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
     const int m_cls = args.cls ? (a.d.per_sample_w ? 1 : a.d.B) * cdiv(a.d.Ho, st) * cdiv(a.d.Wo, st) : a.M;   // largest class
     args.tiles_m = cdiv(m_cls, BM);
     args.tiles_n = cdiv(a.d.Cout, BN);
-    const dim3 grid(sk ? SK_GRID : args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
+    // stream-K grid: all 512 slots, unless that would leave a workgroup fewer than min_kt K-tiles (prologue, partial store and
+    // fix-up then cost more than the MFMA work of the piece)
+    static const int min_kt = getenv("SOMI_SK_MIN_KT") ? atoi(getenv("SOMI_SK_MIN_KT")) : 8;
+    int sk_grid = SK_GRID;
+    if (sk) {
+        const long U = (long)args.tiles_m * args.tiles_n * (a.K / BK);
+        if (U / min_kt < sk_grid) sk_grid = (int)(U / min_kt);
+        if (sk_grid < 2) sk_grid = 2;
+    }
+    const dim3 grid(sk ? sk_grid : args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
     if (mod && fast)
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     else if (mod)
@@ -494,7 +503,7 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
     else
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     if (sk)
-        hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(SK_GRID - 1), dim3(WAVES_M * WAVES_N * 64), 0, s, args, SK_GRID);
+        hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(sk_grid - 1), dim3(WAVES_M * WAVES_N * 64), 0, s, args, sk_grid);
     return launch_status("somi_conv2d_nhwc_f32");
 }
 
