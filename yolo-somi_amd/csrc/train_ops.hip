@@ -90,10 +90,14 @@ __device__ __forceinline__ bool stage2_sums(const float *__restrict__ p1, const 
 }
 
 // ------------------------------------------------------------------------------------------------ BN statistics
+// Sums are taken around a per-channel pivot (the running mean before this step's update, when there is one): the variance
+// sum_sq/n - mean^2 then does not cancel catastrophically for channels whose mean is large against their spread.
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float *__restrict__ x, int cs, int coff, long npix, int C,
-                                                       float *__restrict__ p1, float *__restrict__ p2, int chunk) {
+                                                       const float *__restrict__ pivot, float *__restrict__ p1, float *__restrict__ p2,
+                                                       int chunk) {
     chunk_reduce2(npix, C, p1, p2, chunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * cs + coff + c);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * cs + coff + c);
+        if (pivot) v -= f32x4{pivot[c], pivot[c + 1], pivot[c + 2], pivot[c + 3]};
         s1 += v;
         s2 += v * v;
     });
@@ -107,8 +111,9 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const float *__restrict__
     int c;
     double s, q;
     if (!stage2_sums(p1, p2, nchunk, C, c, s, q)) return;
-    const double m = s / (double)npix;
-    double var = q / (double)npix - m * m;
+    const double dm = s / (double)npix;                           // mean relative to the pivot (the old running mean)
+    const double m = (running_mean ? (double)running_mean[c] : 0.0) + dm;
+    double var = q / (double)npix - dm * dm;
     if (var < 0.0) var = 0.0;
     const float rs = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
@@ -155,11 +160,13 @@ __global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__res
 // order 1 (act then norm): d = dz,                       v = act(x). S1 = sum d, S2 = sum d*v
 __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
                                                          int x_cs, int x_coff, const float *__restrict__ scale,
-                                                         const float *__restrict__ shift, int act, int order, long npix, int C,
-                                                         float *__restrict__ p1, float *__restrict__ p2, int chunk) {
+                                                         const float *__restrict__ shift, const float *__restrict__ mean, int act, int order,
+                                                         long npix, int C, float *__restrict__ p1, float *__restrict__ p2, int chunk) {
+    // S2 is accumulated as sum d*(v - mean) directly (not sum d*v minus mean * sum d afterwards: that difference cancels)
     chunk_reduce2(npix, C, p1, p2, chunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
         const f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
         const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
+        const f32x4 mu = {mean[c], mean[c + 1], mean[c + 2], mean[c + 3]};
         f32x4 d, w;
         if (order == 0) {
             const f32x4 u = v * *reinterpret_cast<const f32x4 *>(scale + c) + *reinterpret_cast<const f32x4 *>(shift + c);
@@ -172,11 +179,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float *__restrict
             for (int e = 0; e < 4; ++e) w[e] = act_fwd(v[e], act);
         }
         s1 += d;
-        s2 += d * w;
+        s2 += d * (w - mu);
     });
 }
 // finalize: per channel coefficients of dv = A*d + Bc*v + Cc, and the parameter gradients (accumulated into dgamma / dbeta)
-//   batch statistics (train):  D = rstd*(S2 - mean*S1) = sum d*vhat;  A = scale, Bc = -scale*rstd*D/N, Cc = scale*(rstd*D*mean - S1)/N
+//   batch statistics (train):  D = rstd*S2 = sum d*vhat  (S2 = sum d*(v - mean));  A = scale, Bc = -scale*rstd*D/N, Cc = scale*(rstd*D*mean - S1)/N
 //   frozen statistics (eval):  A = scale, Bc = Cc = 0
 __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C,
                                                          long npix, const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict
     double s1, s2;
     if (!stage2_sums(p1, p2, nchunk, C, c, s1, s2)) return;
     const double m = mean[c], rs = rstd[c], sc = scale[c];
-    const double D = rs * (s2 - m * s1);
+    const double D = rs * s2;
     coefA[c] = (float)sc;
     if (batch_stats) {
         coefB[c] = (float)(-sc * rs * D / (double)npix);
@@ -275,7 +282,8 @@ extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long
     const int nchunk = somi_red_nchunk(npix);
     float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, p1, p2, red_chunk(npix));
+    hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, (const float *)running_mean, p1, p2,
+                       red_chunk(npix));
     hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
                        scale, shift, running_mean, running_var);
     return launch_status("somi_bn_stats_nhwc_f32");
@@ -302,7 +310,7 @@ extern "C" int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_
     const size_t cpad = ((size_t)C + 3) / 4 * 4;
     float *p1 = workspace, *p2 = p1 + (size_t)nchunk * C, *cA = p2 + (size_t)nchunk * C, *cB = cA + cpad, *cC = cB + cpad;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, act, order, npix, C,
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order, npix, C,
                        p1, p2, red_chunk(npix));
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
                        dgamma, dbeta);
