@@ -144,6 +144,17 @@ int somi_group_softmax_f32(const float *x, float *y, long n_groups, int K, somi_
 int somi_dcnv3_cfs_blend_f32(const float *x, const float *xproj, const float *logit, int logit_cs, float *y, long npix,
                              int G, int Gc, somi_stream_t stream);
 
+/* Backward of those pieces (training through the DCNv3 module).  LayerNorm->GELU: z = gelu(LN(u)), du from dz; dgamma / dbeta
+ * are ACCUMULATED; workspace: somi_layernorm_act_bwd_workspace_floats(npix, C) floats.  Softmax: dx = y*(dy - sum dy*y).
+ * Blend: dx = dout*(1-s), dxproj = dout*s, dlogit[p][g] = s(1-s) * sum_c dout*(xproj - x)  (dlogit row stride dlogit_cs). */
+size_t somi_layernorm_act_bwd_workspace_floats(long npix, int C);
+int somi_layernorm_gelu_bwd_nhwc_f32(const float *u, const float *gamma, const float *beta, float eps, const float *dz, float *du,
+                                     float *dgamma_accumulate, float *dbeta_accumulate, float *workspace, long npix, int C,
+                                     somi_stream_t stream);
+int somi_group_softmax_bwd_f32(const float *y, const float *dy, float *dx, long n_groups, int K, somi_stream_t stream);
+int somi_dcnv3_cfs_blend_bwd_f32(const float *x, const float *xproj, const float *logit, int logit_cs, const float *dout, float *dx,
+                                 float *dxproj, float *dlogit, int dlogit_cs, long npix, int G, int Gc, somi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bandwidth-bound layer kernels of Model._forward_once (models/yolo.py:1269-1290).
  */

@@ -130,3 +130,31 @@ def test_dcnv3_forward_wide_offsets(N, H, W, G, Gc, k, s, p, d, spread):
     dev = torch.device('cuda:0')
     got = dcnv3_forward(x.to(dev), off.to(dev), m.to(dev), k, k, s, s, p, p, d, d, G, Gc, 1.7, 256)
     rel_close(got, want, rel=1e-5, what='forward')
+
+
+@pytest.mark.parametrize('cfs', [True, False])
+def test_dcnv3_module_backward_matches_oracle(cfs):
+    """Training through the whole DCNv3 module (modules/dcnv3.py:222-379): input gradient and every parameter gradient from the
+    HIP autograd node against CPU autograd of the oracle module."""
+    from oracle.somi_ref.dcnv3 import DCNv3 as ODCN
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd.dcnv3 import DCNv3
+    ref = fill_state(ODCN(64, 3, group=4, offset_scale=1.5, center_feature_scale=cfs), 3).train()
+    mod = DCNv3(64, 3, group=4, offset_scale=1.5, center_feature_scale=cfs)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.cuda().train()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 12, 10, 64, generator=g)
+    dout = torch.randn(2, 12, 10, 64, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref(xr).backward(dout)
+    xm = x.cuda().requires_grad_(True)
+    out = mod(xm)
+    rel_close(out, ref(x).detach(), what='module forward (autograd node)')
+    out.backward(dout.cuda())
+    rel_close(xm.grad, xr.grad, what='d input')
+    for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, n
+        got, want = p.grad.cpu().double(), q.grad.double()
+        err, scale = (got - want).abs().max().item(), want.abs().max().item()
+        assert err <= 1e-3 * scale + 1e-6, f'd{n}: max err {err:.3e} vs scale {scale:.3e}'

@@ -1,0 +1,156 @@
+// Backward of the layers around the DCNv3 operator inside the DCNv3 nn.Module (models/ops_dcnv3/modules/dcnv3.py:283-291, 334,
+// 355-377): LayerNorm -> GELU after the depthwise conv, the softmax over the K sampling points of each (pixel, group), and
+// the centre-feature-scale blend.  (The Linear layers are 1x1 convolutions: somi_conv2d_dgrad / wgrad_nhwc_f32; the depthwise
+// conv: somi_dwconv3x3_bwd_nhwc_f32; the operator itself: somi_dcnv3_backward_f32.)
+#include "common.h"
+
+namespace somi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_grad(float v) {               // d/dv [0.5 v (1 + erf(v/sqrt2))]
+    return 0.5f * (1.f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
+
+// z = gelu(LN(u)):  one wave per pixel row.  du = rstd * (g - mean(g) - xhat * mean(g * xhat)) with g = dz * gelu'(v) * gamma;
+// per-row-block partial sums of dgamma = sum g0 * xhat, dbeta = sum g0 (g0 = dz * gelu'(v)) go to part[blk][2][C].
+__global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const float *__restrict__ u, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps, const float *__restrict__ dz,
+                                                          float *__restrict__ du, float *__restrict__ part, long npix, int C) {
+    extern __shared__ float sm[];                                   // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *mg = sm + (size_t)wave * 2 * C, *mb = mg + C;
+    for (int c = lane; c < C; c += 64) { mg[c] = 0.f; mb[c] = 0.f; }
+    const long wave_id = blockIdx.x * 4L + wave, nwave = (long)gridDim.x * 4;
+    for (long p = wave_id; p < npix; p += nwave) {
+        const float *ur = u + p * C, *dr = dz + p * C;
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(ur + c);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(ur + c) - mean;
+            q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 xh = (*reinterpret_cast<const f32x4 *>(ur + c) - mean) * rstd;
+            const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + c), bt = *reinterpret_cast<const f32x4 *>(beta + c);
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g0 = d[e] * gelu_grad(xh[e] * gm[e] + bt[e]);
+                mg[c + e] += g0 * xh[e];                              // this lane owns columns c..c+3 of its wave's partial
+                mb[c + e] += g0;
+                const float g = g0 * gm[e];
+                sg += g;
+                sgx += g * xh[e];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sgx += __shfl_xor(sgx, o); }
+        const float m1 = sg / (float)C, m2 = sgx / (float)C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 xh = (*reinterpret_cast<const f32x4 *>(ur + c) - mean) * rstd;
+            const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + c), bt = *reinterpret_cast<const f32x4 *>(beta + c);
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dr + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rstd * (d[e] * gelu_grad(xh[e] * gm[e] + bt[e]) * gm[e] - m1 - xh[e] * m2);
+            *reinterpret_cast<f32x4 *>(du + p * C + c) = o;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256)                    // fixed order over the 4 waves
+        part[(size_t)blockIdx.x * 2 * C + c] = (sm[c] + sm[2 * C + c]) + (sm[4 * C + c] + sm[6 * C + c]);
+}
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restrict__ part, int nblk, int C, float *dgamma, float *dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 2 * C + c];
+    if (c < C) dgamma[c] += (float)s; else dbeta[c - C] += (float)s;
+}
+
+// y = softmax(x) over K: dx_k = y_k * (dy_k - sum_j dy_j y_j); one lane per (pixel, group)
+__global__ __launch_bounds__(256) void group_softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
+                                                                long n, int K) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float dot = 0.f;
+        for (int k = 0; k < K; ++k) dot += dy[i * K + k] * y[i * K + k];
+        for (int k = 0; k < K; ++k) dx[i * K + k] = y[i * K + k] * (dy[i * K + k] - dot);
+    }
+}
+
+// out = x*(1-s) + xproj*s, s = sigmoid(logit[p][g]):  dx = dout*(1-s); dxproj = dout*s; dlogit[p][g] = s(1-s) * sum_c dout*(xproj - x).
+// One wave per pixel, lanes over channels; the sum over a group's channels is an LDS-free segmented reduction per group.
+__global__ __launch_bounds__(256) void cfs_blend_bwd_kernel(const float *__restrict__ x, const float *__restrict__ xproj,
+                                                            const float *__restrict__ logit, int logit_cs, const float *__restrict__ dout,
+                                                            float *__restrict__ dx, float *__restrict__ dxproj, float *__restrict__ dlogit,
+                                                            int dlogit_cs, long npix, int G, int Gc) {
+    const int C = G * Gc;
+    const int lane = threadIdx.x & 63;
+    const long wave_id = (blockIdx.x * 256L + threadIdx.x) >> 6, nwave = (long)gridDim.x * 4;
+    for (long p = wave_id; p < npix; p += nwave) {
+        for (int g = 0; g < G; ++g) {
+            const float sg = 1.0f / (1.0f + expf(-logit[p * logit_cs + g]));
+            float acc = 0.f;
+            for (int c = lane; c < Gc; c += 64) {
+                const long i = p * C + g * Gc + c;
+                const float d = dout[i];
+                dx[i] = d * (1.f - sg);
+                dxproj[i] = d * sg;
+                acc += d * (xproj[i] - x[i]);
+            }
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) dlogit[p * dlogit_cs + g] = acc * sg * (1.f - sg);
+        }
+    }
+}
+
+static inline int grid_for(long items, long cap = 2048) {
+    long g = (items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace somi
+
+using namespace somi;
+
+extern "C" size_t somi_layernorm_act_bwd_workspace_floats(long npix, int C) {
+    return (size_t)grid_for(npix * 64, 1024) * 2 * (size_t)C;
+}
+
+extern "C" int somi_layernorm_gelu_bwd_nhwc_f32(const float *u, const float *gamma, const float *beta, float eps, const float *dz, float *du,
+                                                float *dgamma_accumulate, float *dbeta_accumulate, float *workspace, long npix, int C,
+                                                somi_stream_t stream) {
+    SOMI_REQUIRE(u && gamma && beta && dz && du && dgamma_accumulate && dbeta_accumulate && workspace && npix > 0 && C > 0 && C % 4 == 0 &&
+                     aligned16(u) && aligned16(dz) && aligned16(du) && aligned16(gamma) && aligned16(beta), SOMI_EINVAL,
+                 "layernorm+gelu backward: bad arguments (C %% 4, 16 B alignment)");
+    SOMI_REQUIRE((size_t)C * 8 * sizeof(float) <= 64 * 1024, SOMI_ENOTIMPL, "layernorm+gelu backward: C up to 2048");
+    const int nblk = grid_for(npix * 64, 1024);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ln_gelu_bwd_kernel, dim3(nblk), dim3(256), (size_t)C * 8 * sizeof(float), s, u, gamma, beta, eps, dz, du, workspace, npix, C);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(2L * C, 256)), dim3(256), 0, s, workspace, nblk, C, dgamma_accumulate, dbeta_accumulate);
+    return launch_status("somi_layernorm_gelu_bwd_nhwc_f32");
+}
+
+extern "C" int somi_group_softmax_bwd_f32(const float *y, const float *dy, float *dx, long n_groups, int K, somi_stream_t stream) {
+    SOMI_REQUIRE(y && dy && dx && n_groups > 0 && K > 0, SOMI_EINVAL, "group softmax backward: bad arguments");
+    hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(n_groups)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n_groups, K);
+    return launch_status("somi_group_softmax_bwd_f32");
+}
+
+extern "C" int somi_dcnv3_cfs_blend_bwd_f32(const float *x, const float *xproj, const float *logit, int logit_cs, const float *dout, float *dx,
+                                            float *dxproj, float *dlogit, int dlogit_cs, long npix, int G, int Gc, somi_stream_t stream) {
+    SOMI_REQUIRE(x && xproj && logit && dout && dx && dxproj && dlogit && npix > 0 && G > 0 && Gc > 0 && logit_cs >= G && dlogit_cs >= G,
+                 SOMI_EINVAL, "cfs blend backward: bad arguments");
+    hipLaunchKernelGGL(cfs_blend_bwd_kernel, dim3(grid_for(npix * 64)), dim3(256), 0, (hipStream_t)stream, x, xproj, logit, logit_cs, dout, dx,
+                       dxproj, dlogit, dlogit_cs, npix, G, Gc);
+    return launch_status("somi_dcnv3_cfs_blend_bwd_f32");
+}

@@ -50,6 +50,10 @@ SIGNATURES = {
     'somi_dcnv3_backward_f32': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, S]),
     'somi_layernorm_act_nhwc_f32': (I, [P, P, P, F, I, P, C.c_long, I, S]),
     'somi_group_softmax_f32': (I, [P, P, C.c_long, I, S]),
+    'somi_layernorm_act_bwd_workspace_floats': (Z, [C.c_long, I]),
+    'somi_layernorm_gelu_bwd_nhwc_f32': (I, [P, P, P, F, P, P, P, P, P, C.c_long, I, S]),
+    'somi_group_softmax_bwd_f32': (I, [P, P, P, C.c_long, I, S]),
+    'somi_dcnv3_cfs_blend_bwd_f32': (I, [P, P, P, I, P, P, P, P, I, C.c_long, I, I, S]),
     'somi_dcnv3_cfs_blend_f32': (I, [P, P, P, I, P, C.c_long, I, I, S]),
     'somi_image_u8_to_nhwc4': (I, [P, P, I, I, I, I, S]),
     'somi_image_f32_to_nhwc4': (I, [P, P, I, I, I, I, F, S]),

@@ -78,8 +78,9 @@ class _ToChannelsLast(nn.Module):
 class DCNv3(nn.Module):
     """DCNv3 layer, NHWC in / NHWC out (modules/dcnv3.py:222-379).
 
-    The forward runs entirely on HIP kernels (see `forward`); autograd is wired for the deformable operator only
-    (`DCNv3Function`), the surrounding layers' backward belongs to the training path that is not built yet.
+    Forward and backward run entirely on HIP kernels: with gradients enabled the whole module is one autograd node
+    (`_DCNv3ModuleFunction`) whose backward chains the operator's backward kernel with the 1x1-conv data / weight gradients
+    of the four Linear layers, the depthwise-conv, LayerNorm+GELU, softmax and centre-feature-scale backward kernels.
     """
 
     def __init__(self, channels=64, kernel_size=3, dw_kernel_size=None, stride=1, pad=1, dilation=1, group=4,
@@ -124,22 +125,29 @@ class DCNv3(nn.Module):
             b = torch.cat([b, b.new_zeros(pad)])
         return ops.conv2d_nhwc(x, w.contiguous(), b.contiguous(), kh=1, kw=1)
 
-    def forward(self, input):
+    def _params(self):
+        dw, ln = self.dw_conv[0], self.dw_conv[1][1]
+        ps = [dw.weight, dw.bias, ln.weight, ln.bias, self.offset.weight, self.offset.bias, self.mask.weight, self.mask.bias,
+              self.input_proj.weight, self.input_proj.bias, self.output_proj.weight, self.output_proj.bias]
+        if self.center_feature_scale:
+            ps += [self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias]
+        return ps
+
+    def _forward_impl(self, input, keep=False):
         """Every arithmetic step runs in libsomi_hip.so: 4 Linear layers = 1x1 MFMA convs, depthwise conv, LayerNorm+GELU,
-        mask softmax, the deformable gather and the centre-feature-scale blend."""
+        mask softmax, the deformable gather and the centre-feature-scale blend.  keep: also return what backward needs."""
         N, H, W, C = input.shape
         if self.dw_kernel_size != 3:
             raise NotImplementedError('depthwise kernel size 3 only on the MI355X path')
         if not input.is_cuda or input.dtype != torch.float32:
             raise RuntimeError('DCNv3 runs on float32 GPU tensors only (no CPU fallback)')
         input = input.contiguous()
-        x = self._linear(input, self.input_proj.weight, self.input_proj.bias)
-        x_proj = x
+        x_proj = self._linear(input, self.input_proj.weight, self.input_proj.bias)
         dw = self.dw_conv[0]
         ln = self.dw_conv[1][1]
         wdw = dw.weight.detach().float()[:, 0].permute(1, 2, 0).reshape(9, C).contiguous()
-        x1 = ops.dwconv3x3(input, wdw, dw.bias.detach().float().contiguous())
-        x1 = ops.layernorm_act(x1, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
+        u = ops.dwconv3x3(input, wdw, dw.bias.detach().float().contiguous())
+        x1 = ops.layernorm_act(u, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
         K = self.kernel_size * self.kernel_size
         offset = self._linear(x1, self.offset.weight, self.offset.bias)
         mlog = self._linear(x1, self.mask.weight, self.mask.bias)
@@ -148,10 +156,88 @@ class DCNv3(nn.Module):
         if mlog.shape[-1] != self.group * K:
             mlog = mlog[..., :self.group * K].contiguous()
         mask = ops.group_softmax(mlog, K)
-        x = DCNv3Function.apply(x, offset, mask, self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad,
-                                self.pad, self.dilation, self.dilation, self.group, self.group_channels,
-                                self.offset_scale, 256)
+        y = dcnv3_forward(x_proj, offset, mask, self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad,
+                          self.pad, self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale, 256)
+        logit, yb = None, y
         if self.center_feature_scale:
             logit = self._linear(x1, self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias)
-            x = ops.cfs_blend(x, x_proj, logit, self.group, self.group_channels)
-        return self._linear(x, self.output_proj.weight, self.output_proj.bias)
+            yb = ops.cfs_blend(y, x_proj, logit, self.group, self.group_channels)
+        out = self._linear(yb, self.output_proj.weight, self.output_proj.bias)
+        if keep:
+            return out, (input, x_proj, wdw, u, x1, offset, mask, y, logit, yb)
+        return out
+
+    def forward(self, input):
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _DCNv3ModuleFunction.apply(self, input, *self._params())
+        return self._forward_impl(input)
+
+    # ------------------------------------------------------------------------------------------ backward of the whole module
+    def _backward_impl(self, saved, dout):
+        """-> (dinput, [parameter gradients in the order of _params()])."""
+        input, x_proj, wdw, u, x1, offset, mask, y, logit, yb = saved
+        N, H, W, C = input.shape
+        G, Gc, K = self.group, self.group_channels, self.kernel_size * self.kernel_size
+        if (G * K) % 4 or (self.center_feature_scale and G % 4) or (H, W) != tuple(y.shape[1:3]):
+            raise NotImplementedError('DCNv3 module backward: group*K (and group, with centre feature scale) must be multiples of 4, '
+                                      'stride 1')
+        dev = input.device
+        dout = dout.contiguous().float()
+
+        def lin_bwd(x, w, dy, need_dx=True):
+            """y = x @ w.T + b as a 1x1 conv: -> (dx, dw (out,in), db)."""
+            cout, cin = w.shape
+            gw = ops.conv2d_wgrad_nhwc(x, dy, kh=1, kw=1, cin=cin, cout=cout)
+            gb = torch.zeros(cout, device=dev)
+            ops.chan_sum_(dy, cout, 0, gb)
+            dx = None
+            if need_dx:
+                dx = ops.conv2d_dgrad_nhwc(dy, w.detach().float().t().contiguous(), B=N, H=x.shape[1], W=x.shape[2], cin=cin, kh=1, kw=1,
+                                           cout=cout)
+            return dx, gw, gb
+
+        dyb, g_wout, g_bout = lin_bwd(yb, self.output_proj.weight, dout)
+        g_wc = g_bc = None
+        dx1 = None
+        if self.center_feature_scale:
+            dy, dxp, dlogit = ops.cfs_blend_backward(y, x_proj, logit, dyb, G, Gc)
+            dx1, g_wc, g_bc = lin_bwd(x1, self.center_feature_scale_proj_weight, dlogit)
+        else:
+            dy, dxp = dyb, None
+        dxp_op, doff, dmask = dcnv3_backward(x_proj, offset, mask, self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad,
+                                             self.pad, self.dilation, self.dilation, G, Gc, self.offset_scale, dy.contiguous(), 256)
+        dxp = dxp_op if dxp is None else ops.add_(dxp, 0, dxp_op, 0, C)
+        dmlog = ops.group_softmax_backward(mask, dmask, K)
+        d1, g_woff, g_boff = lin_bwd(x1, self.offset.weight, doff)
+        d2, g_wm, g_bm = lin_bwd(x1, self.mask.weight, dmlog)
+        dx1 = d1 if dx1 is None else ops.add_(dx1, 0, d1, 0, C)
+        ops.add_(dx1, 0, d2, 0, C)
+        ln = self.dw_conv[1][1]
+        g_lnw, g_lnb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        du = ops.layernorm_gelu_backward(u, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, dx1,
+                                         g_lnw, g_lnb)
+        dinp, g_win, g_bin = lin_bwd(input, self.input_proj.weight, dxp)
+        g_dw9, g_dwb = torch.zeros(9, C, device=dev), torch.zeros(C, device=dev)
+        dinput = ops.dwconv3x3_backward(du, input, wdw, g_dw9, g_dwb, dx_accumulate=dinp)
+        g_dw = g_dw9.view(3, 3, C).permute(2, 0, 1).unsqueeze(1).contiguous()
+        grads = [g_dw, g_dwb, g_lnw, g_lnb, g_woff, g_boff, g_wm, g_bm, g_win, g_bin, g_wout, g_bout]
+        if self.center_feature_scale:
+            grads += [g_wc, g_bc]
+        return dinput, grads
+
+
+class _DCNv3ModuleFunction(Function):
+    """The whole DCNv3 module as one autograd node (forward and backward on HIP kernels only)."""
+
+    @staticmethod
+    def forward(ctx, module, input, *params):
+        out, saved = module._forward_impl(input.detach(), keep=True)
+        ctx.module, ctx.saved = module, saved
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        dinput, grads = ctx.module._backward_impl(ctx.saved, dout)
+        ctx.saved = None
+        return (None, dinput) + tuple(grads)

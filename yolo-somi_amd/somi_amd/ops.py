@@ -245,6 +245,34 @@ def group_softmax(x, K):
     return out
 
 
+def layernorm_gelu_backward(u, gamma, beta, eps, dz, dgamma, dbeta):
+    """z = gelu(LayerNorm(u)) -> du; dgamma / dbeta are accumulated."""
+    C_ = u.shape[-1]
+    n = u.numel() // C_
+    du = torch.empty_like(u)
+    L = _lib.lib()
+    ws = torch.empty(L.somi_layernorm_act_bwd_workspace_floats(n, C_), device=u.device, dtype=torch.float32)
+    check(L.somi_layernorm_gelu_bwd_nhwc_f32(_ptr(_f32c(u)), _ptr(gamma), _ptr(beta), float(eps), _ptr(_f32c(dz)), _ptr(du), _ptr(dgamma),
+                                             _ptr(dbeta), _ptr(ws), n, C_, _stream()), 'layernorm_gelu_bwd')
+    return du
+
+
+def group_softmax_backward(y, dy, K):
+    dx = torch.empty_like(y)
+    check(_lib.lib().somi_group_softmax_bwd_f32(_ptr(_f32c(y)), _ptr(_f32c(dy)), _ptr(dx), y.numel() // K, K, _stream()), 'group_softmax_bwd')
+    return dx
+
+
+def cfs_blend_backward(x, xproj, logit, dout, G, Gc):
+    """-> (dx, dxproj, dlogit) of out = x*(1-s) + xproj*s, s = sigmoid(logit) broadcast over a group's channels."""
+    dx, dxp = torch.empty_like(x), torch.empty_like(x)
+    dlogit = torch.zeros_like(logit)                              # pad columns (if any) stay zero
+    check(_lib.lib().somi_dcnv3_cfs_blend_bwd_f32(_ptr(_f32c(x)), _ptr(_f32c(xproj)), _ptr(_f32c(logit)), logit.shape[-1], _ptr(_f32c(dout)),
+                                                  _ptr(dx), _ptr(dxp), _ptr(dlogit), dlogit.shape[-1], x.numel() // (G * Gc), G, Gc,
+                                                  _stream()), 'cfs_blend_bwd')
+    return dx, dxp, dlogit
+
+
 def cfs_blend(x, xproj, logit, G, Gc):
     out = torch.empty_like(x)
     check(_lib.lib().somi_dcnv3_cfs_blend_f32(_ptr(_f32c(x)), _ptr(_f32c(xproj)), _ptr(_f32c(logit)), logit.shape[-1], _ptr(out),
