@@ -102,3 +102,27 @@ def test_read_checkpoint_without_the_checkpoints_code_base():
     sd, want = m.state_dict(), ref.half().state_dict()
     assert list(sd) == list(want) and all(torch.equal(sd[k], want[k]) for k in sd)
     assert isinstance(m.yaml, dict) and m.yaml['nc'] == 10
+
+
+def test_warmup_and_one_cycle_schedule():
+    """train.py:146,250-256: one_cycle lambda and the per-batch warm-up of lr (biases from warmup_bias_lr) and accumulate."""
+    import math
+    import types
+    from somi_amd.train import one_cycle, scheduler_step, warmup_lr
+    hyp = dict(warmup_bias_lr=0.1, warmup_momentum=0.8, momentum=0.843, lrf=0.12)
+    lf = one_cycle(1, hyp['lrf'], 100)
+    assert abs(lf(0) - 1.0) < 1e-12 and abs(lf(100) - 0.12) < 1e-12 and abs(lf(50) - (0.5 * (0.12 - 1) + 1)) < 1e-12
+    opt = types.SimpleNamespace(param_groups=[dict(lr=3e-4, initial_lr=3e-4), dict(lr=3e-4, initial_lr=3e-4, weight_decay=1e-4),
+                                              dict(lr=3e-4, initial_lr=3e-4)])
+    nw = 1000
+    assert warmup_lr(opt, 0, nw, 0, lf, hyp, batch_size=16) == 1
+    assert [g['lr'] for g in opt.param_groups] == [0.0, 0.0, 0.1]
+    acc = warmup_lr(opt, 500, nw, 2, lf, hyp, batch_size=16)
+    assert acc == 2                                              # halfway between 1 and nbs / batch = 4, rounded like numpy (2.5 -> 2)
+    want = 0.5 * 3e-4 * lf(2)
+    assert abs(opt.param_groups[0]['lr'] - want) < 1e-15 and abs(opt.param_groups[2]['lr'] - (0.05 + want)) < 1e-12
+    assert warmup_lr(opt, nw, nw, 3, lf, hyp, batch_size=16) == 4
+    assert all(abs(g['lr'] - 3e-4 * lf(3)) < 1e-15 for g in opt.param_groups)
+    scheduler_step(opt, 40, lf)
+    assert all(abs(g['lr'] - 3e-4 * lf(40)) < 1e-18 for g in opt.param_groups)
+    assert math.isclose(lf(100), hyp['lrf'])

@@ -15,6 +15,32 @@ from .loss import ComputeLoss
 from .optim import build_optimizer
 
 
+def one_cycle(y1=0.0, y2=1.0, steps=100):
+    """Sinusoidal ramp from y1 to y2 over `steps` epochs (utils/general.py:462-468): the `lf` of train.py:146."""
+    import math
+    return lambda x: ((1 - math.cos(x * math.pi / steps)) / 2) * (y2 - y1) + y1
+
+
+def warmup_lr(optimizer, ni, nw, epoch, lf, hyp, batch_size, nbs=64):
+    """The warm-up of train.py:250-256 for global batch index `ni` (<= nw): every group's lr ramps linearly from 0 (biases - group
+    2 - from hyp['warmup_bias_lr']) to initial_lr * lf(epoch); returns the accumulation count the reference would use at `ni`
+    (ramping 1 -> nbs / batch_size).  Groups that carry a 'momentum' key (SGD) ramp it too; Adam's groups have none."""
+    import numpy as np
+    xi = [0, nw]
+    accumulate = max(1, np.interp(ni, xi, [1, nbs / batch_size]).round())
+    for j, x in enumerate(optimizer.param_groups):
+        x['lr'] = float(np.interp(ni, xi, [hyp['warmup_bias_lr'] if j == 2 else 0.0, x['initial_lr'] * lf(epoch)]))
+        if 'momentum' in x:
+            x['momentum'] = float(np.interp(ni, xi, [hyp['warmup_momentum'], hyp['momentum']]))
+    return int(accumulate)
+
+
+def scheduler_step(optimizer, epoch, lf):
+    """lr_scheduler.LambdaLR(optimizer, lr_lambda=lf).step() (train.py:148,284-285): lr = initial_lr * lf(epoch) for every group."""
+    for x in optimizer.param_groups:
+        x['lr'] = x['initial_lr'] * lf(epoch)
+
+
 class TrainStep:
     def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1):
         """accumulate: optimizer step every `accumulate` batches (train.py:121,252,272: max(round(nbs / total_batch), 1) in the
