@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Soak run of the full-size training step on synthetic data: loss trend, finite checks, steady memory.  usage: soak_train.py [steps]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'yolo-somi_amd'))
+import torch  # noqa: E402
+
+from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch  # noqa: E402
+from somi_amd.model import Model  # noqa: E402
+from somi_amd.train import TrainStep, one_cycle, warmup_lr  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+dev = torch.device('cuda')
+model = fill_state(Model(somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS)), 1).to(dev)
+hyp = dict(HYP_VISDRONE)
+tr = TrainStep(model, hyp, 32)
+lf = one_cycle(1, hyp['lrf'], 300)
+batches = [synthetic_batch(32, 640, seed=50 + i) for i in range(4)]
+batches = [(a.to(dev), b.to(dev)) for a, b in batches]
+log, t0 = [], time.time()
+for it in range(steps):
+    warmup_lr(tr.optimizer, it, max(steps, 1), 0, lf, hyp, 32)            # the reference's warm-up ramp over the whole soak
+    imgs, tg = batches[it % len(batches)]
+    loss, items = tr.step(imgs, tg)
+    if it % 10 == 0 or it == steps - 1:
+        log.append({'step': it, 'loss': round(float(loss), 4), 'items': [round(float(v), 4) for v in items],
+                    'mem_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2)})
+        assert torch.isfinite(loss).all(), log[-1]
+torch.cuda.synchronize()
+finite = all(bool(torch.isfinite(b).all()) for b in tr.optimizer.flat_params)
+print(json.dumps({'steps': steps, 'seconds': round(time.time() - t0, 1), 'weights_finite': finite, 'log': log}))
