@@ -1,4 +1,6 @@
-import sys, os, torch
+import sys
+
+import torch
 sys.path.insert(0, '/root/repo/yolo-somi_amd')
 from somi_amd import ops
 d = torch.device('cuda')

@@ -7,12 +7,10 @@ parameter names, so a reference state_dict loads unchanged.  Errors raise Runtim
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
-from .pack import pad4
 
 
 def _checked(t, name):

@@ -8,8 +8,6 @@ the hand-written reverse walk (conv dgrad / wgrad on MFMA, BN / attention / ODCo
 With more than one rank the flat gradient buffers are all-reduced (SUM) in buckets on a side stream while the backward walk is
 still running (ddp.GradBuckets) - DDP's semantics without the wrapper.  fp32 throughout (no GradScaler: nothing to scale).
 """
-import torch
-
 from .ddp import GradBuckets, layer_offsets
 from .loss import ComputeLoss
 from .optim import build_optimizer
