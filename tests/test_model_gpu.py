@@ -175,3 +175,38 @@ def test_hipgraph_replay_matches_eager():
             assert torch.equal(z, ze) and all(torch.equal(a, b) for a, b in zip(raws, rawe))
     with pytest.raises(RuntimeError, match='captured for'):
         fast(x0[:1])
+
+
+@pytest.mark.parametrize('nc', [1, 80])
+def test_other_class_counts(nc):
+    """single-class (no = 6; the reference drops the class loss, utils/loss.py:182) and COCO-sized heads (no = 85): eval
+    predictions, training loss and gradients against the oracle."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.loss import ComputeLoss as OLoss
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    from somi_amd.model import Model
+    cfg = somi_cfg(0.25, 0.33, nc=nc, anchors=SOMI_ANCHORS)
+    ref = fill_state(OModel(cfg), 9)
+    mine = Model(cfg)
+    mine.load_state_dict(ref.state_dict())
+    ref.hyp = mine.hyp = dict(HYP_VISDRONE)
+    imgs, targets = synthetic_batch(2, 64, nc=nc, seed=2)
+    mine = mine.cuda().eval()
+    ref.eval()
+    with torch.no_grad():
+        rel_close(mine(imgs.cuda())[0], ref(imgs.float() / 255)[0], what=f'z nc={nc}')
+    ref.train()
+    mine.train()
+    lr, ir = OLoss(ref)(ref(imgs.float() / 255), targets)
+    lr.backward()
+    lm, im = ComputeLoss(mine)(mine(imgs.cuda()), targets.cuda())
+    rel_close(lm, lr.detach(), rel=1e-4, what='loss')
+    rel_close(im, ir, rel=1e-4, what='loss items')
+    lm.backward()
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            continue
+        err = (p.grad.cpu().double() - q.grad.double()).abs().max().item()
+        scale = q.grad.double().abs().max().item()
+        assert err <= 2e-3 * scale + 2e-6, (n, err, scale)
