@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 4
+#define SOMI_ABI_VERSION 5
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -80,11 +80,20 @@ typedef struct somi_conv_desc {
                                * then differ from the unsplit sum by fp32 rounding only).  NULL: one workgroup per tile. */
     uint64_t workspace_bytes;
     const float *residual2;   /* optional second tensor added after the activation (NHWC (B,Ho,Wo,*)), or NULL */
+    /* Optional per-channel statistics of the stored output for a following BatchNorm in training mode (the conv epilogue
+     * has every value in registers: this saves the separate read of y).  stat_sum / stat_sumsq: [somi_conv2d_stat_rows(d)][Cout]
+     * partial sums of (y - pivot) and (y - pivot)^2 - one row per (row tile, wave row), each written exactly once; stat_pivot:
+     * [Cout] or NULL (= 0).  Reduce them with somi_bn_stats_partials_f32.  Needs Cout % 4 == 0 and per_sample_w == 0. */
+    float *stat_sum;
+    float *stat_sumsq;
+    const float *stat_pivot;
 } somi_conv_desc;
 
 int somi_conv2d_nhwc_f32(const somi_conv_desc *d, somi_stream_t stream);
 /* Scratch size that enables the stream-K schedule for every shape (64 MiB). */
 size_t somi_conv2d_workspace_bytes(void);
+/* Rows of the stat_sum / stat_sumsq partial arrays somi_conv2d_nhwc_f32 would write for this descriptor. */
+int somi_conv2d_stat_rows(const somi_conv_desc *d);
 
 /* Data gradient of the convolution whose FORWARD geometry `fwd` describes (x (B,H,W,Cin) -> y (B,Ho,Wo,Cout); the pointer
  * fields of `fwd` are ignored):  dx[b,h,w,ci] = sum_{r,q,co} dy[b,(h+p-r)/s,(w+p-q)/s,co] * W[co][ci][r][q]
@@ -251,6 +260,11 @@ int somi_red_nchunk(long npix);
 int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float eps, float momentum,
                            const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
                            float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
+/* The same from the partial sums a convolution left behind (somi_conv_desc.stat_sum / stat_sumsq, `rows` rows, taken around
+ * running_mean as the pivot when running_mean is given - pass the same pointer as stat_pivot).  workspace: 2*1024*C floats. */
+int somi_bn_stats_partials_f32(const float *part_sum, const float *part_sumsq, int rows, long npix, int C, float eps, float momentum,
+                               const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                               float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
 int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act,
                                   int order, float *z, int z_cs, int z_coff, long npix, int C, const float *residual /* or NULL: added last */,
                                   int res_cs, int res_coff, somi_stream_t stream);

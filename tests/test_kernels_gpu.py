@@ -360,3 +360,35 @@ def test_conv_tensors_beyond_the_descriptor_range():
     dx = ops.conv2d_dgrad_nhwc(x, wt, B=B, H=H, W=H, cin=32, kh=1, kw=1)
     rel_close(dx[:h], ops.conv2d_dgrad_nhwc(x[:h], wt, B=h, H=H, W=H, cin=32, kh=1, kw=1), rel=1e-5, what='dgrad, first half')
     rel_close(dx[h:], ops.conv2d_dgrad_nhwc(x[h:], wt, B=B - h, H=H, W=H, cin=32, kh=1, kw=1), rel=1e-5, what='dgrad, second half')
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,s', [(4, 40, 40, 128, 256, 3, 1),      # stream-K schedule: cut tiles finish in the fix-up kernel
+                                                (3, 37, 29, 32, 64, 3, 2),       # ragged rows, 128x64 tiles
+                                                (2, 16, 16, 4, 32, 3, 1),        # generic (non-uniform tap) path, 128x32 tiles
+                                                (64, 20, 20, 64, 256, 1, 1),     # whole tiles, one workgroup each
+                                                (40, 80, 80, 32, 128, 1, 1)])    # more than 1024 partial rows: the fold pass
+def test_conv_epilogue_batchnorm_statistics(B, H, W, Cin, Cout, k, s):
+    """The training forward takes BatchNorm's batch statistics from partial sums the conv epilogue leaves behind (around the
+    running mean as pivot): mean / variance / running statistics must equal the separate statistics pass over y."""
+    from somi_amd import ops
+    g = torch.Generator().manual_seed(B + H + Cout)
+    d = dev()
+    x = torch.randn(B, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, k * k * Cin, generator=g) / math.sqrt(k * k * Cin)).to(d)
+    gam, bet = (torch.rand(Cout, generator=g) + 0.5).to(d), torch.randn(Cout, generator=g).to(d)
+    rm0, rv0 = (torch.randn(Cout, generator=g) * 0.3).to(d), (torch.rand(Cout, generator=g) + 0.5).to(d)
+    st = {'pivot': rm0}
+    y = ops.conv2d_nhwc(x, w, None, kh=k, kw=k, stride=s, pad=k // 2, bn_stats=st)
+    y_plain = ops.conv2d_nhwc(x, w, None, kh=k, kw=k, stride=s, pad=k // 2)
+    assert torch.equal(y, y_plain)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    got = ops.bn_stats_from_partials(st['part'], st['rows'], y.shape[0] * y.shape[1] * y.shape[2], Cout, gam, bet, 1e-3, 0.03, rm1, rv1)
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    want = ops.bn_stats(y, Cout, 0, gam, bet, 1e-3, 0.03, rm2, rv2)
+    for a, b, what in zip(got, want, ('mean', 'rstd', 'scale', 'shift')):
+        rel_close(a, b, rel=1e-5, what=what)
+    rel_close(rm1, rm2, rel=1e-6, what='running mean')
+    rel_close(rv1, rv2, rel=1e-5, what='running var')
+    yd = y.double().cpu().reshape(-1, Cout)
+    rel_close(got[0], yd.mean(0), rel=1e-5, what='mean vs fp64')
+    rel_close(1.0 / got[1].double().cpu() ** 2 - 1e-3, yd.var(0, unbiased=False), rel=1e-4, what='variance vs fp64')

@@ -94,6 +94,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
     const size_t row_base = (size_t)rm.bz * a.M;
     constexpr int NQ = WN / 4;                                    // float4 per staged row
     const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+    // optional BatchNorm statistics: a lane always sweeps the same column quad (64 % NQ == 0), so it keeps that quad's sums
+    const bool stats = d.stat_sum != nullptr;
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, piv = st1;
+    if (stats && d.stat_pivot && nw + (lane % NQ) * 4 < d.Cout) piv = *reinterpret_cast<const f32x4 *>(d.stat_pivot + nw + (lane % NQ) * 4);
     for (int idx = lane; idx < WM * NQ; idx += 64) {
         const int ml = idx / NQ, n = nw + (idx % NQ) * 4, m = mw + ml;
         if (m >= rm.Mrows || n >= d.Cout) continue;
@@ -120,6 +124,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
             if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + n);
             if (rrow2) v += *reinterpret_cast<const f32x4 *>(rrow2 + n);
             *reinterpret_cast<f32x4 *>(yrow + n) = v;
+            if (stats) {
+                const f32x4 t = v - piv;
+                st1 += t;
+                st2 += t * t;
+            }
         } else {
             for (int e = 0; e < 4 && n + e < d.Cout; ++e) {          // ragged Cout tail
                 float t = v[e] + (bias ? bias[n + e] : 0.f);
@@ -129,6 +138,21 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
                 if (rrow2) t += rrow2[n + e];
                 yrow[n + e] = t;
             }
+        }
+    }
+    if (stats) {                                                  // fold the 64 / NQ lanes that share a column quad, then one row per (tile, wave row)
+#pragma unroll
+        for (int off = NQ; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st1[e] += __shfl_xor(st1[e], off);
+                st2[e] += __shfl_xor(st2[e], off);
+            }
+        const int n = nw + lane * 4;
+        if (lane < NQ && n < d.Cout) {
+            const size_t prow = (size_t)(m0 / BM) * WAVES_M + wm;
+            *reinterpret_cast<f32x4 *>(d.stat_sum + prow * d.Cout + n) = st1;
+            *reinterpret_cast<f32x4 *>(d.stat_sumsq + prow * d.Cout + n) = st2;
         }
     }
 }
@@ -557,6 +581,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
             sub.y = d.y + (size_t)b0 * d.Ho * d.Wo * d.y_cs;
             if (d.residual) sub.residual = d.residual + (size_t)b0 * d.Ho * d.Wo * d.res_cs;
             if (d.residual2) sub.residual2 = d.residual2 + (size_t)b0 * d.Ho * d.Wo * d.res2_cs;
+            SOMI_REQUIRE(!d.stat_sum, SOMI_ENOTIMPL, "conv: statistics of a tensor beyond the 4 GiB descriptor range");
             if (d.a_chan_scale) sub.a_chan_scale = d.a_chan_scale + (size_t)b0 * d.Cin;
             if (d.a_pix_scale) sub.a_pix_scale = d.a_pix_scale + (size_t)b0 * d.H * d.W;
             if (d.per_sample_w) {
@@ -573,6 +598,10 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
     a.chan_bytes = (unsigned)((size_t)d.B * d.Cin * 4);
     a.pix_bytes = (unsigned)((size_t)d.B * d.H * d.W * 4);
     SOMI_REQUIRE(!d.workspace || aligned16(d.workspace), SOMI_EINVAL, "conv: workspace must be 16 B aligned");
+    SOMI_REQUIRE(!d.stat_sum == !d.stat_sumsq, SOMI_EINVAL, "conv: stat_sum and stat_sumsq go together");
+    SOMI_REQUIRE(!d.stat_sum || (d.Cout % 4 == 0 && !d.per_sample_w && !dgrad && aligned16(d.stat_sum) && aligned16(d.stat_sumsq) &&
+                                 (!d.stat_pivot || aligned16(d.stat_pivot))),
+                 SOMI_EINVAL, "conv: statistics need Cout %% 4 == 0, shared weights, 16 B aligned buffers");
     a.dgrad = dgrad;
     a.cls = 0;
     a.sk = 0;
@@ -625,6 +654,14 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
     snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::plan_tiles(*dp, M, 0).variant], mod ? "true" : "false",
              fast ? "true" : "false");
     return name;
+}
+
+extern "C" int somi_conv2d_stat_rows(const somi_conv_desc *dp) {
+    if (!dp || dp->Cout <= 0 || dp->Ho <= 0 || dp->Wo <= 0 || dp->B <= 0 || dp->per_sample_w) return 0;
+    static const int waves_m[6] = {2, 1, 2, 4, 2, 4};
+    const int M = dp->B * dp->Ho * dp->Wo;
+    const int v = somi::plan_tiles(*dp, M, 0).variant;
+    return somi::cdiv(M, somi::kTileBM[v]) * waves_m[v];
 }
 
 extern "C" size_t somi_conv2d_workspace_bytes(void) { return (size_t)somi::SK_GRID * 2 * 128 * 128 * sizeof(float); }

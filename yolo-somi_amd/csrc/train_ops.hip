@@ -128,6 +128,19 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const float *__restrict__
     }
 }
 
+// partial rows left by a convolution's epilogue (one per row tile and wave row, up to tens of thousands): fold them to <= 1024 rows
+// so that stage 2 keeps its short chains.  grid (rows_out, ceil(C/256)); fixed summation order.
+__global__ __launch_bounds__(256) void rows_fold_kernel(const float *__restrict__ p1, const float *__restrict__ p2, int rows, int C, int per,
+                                                        float *__restrict__ o1, float *__restrict__ o2) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.x * per, r1 = min(r0 + per, rows);
+    float a = 0.f, b = 0.f;
+    for (int r = r0; r < r1; ++r) { a += p1[(size_t)r * C + c]; b += p2[(size_t)r * C + c]; }
+    o1[(size_t)blockIdx.x * C + c] = a;
+    o2[(size_t)blockIdx.x * C + c] = b;
+}
+
 // ------------------------------------------------------------------------------------------------ affine + activation
 // order 0: z = act(x*scale + shift) ; order 1: z = act(x)*scale + shift        (x, z: channel slices; in place allowed)
 __global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__restrict__ x, int x_cs, int x_coff,
@@ -287,6 +300,28 @@ extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long
     hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
                        scale, shift, running_mean, running_var);
     return launch_status("somi_bn_stats_nhwc_f32");
+}
+
+extern "C" int somi_bn_stats_partials_f32(const float *part_sum, const float *part_sumsq, int rows, long npix, int C, float eps, float momentum,
+                                          const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                                          float *running_mean, float *running_var, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(part_sum && part_sumsq && rows > 0 && npix > 0 && C > 0 && mean && rstd && scale && shift && workspace, SOMI_EINVAL,
+                 "bn stats from partials: bad arguments");
+    SOMI_REQUIRE(!running_mean == !running_var, SOMI_EINVAL, "bn stats: running_mean and running_var go together");
+    hipStream_t s = (hipStream_t)stream;
+    const float *p1 = part_sum, *p2 = part_sumsq;
+    int nchunk = rows;
+    if (rows > 1024) {
+        const int per = cdiv(rows, 1024);
+        nchunk = cdiv(rows, per);
+        float *o1 = workspace, *o2 = workspace + (size_t)1024 * C;
+        hipLaunchKernelGGL(rows_fold_kernel, dim3(nchunk, cdiv(C, 256)), dim3(256), 0, s, part_sum, part_sumsq, rows, C, per, o1, o2);
+        p1 = o1;
+        p2 = o2;
+    }
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
+                       scale, shift, running_mean, running_var);
+    return launch_status("somi_bn_stats_partials_f32");
 }
 
 extern "C" int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act,

@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ('B', 'H', 'W', 'Cin', 'x_cs', 'x_coff', 'Ho', 'Wo', 'Cout', 'y_cs', 'y_coff',
                                          'kh', 'kw', 'stride', 'pad', 'dil', 'res_cs', 'res_coff', 'act', 'per_sample_w')] + \
                [('res2_cs', C.c_int32), ('res2_coff', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_uint64),
-                ('residual2', C.c_void_p)]
+                ('residual2', C.c_void_p), ('stat_sum', C.c_void_p), ('stat_sumsq', C.c_void_p), ('stat_pivot', C.c_void_p)]
 
 
 class LossDesc(C.Structure):
@@ -42,6 +42,7 @@ SIGNATURES = {
     'somi_last_error': (C.c_char_p, []),
     'somi_conv2d_nhwc_f32': (I, [C.POINTER(ConvDesc), S]),
     'somi_conv2d_workspace_bytes': (Z, []),
+    'somi_conv2d_stat_rows': (I, [C.POINTER(ConvDesc)]),
     'somi_conv2d_dgrad_nhwc_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, P, I, I, P, I, I, S]),
     'somi_conv2d_wgrad_workspace_bytes': (Z, [C.POINTER(ConvDesc)]),
     'somi_conv2d_wgrad_nhwc_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, I, I, P, P, P, Z, S]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     'somi_detect_decode_f32': (I, [P, I, P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
     'somi_red_nchunk': (I, [C.c_long]),
     'somi_bn_stats_nhwc_f32': (I, [P, I, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
+    'somi_bn_stats_partials_f32': (I, [P, P, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
     'somi_chan_affine_act_nhwc_f32': (I, [P, I, I, P, P, I, I, P, I, I, C.c_long, I, P, I, I, S]),
     'somi_bn_act_backward_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, P, I, I, P, P, C.c_long, I, P, S]),
     'somi_add_nhwc_f32': (I, [P, I, I, P, I, I, P, I, I, C.c_long, I, S]),
@@ -122,7 +124,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != 4:
+        if L.somi_abi_version() != 5:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib

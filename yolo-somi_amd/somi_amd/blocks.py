@@ -182,9 +182,16 @@ class Conv(_Packed):
         B, H, W, _ = x.shape
         Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
         y = torch.empty(B, Ho, Wo, cp, device=x.t.device, dtype=torch.float32)
-        ops.conv2d_nhwc(x.t, pk['wp'], None, kh=k, kw=k, stride=s, pad=p, act='none', cin=pad4(x.c), x_coff=x.coff, out=y, cout=cp,
-                        alg_cin=x.c, alg_cout=c2)
-        mean, rstd, scale, shift = ops.bn_stats(y, cp, 0, pk['gamma'], pk['beta'], self.bn.eps, self.bn.momentum, pk['rm'], pk['rv'])
+        if ops.FUSED_BN_STATS and y.numel() * 4 <= 0xE0000000:      # the conv epilogue leaves the per-channel partial sums of y
+            st = {'pivot': pk['rm']}
+            ops.conv2d_nhwc(x.t, pk['wp'], None, kh=k, kw=k, stride=s, pad=p, act='none', cin=pad4(x.c), x_coff=x.coff, out=y, cout=cp,
+                            alg_cin=x.c, alg_cout=c2, bn_stats=st)
+            mean, rstd, scale, shift = ops.bn_stats_from_partials(st['part'], st['rows'], B * Ho * Wo, cp, pk['gamma'], pk['beta'],
+                                                                  self.bn.eps, self.bn.momentum, pk['rm'], pk['rv'])
+        else:
+            ops.conv2d_nhwc(x.t, pk['wp'], None, kh=k, kw=k, stride=s, pad=p, act='none', cin=pad4(x.c), x_coff=x.coff, out=y, cout=cp,
+                            alg_cin=x.c, alg_cout=c2)
+            mean, rstd, scale, shift = ops.bn_stats(y, cp, 0, pk['gamma'], pk['beta'], self.bn.eps, self.bn.momentum, pk['rm'], pk['rv'])
         with torch.no_grad():                                    # running statistics back into the module buffers
             if not pk['inplace']:
                 self.bn.running_mean.copy_(pk['rm'][:c2])

@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import ConvDesc, check
 
 STREAMK = os.environ.get('SOMI_CONV_STREAMK', '1') != '0'
+FUSED_BN_STATS = os.environ.get('SOMI_FUSED_BN_STATS', '1') != '0'   # batch statistics from the conv epilogue (training forward)
 PROFILE = None   # bench.py sets this to a list: every conv launch appends (kernel name, algorithmic FLOPs, ev0, ev1)
 
 ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4, 'softmax': 5}
@@ -56,7 +57,7 @@ def conv_out_size(size, k, s, p, d=1):
 
 def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', cin=None, x_coff=0, out=None,
                 cout=None, y_coff=0, post_scale=None, post_shift=None, residual=None, res_coff=0, a_chan_scale=None,
-                a_pix_scale=None, per_sample_w=False, alg_cin=None, alg_cout=None):
+                a_pix_scale=None, per_sample_w=False, alg_cin=None, alg_cout=None, bn_stats=None):
     """x (B,H,W,x_cs) NHWC; w packed [n_sets][Cout][kh*kw*Cin]; returns / fills out (B,Ho,Wo,y_cs)."""
     B, H, W, x_cs = x.shape
     cin = x_cs - x_coff if cin is None else cin
@@ -76,6 +77,11 @@ def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', 
     d.act, d.per_sample_w = ACT[act], int(per_sample_w)
     if w.numel() != (B if per_sample_w else 1) * cout * kh * kw * cin:
         raise RuntimeError(f'weight has {w.numel()} elements, expected {(B if per_sample_w else 1) * cout * kh * kw * cin}')
+    if bn_stats is not None:                                      # dict filled in place: the epilogue leaves partial channel sums
+        rows = _lib.lib().somi_conv2d_stat_rows(C.byref(d))
+        part = torch.empty(2, rows, cout, device=x.device, dtype=torch.float32)
+        d.stat_sum, d.stat_sumsq, d.stat_pivot = part[0].data_ptr(), part[1].data_ptr(), _ptr(bn_stats.get('pivot'))
+        bn_stats['part'], bn_stats['rows'] = part, rows
     if PROFILE is None:
         check(_lib.lib().somi_conv2d_nhwc_f32(C.byref(d), _stream()), 'conv2d_nhwc')
         return out
@@ -363,6 +369,18 @@ def bn_stats(x, c, x_coff, gamma, beta, eps, momentum, running_mean=None, runnin
     check(_lib.lib().somi_bn_stats_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, n, c, float(eps), float(momentum), _ptr(gamma), _ptr(beta),
                                             _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var),
                                             _ptr(ws), _stream()), 'bn_stats')
+    return mean, rstd, scale, shift
+
+
+def bn_stats_from_partials(part, rows, npix, c, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """Batch statistics from the partial sums a convolution's epilogue left (conv2d_nhwc(..., bn_stats={'pivot': running_mean}));
+    `running_mean` must be that same pivot.  -> (mean, rstd, scale, shift); updates the running statistics."""
+    dev = part.device
+    mean, rstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
+    ws = torch.empty(2 * 1024 * c, device=dev, dtype=torch.float32)
+    check(_lib.lib().somi_bn_stats_partials_f32(part[0].data_ptr(), part[1].data_ptr(), rows, npix, c, float(eps), float(momentum), _ptr(gamma),
+                                                _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean),
+                                                _ptr(running_var), _ptr(ws), _stream()), 'bn_stats_partials')
     return mean, rstd, scale, shift
 
 
