@@ -441,18 +441,44 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N / 2) void
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[jn][i][e] = 0.f;
-    for (int w = g - 1; w < G; ++w) {
+    // the pieces of this tile in ascending workgroup order; two are fetched at a time (the walk is latency bound: a tile of a small
+    // layer is cut into a dozen pieces) and added in order
+    auto slot_of = [&](int w) -> const float * {
         const long lo = sk_lo(w, U, G), hi = sk_lo(w + 1, U, G);
-        if (lo >= t_hi) break;
-        if (hi <= t_lo || hi == lo) continue;                         // (only w = g-1 can end at or before the tile start)
+        if (w >= G || lo >= t_hi) return nullptr;                     // past the tile: stop
+        if (hi <= t_lo || hi == lo) return a.ws;                      // contributes nothing (never dereferenced: see `live`)
         const long seg = lo > t_lo ? lo : t_lo;
-        const float *slot = a.ws + ((size_t)w * 2 + (seg == lo ? 0 : 1)) * (BM * BN);
+        return a.ws + ((size_t)w * 2 + (seg == lo ? 0 : 1)) * (BM * BN);
+    };
+    auto live = [&](int w) {
+        const long lo = sk_lo(w, U, G), hi = sk_lo(w + 1, U, G);
+        return w < G && lo < t_hi && hi > t_lo && hi != lo;
+    };
+    for (int w = g - 1; w < G; w += 2) {
+        const float *s0 = slot_of(w), *s1 = slot_of(w + 1);
+        if (!s0) break;
+        const bool l0 = live(w), l1 = s1 && live(w + 1);
+        f32x16 t0[TN][TM], t1[TN][TM];
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[jn][i][e] += slot[((jn * TM + i) * 16 + e) * NT + tid];
+                for (int e = 0; e < 16; ++e) {
+                    const int o = ((jn * TM + i) * 16 + e) * NT + tid;
+                    t0[jn][i][e] = l0 ? s0[o] : 0.f;
+                    t1[jn][i][e] = l1 ? s1[o] : 0.f;
+                }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (l0) acc[jn][i][e] += t0[jn][i][e];
+                    if (l1) acc[jn][i][e] += t1[jn][i][e];
+                }
+        if (!s1) break;
     }
     const RowMap rmap = {a.M, a.d.Ho * a.d.Wo, a.d.Wo, 1, 0, 0, 0, false};
     conv_epilogue<BM, BN, WAVES_M, WAVES_N>(acc, lds, a, rmap, (tile / a.tiles_n) * BM, (tile % a.tiles_n) * BN);
@@ -490,7 +516,7 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
         const long ntile = (long)cdiv(M, bm) * cdiv(d.Cout, bn), nkt = (long)d.kh * d.kw * d.Cin / BK;
         const long rounds = (ntile + SK_GRID - 1) / SK_GRID;
         static const int sk_pct = getenv("SOMI_SK_PCT") ? atoi(getenv("SOMI_SK_PCT")) : 90;   // stream-K below this slot efficiency (%)
-        p.sk = ntile * 100 < rounds * SK_GRID * sk_pct && ntile * nkt >= SK_GRID * 4L &&
+        p.sk = ntile * 100 < rounds * SK_GRID * sk_pct && ntile * nkt >= 32 &&     // (the grid shrinks to >= 8 K-tiles per workgroup)
                d.workspace_bytes >= (size_t)SK_GRID * 2 * bm * bn * sizeof(float);
     }
     return p;
