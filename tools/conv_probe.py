@@ -33,13 +33,17 @@ if os.environ.get('PROBE_MODE') == 'wgrad':
     print(f'wgrad B{B} {H}x{H} {Cin}->{Cout} k{k}s{s}: {t*1e6:.1f} us  {2.0 * B * Ho * Ho * Cout * Cin * k * k / t / 1e12:.1f} TFLOP/s')
     sys.exit(0)
 kw = dict(a_chan_scale=torch.rand(B, Cin, device=d), a_pix_scale=torch.rand(B, H, H, device=d)) if mod else {}
+if os.environ.get('PROBE_STATS'):                            # BatchNorm partial sums from the epilogue (training forward)
+    kw['bn_stats'] = {'pivot': torch.zeros(Cout, device=d)}
+    b = None
+act = 'none' if os.environ.get('PROBE_STATS') else 'silu'
 for _ in range(reps):
-    y = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, stride=s, pad=k // 2, act='silu', **kw)
+    y = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, stride=s, pad=k // 2, act=act, **kw)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    y = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, stride=s, pad=k // 2, act='silu', **kw)
+    y = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, stride=s, pad=k // 2, act=act, **kw)
 e1.record()
 torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / reps * 1e-3
