@@ -392,3 +392,46 @@ def test_conv_epilogue_batchnorm_statistics(B, H, W, Cin, Cout, k, s):
     yd = y.double().cpu().reshape(-1, Cout)
     rel_close(got[0], yd.mean(0), rel=1e-5, what='mean vs fp64')
     rel_close(1.0 / got[1].double().cpu() ** 2 - 1e-3, yd.var(0, unbiased=False), rel=1e-4, what='variance vs fp64')
+
+
+def _random_conv_cases(n, seed):
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    while len(cases) < n:
+        k = rnd.choice([1, 1, 3, 3, 3, 5])
+        s = rnd.choice([1, 1, 1, 2])
+        cin = rnd.choice([4, 8, 20, 32, 36, 64, 96, 128, 160])
+        cout = rnd.choice([4, 12, 32, 36, 64, 100, 128, 192, 260])
+        H, W = rnd.randint(3, 44), rnd.randint(3, 44)
+        B = rnd.choice([1, 2, 3, 5, 8])
+        p = rnd.choice([k // 2, k // 2, 0]) if k > 1 else 0
+        if H + 2 * p < k or W + 2 * p < k:
+            continue
+        cases.append((B, H, W, cin, cout, k, s, p))
+    return cases
+
+
+@pytest.mark.parametrize('case', _random_conv_cases(36, 2024), ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv_forward_dgrad_wgrad_random_shapes(case):
+    """Differential test over seeded random geometries (odd sizes, padding 0, 5x5, stride 2, channel counts on and off the
+    uniform-tap fast path, batch 1): forward, data gradient and weight gradient against torch autograd on the CPU."""
+    from somi_amd import ops
+    from somi_amd.pack import pack_conv_weight, pack_dgrad_weight
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    d = dev()
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    bias = torch.randn(Cout, generator=g)
+    y = F.conv2d(x, w, bias, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = pack_conv_weight(w.detach(), cin_pad=Cin).to(d)
+    got = ops.conv2d_nhwc(nhwc(x.detach()).to(d), wp, bias.to(d), kh=k, kw=k, stride=s, pad=p)
+    rel_close(got, nhwc(y), what='forward')
+    gx = ops.conv2d_dgrad_nhwc(nhwc(dy).to(d), pack_dgrad_weight(w.detach(), cin_pad=Cin, cout_pad=Cout).to(d), B=B, H=H, W=W, cin=Cin,
+                               kh=k, kw=k, stride=s, pad=p)
+    rel_close(gx, nhwc(x.grad), what='dgrad')
+    gw = ops.conv2d_wgrad_nhwc(nhwc(x.detach()).to(d), nhwc(dy).to(d), kh=k, kw=k, stride=s, pad=p)
+    rel_close(gw, pack_conv_weight(w.grad, cin_pad=Cin), what='wgrad')
