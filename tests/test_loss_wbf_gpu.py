@@ -122,3 +122,39 @@ def test_repulsion_matches_oracle(B, A, pfg, kw):
     got = repulsion_loss(pb.to(dev), gb.to(dev), fg.to(dev), **kw)
     for a, b, what in zip(got, want, ('rep_gt', 'rep_box')):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=2e-5, atol=1e-7, err_msg=what)
+
+
+@pytest.mark.parametrize('B,nc,nl,na,nt,S,ls', [(3, 10, 4, 4, 200, 96, 0.0), (1, 3, 3, 3, 7, 64, 0.1), (5, 1, 4, 4, 60, 64, 0.0),
+                                                (2, 80, 3, 3, 900, 128, 0.0), (4, 10, 4, 4, 0, 64, 0.0)])
+def test_compute_loss_random_against_oracle(B, nc, nl, na, nt, S, ls):
+    """Differential test of the fused loss (value + gradient) on random predictions: 3- and 4-level heads, 1 / 3 / 10 / 80 classes,
+    label smoothing, no targets at all, and 900 targets of which many land in the same cell (duplicate (b, a, gj, gi) rows: the
+    reference's argsort-then-scatter keeps the highest IoU, utils/loss.py:174-178)."""
+    from oracle.somi_ref.loss import ComputeLoss as OLoss
+    from somi_amd.configs import HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    g = torch.Generator().manual_seed(B * 100 + nc + nt)
+    no = nc + 5
+    strides = [4, 8, 16, 32][:nl] if nl == 4 else [8, 16, 32]
+    anchors = torch.rand(nl, na, 2, generator=g) * 6 + 0.5                # in grid units, like Detect.anchors after /stride
+    hyp = dict(HYP_VISDRONE, label_smoothing=ls)
+    p = [torch.randn(B, na, S // s_, S // s_, no, generator=g) for s_ in strides]
+    tg = torch.zeros(nt, 6)
+    if nt:
+        tg[:, 0] = torch.randint(0, B, (nt,), generator=g).float()
+        tg[:, 1] = torch.randint(0, nc, (nt,), generator=g).float()
+        tg[:, 2:4] = torch.rand(nt, 2, generator=g) * 0.98 + 0.01
+        tg[:, 4:6] = torch.exp(torch.randn(nt, 2, generator=g) * 0.7 - 2.5).clamp(0.01, 0.6)
+        tg[: nt // 3, 2:6] = tg[nt // 3: 2 * (nt // 3), 2:6][: nt // 3] + torch.randn(nt // 3, 4, generator=g) * 1e-3   # near-duplicates
+        tg[:, 2:6] = tg[:, 2:6].clamp(0.005, 0.995)
+    pr = [t.clone().requires_grad_(True) for t in p]
+    want, want_items = OLoss(_M(anchors, hyp, nc))(pr, tg)
+    want.backward()
+    pm = [t.clone().cuda().requires_grad_(True) for t in p]
+    got, items = ComputeLoss(_M(anchors, hyp, nc))(pm, tg.cuda())
+    rel_close(got, want.detach(), rel=1e-4, what='loss')
+    rel_close(items, want_items, rel=1e-4, what='loss items')
+    got.backward()
+    for i in range(nl):
+        gr, gm = pr[i].grad, pm[i].grad.cpu()
+        assert (gm - gr).abs().max().item() <= 1e-3 * gr.abs().max().item() + 1e-9, f'd loss / d p[{i}]'
