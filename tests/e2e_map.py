@@ -60,12 +60,12 @@ def oracle_eval(state, cfg, batches, conf_thres, iou_thres):
     return float(p.mean()), float(r.mean()), float(ap[:, 0].mean()), float(ap.mean(1).mean())
 
 
-def main(steps=300, S=128, B=16, nc=4):
+def main(steps=300, S=128, B=16, nc=4, width=0.25, depth=0.33):
     from somi_amd import val as V
     from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg
     from somi_amd.model import Model
     from somi_amd.train import TrainStep
-    cfg = somi_cfg(0.25, 0.33, nc=nc, anchors=SOMI_ANCHORS)
+    cfg = somi_cfg(width, depth, nc=nc, anchors=SOMI_ANCHORS)
     model = fill_state(Model(cfg), 1).cuda()
     with torch.no_grad():                                         # fill_state randomises BN statistics for parity tests; start clean
         for m in model.modules():
@@ -90,7 +90,7 @@ def main(steps=300, S=128, B=16, nc=4):
     mp, mr, m50, m, det = V.run(model, val_batches, conf_thres=0.001, iou_thres=0.6)
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     omp, omr, om50, om = oracle_eval(state, cfg, val_batches, 0.001, 0.6)
-    res = {'train_steps': steps, 'train_seconds': round(t_train, 1), 'loss_first': round(first, 4), 'loss_last': round(last, 4),
+    res = {'width': width, 'depth': depth, 'imgsz': S, 'batch': B, 'train_steps': steps, 'train_seconds': round(t_train, 1), 'loss_first': round(first, 4), 'loss_last': round(last, 4),
            'product': {'P': mp, 'R': mr, 'mAP50': m50, 'mAP50_95': m}, 'oracle': {'P': omp, 'R': omr, 'mAP50': om50, 'mAP50_95': om},
            'abs_diff_mAP50': abs(m50 - om50), 'abs_diff_mAP50_95': abs(m - om)}
     print(json.dumps(res))
@@ -98,4 +98,5 @@ def main(steps=300, S=128, B=16, nc=4):
 
 
 if __name__ == '__main__':
-    main(*(int(v) for v in sys.argv[1:]))
+    a = sys.argv[1:]
+    main(*(int(v) for v in a[:4]), *(float(v) for v in a[4:6]))
