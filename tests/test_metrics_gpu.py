@@ -82,3 +82,21 @@ def test_metrics_empty_inputs():
     p, r, ap, f1, cls_ = ap_per_class(torch.zeros(0, 10, dtype=torch.bool, device=DEV), torch.zeros(0, device=DEV), torch.zeros(0, device=DEV),
                                       torch.tensor([2., 2., 5.], device=DEV))
     assert cls_.tolist() == [2, 5] and float(ap.abs().max()) == 0.0 and float(p.abs().max()) == 0.0
+
+
+def test_scale_coords_matches_reference_formula():
+    """val.scale_coords (utils/general.py:602-628): letterbox undo + clipping, with and without an explicit ratio / pad."""
+    from somi_amd.val import scale_coords
+    g = torch.Generator().manual_seed(3)
+    boxes = torch.rand(50, 4, generator=g) * 700 - 30
+    for img1, img0, rp in (((640, 640), (480, 720), None), ((384, 640), (1080, 1920), None), ((640, 640), (300, 500), ((1.28, 1.28), (0.0, 128.0)))):
+        want = boxes.clone().double()
+        if rp is None:
+            gain = min(img1[0] / img0[0], img1[1] / img0[1])
+            pad = ((img1[1] - img0[1] * gain) / 2, (img1[0] - img0[0] * gain) / 2)
+        else:
+            gain, pad = rp[0][0], rp[1]
+        want[:, [0, 2]] = ((want[:, [0, 2]] - pad[0]) / gain).clamp(0, img0[1])
+        want[:, [1, 3]] = ((want[:, [1, 3]] - pad[1]) / gain).clamp(0, img0[0])
+        got = scale_coords(img1, boxes.clone().to(DEV), img0, rp)
+        np.testing.assert_allclose(got.cpu().numpy(), want.float().numpy(), rtol=1e-6, atol=1e-4)

@@ -2,10 +2,11 @@
 
     mp, mr, map50, map_, per_class = run(model, batches, conf_thres=0.001, iou_thres=0.6)
 
-`batches` yields (imgs uint8 (B,3,H,W), targets (nt,6) [image, class, x, y, w, h normalised]) like the reference's dataloader
-(`collate_fn`, utils/datasets.py:676-680).  Predictions and statistics stay on the GPU until the five result numbers are read.
-Inputs are evaluated at their own size (no letterbox ratio / pad: `scale_coords` is the identity); plots, json / txt dumps and
-the confusion matrix are the reference's CPU tooling and stay there.
+`batches` yields (imgs uint8 (B,3,H,W), targets (nt,6) [image, class, x, y, w, h normalised]) or, like the reference's
+dataloader (`collate_fn`, utils/datasets.py:676-680), (imgs, targets, paths, shapes) with shapes[i] = (native (h, w), (ratio,
+pad)) of the letterbox - predictions and labels are then mapped back to the native image with `scale_coords` (val.py:180-183).
+Predictions and statistics stay on the GPU until the five result numbers are read.  Plots, json / txt dumps and the confusion
+matrix are the reference's CPU tooling and stay there.
 """
 import torch
 
@@ -23,6 +24,24 @@ def xywh2xyxy(x):
     return y
 
 
+def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
+    """Map xyxy boxes from the (letterboxed) network input `img1_shape` (h, w) back to the native image `img0_shape`, in place,
+    and clip them to it (utils/general.py:602-628)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    coords[:, 0].clamp_(0, img0_shape[1])
+    coords[:, 1].clamp_(0, img0_shape[0])
+    coords[:, 2].clamp_(0, img0_shape[1])
+    coords[:, 3].clamp_(0, img0_shape[0])
+    return coords
+
+
 @torch.no_grad()
 def run(model, batches, conf_thres=0.001, iou_thres=0.6, single_cls=False, device=None):
     """-> (mp, mr, map50, map, dict(p, r, ap50, ap, ap_class, seen, nt)); val.py:148-212 with plots / saving off."""
@@ -34,21 +53,29 @@ def run(model, batches, conf_thres=0.001, iou_thres=0.6, single_cls=False, devic
     iouv = torch.linspace(0.5, 0.95, 10, device=device)
     niou = iouv.numel()
     seen, tps, confs, pclss, tclss = 0, [], [], [], []
-    for imgs, targets in batches:
+    for batch in batches:
+        imgs, targets = batch[0], batch[1]
+        shapes = batch[3] if len(batch) > 3 else None
         imgs, targets = imgs.to(device), targets.to(device).float().clone()
         nb, _, height, width = imgs.shape
         out, _ = model(imgs)
         targets[:, 2:] *= torch.tensor([width, height, width, height], device=device, dtype=torch.float32)     # val.py:166
         out = non_max_suppression(out, conf_thres, iou_thres, multi_label=True, agnostic=single_cls)            # val.py:169
-        labs = []
+        labs, predn = [], []
         for si in range(nb):
             labels = targets[targets[:, 0] == si, 1:]
-            labs.append(torch.cat((labels[:, 0:1], xywh2xyxy(labels[:, 1:5])), 1) if len(labels) else labels.new_zeros(0, 5))
-            tclss.append(labels[:, 0])
+            tbox = xywh2xyxy(labels[:, 1:5]) if len(labels) else labels.new_zeros(0, 4)
             if single_cls and len(out[si]):
                 out[si][:, 5] = 0
+            pn = out[si].clone()
+            if shapes is not None:                                # native-space boxes (val.py:180-183)
+                scale_coords((height, width), pn[:, :4], shapes[si][0], shapes[si][1])
+                scale_coords((height, width), tbox, shapes[si][0], shapes[si][1])
+            labs.append(torch.cat((labels[:, 0:1], tbox), 1) if len(labels) else labels.new_zeros(0, 5))
+            predn.append(pn)
+            tclss.append(labels[:, 0])
         seen += nb
-        corrects = process_batches(out, labs, iouv)               # the whole batch in one launch (val.py:184 per image)
+        corrects = process_batches(predn, labs, iouv)             # the whole batch in one launch (val.py:184 per image)
         for pred, correct in zip(out, corrects):
             tps.append(correct)
             confs.append(pred[:, 4])
