@@ -126,3 +126,36 @@ def test_warmup_and_one_cycle_schedule():
     scheduler_step(opt, 40, lf)
     assert all(abs(g['lr'] - 3e-4 * lf(40)) < 1e-18 for g in opt.param_groups)
     assert math.isclose(lf(100), hyp['lrf'])
+
+
+def test_header_is_plain_c():
+    """include/somi_hip.h is the drop-in boundary: it must compile as C (no C++ or torch types) and the INTEGRATION.md conv
+    example must compile against it."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = '''#include <stdio.h>
+#include "somi_hip.h"
+int run(const float *x, const float *w_packed, const float *bias, float *y, void *scratch, somi_stream_t stream) {
+    somi_conv_desc d = {0};
+    d.x = x; d.w = w_packed; d.bias = bias; d.y = y;
+    d.B = 32; d.H = d.W = 160; d.Cin = 128; d.x_cs = 128;
+    d.Ho = d.Wo = 160; d.Cout = 128; d.y_cs = 128;
+    d.kh = d.kw = 3; d.stride = 1; d.pad = 1; d.dil = 1; d.act = SOMI_ACT_SILU;
+    d.workspace = scratch; d.workspace_bytes = somi_conv2d_workspace_bytes();
+    if (somi_conv2d_nhwc_f32(&d, stream)) { fprintf(stderr, "%s\\n", somi_last_error()); return 1; }
+    return 0;
+}
+'''
+    with tempfile.NamedTemporaryFile('w', suffix='.c', delete=False) as f:
+        f.write(src)
+    try:
+        r = subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(root, 'include'), f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    finally:
+        os.unlink(f.name)
