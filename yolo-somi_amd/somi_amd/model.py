@@ -204,7 +204,13 @@ class Model(nn.Module):
             elif srcs[0] < 0:
                 m.backward(g, need_dx=False)
             else:
-                give(srcs[0], m.backward(g))
+                have = grads.get(srcs[0])
+                if (have is not None and isinstance(m, (B.Conv, B.C2fCBAM)) and have.coff == 0 and
+                        have.t.shape[3] == B.pad4(have.c) and have.t.is_contiguous()):
+                    # the input already holds another consumer's gradient: the data-gradient epilogue adds to it in place
+                    m.backward(g, dx_out=have, accumulate=True)
+                else:
+                    give(srcs[0], m.backward(g))
             if hook:
                 hook(m.i)
 
