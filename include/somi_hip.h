@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 5
+#define SOMI_ABI_VERSION 6
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -431,6 +431,45 @@ size_t somi_ap_per_class_workspace_bytes(long N, int T, int ncap);
 int somi_ap_per_class_f64(const uint8_t *tp, const float *conf, const float *pred_cls, const float *target_cls, long N, long M,
                           int T, int ncap, int *out_classes, int *out_n, double *out_ap, double *out_p, double *out_r,
                           double *out_f1, void *workspace, size_t workspace_bytes, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline on device: what `LoadImagesAndLabels.__getitem__` does to the pixels of one
+ * sample once the source images are cached at the training size - mosaic composition (utils/datasets.py:732-777), the
+ * affine crop (`random_perspective` -> cv2.warpAffine, utils/augmentations.py:126-169), mixup (:305-310), HSV jitter
+ * (`augment_hsv` :47-61), flips and the HWC BGR -> CHW RGB transpose (datasets.py:648-671) - fused into one pass per output
+ * pixel: the 2s x 2s mosaic canvas is never materialised.  Random draws, matrices and label boxes stay with the caller
+ * (they are a few hundred scalars per sample); it passes one `somi_aug_sample` per output image, in device memory.
+ *
+ * canvas(x, y) = the LAST source whose rectangle [x1,x2) x [y1,y2) holds (x, y), read at pixels[y - dy][x - dx], else `fill`.
+ * warp == 0: out(x, y) = canvas(x, y) (letterbox: one source placed at (left, top)).
+ * warp == 1: out(x, y) = bilinear sample of the canvas at minv * (x, y, 1), taps outside the canvas = `fill`, in the fixed
+ *            point of OpenCV 4.9 warpAffine (coordinates to 1/32 pixel from round(m*1024) terms, 15-bit weights).
+ * mix:  out = (uint8) trunc(canvas[0] * mix_r + canvas[1] * (1 - mix_r)) in fp64.
+ * hsv:  BGR -> HSV (OpenCV 8-bit, hue range 180), channel-wise through lut[0..2], HSV -> BGR.
+ * flips move the pixel, then it is stored as out[b][2 - c][y][x] (RGB planes).
+ * Sources and output are at most 16384 px a side.  The caller guarantees that every rectangle maps inside its source
+ * (0 <= x1 - dx, x2 - dx <= w, same for y): the records live in device memory, so the library cannot check them. */
+typedef struct somi_aug_source {
+    const uint8_t *pixels;       /* device, (h, w, 3) BGR, tightly packed */
+    int32_t h, w;
+    int32_t x1, y1, x2, y2;
+    int32_t dx, dy;
+} somi_aug_source;
+
+typedef struct somi_aug_canvas {
+    somi_aug_source src[4];
+    int32_t nsrc, height, width, warp;
+    double minv[6];              /* dst -> src, row-major 2x3 (the inverse of the matrix cv2.warpAffine is given) */
+} somi_aug_canvas;
+
+typedef struct somi_aug_sample {
+    somi_aug_canvas canvas[2];
+    int32_t mix, hsv, flipud, fliplr;
+    double mix_r;
+    uint8_t lut[3][256];
+} somi_aug_sample;
+
+int somi_augment_u8(const somi_aug_sample *samples, int B, int H, int W, int fill, uint8_t *out, somi_stream_t stream);
 
 #ifdef __cplusplus
 }

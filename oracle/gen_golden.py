@@ -332,7 +332,54 @@ def gen_val():
     save('val_metrics', **rec)
 
 
+AUGMENT_CASES = (        # name, hyp overrides, augment, seeds
+    ('mosaic', {}, True, (0, 1, 2, 3, 4, 5)),
+    ('mixup', dict(mixup=1.0), True, (10, 11, 12)),
+    ('general', dict(degrees=10.0, translate=0.1, shear=5.0, flipud=0.5, mixup=0.5), True, (20, 21, 22, 23)),
+    ('single', dict(mosaic=0.0), True, (30, 31, 32, 33)),
+    ('val', {}, False, (40, 41, 42)),
+)
+
+
+def gen_augment():
+    """The reference's own `LoadImagesAndLabels.__getitem__` (utils/datasets.py:590-673: load_mosaic, random_perspective,
+    mixup, augment_hsv, flips, letterbox) on a cached synthetic image set.  cv2 is not installed: `oracle.somi_ref.cv_port`
+    (the restated OpenCV arithmetic, parity unpinned) stands in for it, so this pins everything around the pixel kernels -
+    random draw order, mosaic geometry, matrices, label transforms - through the reference's code."""
+    import random
+    from types import SimpleNamespace
+    import utils.augmentations as RA
+    import utils.datasets as RD
+    from oracle.somi_ref import cv_port
+    from oracle.somi_ref.testing import HYP_AUGMENT, synthetic_image_set
+    RA.cv2 = RD.cv2 = cv_port
+    S = 64
+    imgs, labels = synthetic_image_set(S, n=6, seed=600)
+    rec = {'img_size': S, 'n': len(imgs)}
+    for i, (im, lab) in enumerate(zip(imgs, labels)):
+        rec[f'src{i}'], rec[f'lab{i}'] = im, lab
+    names, seeds, indices = [], [], []
+    for name, over, augment, case_seeds in AUGMENT_CASES:
+        hyp = dict(HYP_AUGMENT, **over)
+        ds = SimpleNamespace(indices=range(len(imgs)), n=len(imgs), hyp=hyp, augment=augment, rect=False, mosaic=augment,
+                             img_size=S, mosaic_border=[-S // 2, -S // 2], imgs=imgs,
+                             img_hw0=[im.shape[:2] for im in imgs], img_hw=[im.shape[:2] for im in imgs],
+                             labels=labels, segments=[[] for _ in imgs], img_files=[f'{i}.jpg' for i in range(len(imgs))],
+                             albumentations=RA.Albumentations() if augment else None)
+        for seed in case_seeds:
+            random.seed(seed)
+            np.random.seed(seed)
+            index = seed % len(imgs)
+            img, lab, _, shapes = RD.LoadImagesAndLabels.__getitem__(ds, index)
+            k = len(names)
+            rec[f'out_img{k}'], rec[f'out_lab{k}'] = img, lab
+            rec[f'out_pad{k}'] = np.array(shapes[1][1] if shapes else (-1.0, -1.0))
+            names.append(name), seeds.append(seed), indices.append(index)
+    rec.update(case=np.array(names), seed=np.array(seeds), index=np.array(indices))
+    save('augment', **rec)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'loss', 'nms', 'val']
+    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'loss', 'nms', 'val', 'augment']
     for w in which:
         globals()[f'gen_{w}']()

@@ -61,6 +61,31 @@ HYP_VISDRONE = dict(lr0=0.0032, lrf=0.12, momentum=0.843, weight_decay=0.00036, 
                     deta=0.5, slide_ratio=0, nwdloss=0, shapeloss=0, label_smoothing=0.0)
 """Loss-relevant keys of data/hyps/hyp.VisDrone.yaml (values are configuration data)."""
 
+HYP_AUGMENT = dict(hsv_h=0.4, hsv_s=0.3, hsv_v=0.5, degrees=0.2, translate=0.0, scale=0.4, shear=0.0, perspective=0.0,
+                   flipud=0.0, fliplr=0.5, mosaic=1.0, mixup=0.2, copy_paste=0.0)
+"""Augmentation keys of data/hyps/hyp.VisDrone.yaml:17-29."""
+
+
+def synthetic_image_set(img_size, n=6, seed=0):
+    """`n` BGR uint8 images whose longer side is `img_size` (what the reference's image cache holds) with (k,5) float32
+    [cls, x, y, w, h] labels: smooth colour gradients plus noise, so HSV jitter and bilinear taps see varied values."""
+    rng = np.random.RandomState(seed)
+    fr = [(1.0, 0.75), (0.75, 1.0), (1.0, 1.0), (0.625, 1.0), (1.0, 0.875), (1.0, 1.0), (0.5, 1.0), (1.0, 0.5)]
+    imgs, labels = [], []
+    for i in range(n):
+        h, w = (max(8, int(round(img_size * f))) for f in fr[i % len(fr)])
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        base = np.stack([127 + 120 * np.sin(xx / (3 + 2 * c + i) + c) * np.cos(yy / (5 + i - c) + i) for c in range(3)], -1)
+        img = np.clip(base + rng.randint(-40, 41, size=(h, w, 3)), 0, 255).astype(np.uint8)
+        if i % 4 == 3:
+            img[: h // 3, : w // 3] = rng.randint(0, 256, size=3)          # a flat patch: saturation 0 / grey paths
+        k = int(rng.randint(3, 9)) if i != 1 else 0                         # image 1 has no labels
+        wh = rng.uniform(0.05, 0.35, size=(k, 2))
+        xy = rng.uniform(0, 1, size=(k, 2)) * (1 - wh) + wh / 2
+        labels.append(np.concatenate((rng.randint(0, 10, size=(k, 1)), xy, wh), 1).astype(np.float32).reshape(k, 5))
+        imgs.append(img)
+    return imgs, labels
+
 
 def somi_cfg(width=1.0, depth=1.0, nc=10, anchors=4):
     """The layer table of models/modules/YOLO-SOMI.yaml as a dict (C2fEACBAM -> C2fCBAM)."""

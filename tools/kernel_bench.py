@@ -114,8 +114,45 @@ def val_metrics(nimg=548, nc=10):
                       'match_ms_incl_host_concat': round(t_match * 1e3, 3), 'ap_per_class_ms': round(t_ap * 1e3, 3)}), flush=True)
 
 
+def augment(B=32, S=640, nimg=256):
+    """somi_augment_u8 at the training batch: mosaic + affine crop + HSV + flip (and with mixup on every sample) from an
+    HBM-resident cache of VisDrone-shaped images (640 x 360).  Algorithmic bytes per output pixel: 3 read (each source
+    pixel under the crop once; 6 with mixup) + 3 written."""
+    import random
+    import time
+    import numpy as np
+    from somi_amd.augment import DeviceImageCache, HYP_VISDRONE_AUGMENT
+    rng = np.random.RandomState(0)
+    imgs = [rng.randint(0, 256, (360, 640, 3)).astype(np.uint8) for _ in range(nimg)]
+    labs = []
+    for _ in range(nimg):
+        k = int(rng.randint(20, 90))
+        wh = rng.uniform(0.01, 0.1, (k, 2))
+        labs.append(np.concatenate((rng.randint(0, 10, (k, 1)), rng.uniform(0, 1, (k, 2)) * (1 - wh) + wh / 2, wh), 1).astype(np.float32))
+    for tag, over in (('mosaic+hsv+flip', dict(mixup=0.0)), ('mosaic+mixup+hsv+flip', dict(mixup=1.0))):
+        ds = DeviceImageCache(imgs, labs, S, dict(HYP_VISDRONE_AUGMENT, **over))
+        random.seed(0), np.random.seed(0)
+        t0 = time.perf_counter()
+        plans = [ds.plan(i)[0] for i in range(B)]
+        t_plan = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        recs = ds.upload(plans)
+        torch.cuda.synchronize()
+        t_up = time.perf_counter() - t0
+        out = ds.launch(recs, B)
+        t = timeit(lambda: ds.launch(recs, B, out), warm=3, iters=20)
+        px = B * S * S
+        alg = px * (9 if over['mixup'] else 6)
+        print(json.dumps({'kernel': 'augment_kernel', 'case': tag, 'shape': f'B{B} {S}x{S} from {nimg} cached 360x640 images',
+                          'us': round(t * 1e6, 1), 'Gpixel_per_s': round(px / t / 1e9, 2), 'alg_GBps': round(alg / t / 1e9, 1),
+                          'frac_hbm_peak': round(alg / t / 1e9 / HBM_PEAK, 4), 'host_plan_ms_per_batch': round(t_plan * 1e3, 2),
+                          'record_upload_ms': round(t_up * 1e3, 2), 'images_per_s_kernel_only': round(B / t, 0)}), flush=True)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['dcn', 'backbone', 'val']
+    which = sys.argv[1:] or ['dcn', 'backbone', 'val', 'augment']
+    if 'augment' in which:
+        augment()
     if 'val' in which:
         val_metrics()
     if 'dcn' in which:

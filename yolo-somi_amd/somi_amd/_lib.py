@@ -34,6 +34,24 @@ class LossDesc(C.Structure):
                 ('obj_pw', C.c_float), ('anchor_t', C.c_float), ('cp', C.c_float), ('cn', C.c_float), ('gr', C.c_float)]
 
 
+class AugSource(C.Structure):
+    """struct somi_aug_source (include/somi_hip.h)."""
+    _fields_ = [('pixels', C.c_void_p), ('h', C.c_int32), ('w', C.c_int32), ('x1', C.c_int32), ('y1', C.c_int32),
+                ('x2', C.c_int32), ('y2', C.c_int32), ('dx', C.c_int32), ('dy', C.c_int32)]
+
+
+class AugCanvas(C.Structure):
+    """struct somi_aug_canvas."""
+    _fields_ = [('src', AugSource * 4), ('nsrc', C.c_int32), ('height', C.c_int32), ('width', C.c_int32), ('warp', C.c_int32),
+                ('minv', C.c_double * 6)]
+
+
+class AugSample(C.Structure):
+    """struct somi_aug_sample."""
+    _fields_ = [('canvas', AugCanvas * 2), ('mix', C.c_int32), ('hsv', C.c_int32), ('flipud', C.c_int32), ('fliplr', C.c_int32),
+                ('mix_r', C.c_double), ('lut', (C.c_uint8 * 256) * 3)]
+
+
 I, F, P, S, Z, U64 = C.c_int, C.c_float, C.c_void_p, c_stream, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes); every symbol include/somi_hip.h declares
@@ -107,6 +125,7 @@ SIGNATURES = {
     'somi_repulsion_workspace_bytes': (Z, [I, I]),
     'somi_repulsion_loss_f32': (I, [P, P, P, I, I, F, F, F, F, P, P, Z, S]),
     'somi_wbf_workspace_bytes': (Z, [I]),
+    'somi_augment_u8': (I, [P, I, I, I, I, P, S]),
     'somi_wbf_f32': (I, [P, P, P, P, I, I, C.POINTER(C.c_float), F, F, P, P, P, P, P, Z, S]),
 }
 
@@ -124,7 +143,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != 5:
+        if L.somi_abi_version() != 6:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib
