@@ -10,6 +10,7 @@ file they stand in for:
     nms, wbf         utils/general.py non_max_suppression, wbf.py / ensemble_boxes weighted_boxes_fusion
     metrics, val     val.py process_batch / loop body, utils/metrics.py ap_per_class
     train, optim, ddp   train.py step (forward, loss, backward, Adam + ModelEMA), DDP gradient exchange
+    augment          utils/datasets.py LoadImagesAndLabels.__getitem__ / collate_fn, utils/augmentations.py (device input pipeline)
     checkpoint       models/experimental.py attempt_load (reads the reference's pickled checkpoints)
     graph            hipGraph replay of the inference forward
 
