@@ -378,6 +378,33 @@ def gen_augment():
     rec.update(case=np.array(names), seed=np.array(seeds), index=np.array(indices))
     save('augment', **rec)
 
+    # rectangular validation batches (val.py:129-138: rect=True, pad=0.5): the aspect-ratio ordering and batch shapes come from
+    # the reference's own source text (datasets.py "if self.rect:" block, executed on a stand-in `self`), the samples from its
+    # __getitem__ with augment=False
+    import textwrap
+    src = open(f'{REF}/utils/datasets.py').read().split('\n')
+    lo = next(i for i, l in enumerate(src) if l.strip() == 'if self.rect:' and 'self.shapes' in ''.join(src[i:i + 4]))
+    hi = next(i for i in range(lo, len(src)) if 'self.batch_shapes =' in src[i]) + 1
+    block = textwrap.dedent('\n'.join(src[lo:hi]))
+    S, bs, stride, pad = 96, 3, 32, 0.5
+    imgs, labels = synthetic_image_set(S, n=8, seed=601)
+    n = len(imgs)
+    bi = np.floor(np.arange(n) / bs).astype(int)
+    ds = SimpleNamespace(rect=True, shapes=np.array([(im.shape[1], im.shape[0]) for im in imgs], dtype=np.float64),
+                         img_files=list(range(n)), label_files=list(range(n)), labels=list(labels))
+    exec(block, {'self': ds, 'np': np, 'nb': bi[-1] + 1, 'bi': bi, 'img_size': S, 'stride': stride, 'pad': pad})
+    order = np.array(ds.img_files)
+    ds.__dict__.update(indices=range(n), n=n, hyp=dict(HYP_AUGMENT), augment=False, mosaic=False, img_size=S, batch=bi,
+                       imgs=[imgs[i] for i in order], img_hw0=[imgs[i].shape[:2] for i in order],
+                       img_hw=[imgs[i].shape[:2] for i in order], segments=[[] for _ in imgs], albumentations=None)
+    rec = dict(img_size=S, n=n, batch_size=bs, stride=stride, pad=pad, order=order, batch_shapes=ds.batch_shapes)
+    for i, (im, lab) in enumerate(zip(imgs, labels)):
+        rec[f'src{i}'], rec[f'lab{i}'] = im, lab
+    for k in range(n):
+        img, lab, _, shapes = RD.LoadImagesAndLabels.__getitem__(ds, k)
+        rec[f'out_img{k}'], rec[f'out_lab{k}'], rec[f'out_pad{k}'] = img, lab, np.array(shapes[1][1])
+    save('augment_rect', **rec)
+
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'loss', 'nms', 'val', 'augment']

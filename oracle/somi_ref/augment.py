@@ -107,6 +107,7 @@ def letterbox(im, new_shape, scaleup=True):
     shape = im.shape[:2]
     if isinstance(new_shape, int):
         new_shape = (new_shape, new_shape)
+    new_shape = (int(new_shape[0]), int(new_shape[1]))
     r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
     if not scaleup:
         r = min(r, 1.0)
@@ -119,19 +120,43 @@ def letterbox(im, new_shape, scaleup=True):
     return cv.copyMakeBorder(im, top, bottom, left, right, cv.BORDER_CONSTANT, value=FILL), (r, r), (dw, dh)
 
 
+def aspect_ordered_batches(wh, batch_index, img_size, stride, pad):
+    """datasets.py:497-523 (rect=True): sort by aspect ratio h/w; per batch the letterbox shape [h, w] is the unit box shrunk
+    along one side to the extreme ratio of the batch, scaled to img_size and rounded up (with `pad` strides of slack) to the
+    stride.  wh: (n,2) float64 [width, height] -> (order, (nb,2) int shapes)."""
+    ar = wh[:, 1] / wh[:, 0]
+    order = ar.argsort()
+    ar = ar[order]
+    nb = batch_index[-1] + 1
+    unit = [[1, 1]] * nb
+    for b in range(nb):
+        mine = ar[batch_index == b]
+        if mine.max() < 1:
+            unit[b] = [mine.max(), 1]
+        elif mine.min() > 1:
+            unit[b] = [1, 1 / mine.min()]
+    return order, np.ceil(np.array(unit) * img_size / stride + pad).astype(int) * stride
+
+
 class CachedDataset:
     """The slice of `LoadImagesAndLabels` that runs per sample once images are cached (datasets.py:405-420 attributes).
 
     imgs: list of (h, w, 3) BGR uint8 arrays whose longer side is `img_size`; labels: list of (n, 5) float32 [cls, x, y, w, h]
     normalised."""
 
-    def __init__(self, imgs, labels, img_size, hyp, augment=True, rect=False):
+    def __init__(self, imgs, labels, img_size, hyp, augment=True, rect=False, batch_size=16, stride=32, pad=0.0, shapes=None):
         self.imgs, self.labels, self.img_size, self.hyp, self.augment = imgs, labels, img_size, hyp, augment
         self.rect = rect
         self.mosaic = augment and not rect
         self.mosaic_border = [-img_size // 2, -img_size // 2]
         self.n = len(imgs)
         self.indices = range(self.n)
+        self.batch = np.floor(np.arange(self.n) / batch_size).astype(int)            # datasets.py:477-479
+        if rect:
+            wh = np.array([(im.shape[1], im.shape[0]) for im in imgs] if shapes is None else shapes, dtype=np.float64)
+            self.order, self.batch_shapes = aspect_ordered_batches(wh, self.batch, img_size, stride, pad)
+            self.imgs = [imgs[i] for i in self.order]
+            self.labels = [labels[i] for i in self.order]
 
     def mosaic4(self, index):
         """datasets.py:732-798: four images around a random centre on a 2s x 2s canvas, then the affine crop to s x s."""
@@ -178,7 +203,8 @@ class CachedDataset:
         else:
             img = self.imgs[index]
             h, w = img.shape[:2]
-            img, ratio, pad = letterbox(img, self.img_size, scaleup=self.augment)
+            shape = self.batch_shapes[self.batch[index]] if self.rect else self.img_size
+            img, ratio, pad = letterbox(img, shape, scaleup=self.augment)
             shapes = (h, w), ((1.0, 1.0), pad)
             labels = self.labels[index].copy()
             if labels.size:

@@ -65,7 +65,9 @@ def test_host_plan_matches_the_reference_labels_and_geometry(golden):
     for k, name, seed, idx, imgs, labs, S, hyp, augment in fixture_cases(g):
         ds = DeviceImageCache(imgs, labs, S, hyp, augment=augment, device='cpu')
         random.seed(seed), np.random.seed(seed)
-        (canvases, mix_r, luts, flipud, fliplr), labels, shapes = ds.plan(idx)
+        plan, labels, shapes = ds.plan(idx)
+        canvases, mix_r, luts, flipud, fliplr, out_hw = plan
+        assert out_hw == (S, S)
         want = g[f'out_lab{k}']
         assert labels.shape[0] == want.shape[0], (name, seed)
         assert np.array_equal(labels.astype(np.float32), want[:, 1:]), (name, seed)
@@ -78,7 +80,30 @@ def test_host_plan_matches_the_reference_labels_and_geometry(golden):
         if shapes is not None:
             assert tuple(shapes[1][1]) == tuple(g[f'out_pad{k}'])
         with pytest.raises(RuntimeError, match='no CPU fallback'):
-            ds.render([(canvases, mix_r, luts, flipud, fliplr)])
+            ds.render([plan])
+
+
+def test_rect_batches_follow_the_reference(golden):
+    """val.py's loader (rect=True, pad=0.5): aspect-ratio order and batch shapes from the reference's own source text, samples
+    from its __getitem__ - against the oracle (pixels + labels) and the product's host plan (order, shapes, labels, placement)."""
+    from somi_amd.augment import DeviceImageCache
+    g = golden('augment_rect')
+    n, S, bs = int(g['n']), int(g['img_size']), int(g['batch_size'])
+    imgs, labs = [g[f'src{i}'] for i in range(n)], [g[f'lab{i}'] for i in range(n)]
+    kw = dict(augment=False, rect=True, batch_size=bs, stride=int(g['stride']), pad=float(g['pad']))
+    ora = CachedDataset(imgs, labs, S, dict(HYP_AUGMENT), **kw)
+    dev = DeviceImageCache(imgs, labs, S, dict(HYP_AUGMENT), device='cpu', **kw)
+    assert np.array_equal(ora.order, g['order']) and np.array_equal(ora.batch_shapes, g['batch_shapes'])
+    assert np.array_equal(dev.order, g['order']) and np.array_equal(dev.batch_shapes, g['batch_shapes'])
+    for k in range(n):
+        img, lab, shapes = ora[k]
+        assert np.array_equal(img.numpy(), g[f'out_img{k}']) and np.array_equal(lab.numpy(), g[f'out_lab{k}'])
+        assert tuple(shapes[1][1]) == tuple(g[f'out_pad{k}'])
+        plan, labels, shapes = dev.plan(k)
+        assert plan.out_hw == tuple(g[f'out_img{k}'].shape[1:]) and plan.mix_r is None and plan.luts is None
+        assert np.array_equal(labels, g[f'out_lab{k}'][:, 1:]) and tuple(shapes[1][1]) == tuple(g[f'out_pad{k}'])
+    with pytest.raises(RuntimeError, match='different letterbox shapes'):
+        DeviceImageCache.render(dev, [dev.plan(0)[0], dev.plan(n - 1)[0]])
 
 
 def test_batch_collates_like_the_reference(golden):
@@ -99,6 +124,8 @@ def test_batch_collates_like_the_reference(golden):
         b[:, 0] = j
         blocks.append(b)
     assert torch.equal(torch.cat(blocks, 0), ref[1])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):          # the public entry point renders on the device only
+        ds.batch([3, 0])
 
 
 def test_unbuilt_options_raise():

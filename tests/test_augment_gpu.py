@@ -70,6 +70,23 @@ def test_validation_path_is_a_letterboxed_copy():
         assert rows.shape[0] == labs[j].shape[0]
 
 
+def test_rect_validation_batches_match_the_reference_fixture(golden):
+    """val.py's loader: rect=True, pad=0.5, augment=False -> non-square (B,3,h,w) batches, one launch per batch."""
+    from somi_amd.augment import DeviceImageCache
+    g = golden('augment_rect')
+    n, S, bs = int(g['n']), int(g['img_size']), int(g['batch_size'])
+    imgs, labs = [g[f'src{i}'] for i in range(n)], [g[f'lab{i}'] for i in range(n)]
+    ds = DeviceImageCache(imgs, labs, S, dict(HYP_AUGMENT), augment=False, rect=True, batch_size=bs, stride=int(g['stride']),
+                          pad=float(g['pad']))
+    for b0 in range(0, n, bs):
+        picks = list(range(b0, min(b0 + bs, n)))
+        out, targets, shapes = ds.batch(picks)
+        assert tuple(out.shape[2:]) == tuple(g['batch_shapes'][b0 // bs])
+        for j, k in enumerate(picks):
+            assert np.array_equal(out[j].cpu().numpy(), g[f'out_img{k}']), k
+            assert np.array_equal(targets[targets[:, 0] == j][:, 1:].numpy(), g[f'out_lab{k}'][:, 1:])
+
+
 def test_flips_and_identity_tables_are_pure_moves():
     """Properties at full size: with HSV gains 0 the colour path is skipped, so fliplr/flipud forced on vs off differ by
     exactly a flip; and jitter tables that are the identity change at most the rounding of the HSV round trip."""
@@ -99,8 +116,8 @@ def test_records_are_validated_before_launch():
     ds = DeviceImageCache(imgs, labs, 32)
     seed_all(0)
     plan, _, _ = ds.plan(0)
-    idx, x1, y1, x2, y2, dx, dy = plan[0][0].sources[0]
-    plan[0][0].sources[0] = (idx, x1, y1, x2 + 64, y2, dx, dy)              # rectangle wider than its source
+    idx, x1, y1, x2, y2, dx, dy = plan.canvases[0].sources[0]
+    plan.canvases[0].sources[0] = (idx, x1, y1, x2 + 64, y2, dx, dy)        # rectangle wider than its source
     with pytest.raises(RuntimeError, match='outside its source'):
         ds.render([plan])
 
@@ -144,4 +161,23 @@ def test_device_batches_drive_the_training_step():
         opt.step()
         lm, _ = tr.step(di, dt.cuda())
         tol = (1e-4, 1e-2)[step]
-        assert abs(float(lm) - float(lr_)) <= tol * abs(float(lr_)), (step, float(lm), float(lr_))
+        want = float(lr_.detach())
+        assert abs(float(lm) - want) <= tol * abs(want), (step, float(lm), want)
+
+
+def test_rect_batches_feed_the_eval_forward(golden):
+    """val.py:148-157: a rect batch from the device loader through the eval forward, against the oracle model on the oracle
+    loader's batch (non-square 96x128 input, batch 3)."""
+    from oracle.somi_ref.testing import SOMI_ANCHORS
+    from somi_amd.augment import DeviceImageCache
+    from tests.test_model_gpu import build, rel_close
+    g = golden('augment_rect')
+    n, S, bs = int(g['n']), int(g['img_size']), int(g['batch_size'])
+    imgs, labs = [g[f'src{i}'] for i in range(n)], [g[f'lab{i}'] for i in range(n)]
+    kw = dict(augment=False, rect=True, batch_size=bs, stride=int(g['stride']), pad=float(g['pad']))
+    ref, mine = build(0.25, 0.33, SOMI_ANCHORS, seed=6)
+    want_img, _, _ = collate([CachedDataset(imgs, labs, S, dict(HYP_AUGMENT), **kw)[k] for k in range(bs)])
+    got_img, _, _ = DeviceImageCache(imgs, labs, S, dict(HYP_AUGMENT), **kw).batch(range(bs))
+    assert torch.equal(got_img.cpu(), want_img) and got_img.shape[2] != got_img.shape[3]
+    with torch.no_grad():
+        rel_close(mine(got_img)[0], ref(want_img.float() / 255)[0], what='z on a rect batch')

@@ -20,6 +20,7 @@ and draw no random numbers; a non-zero `copy_paste` or `perspective` raises.
 import ctypes as C
 import math
 import random
+from collections import namedtuple
 
 import numpy as np
 import torch
@@ -71,6 +72,11 @@ def _inverse_affine(M):
     return [ia, ib, -ia * tx - ib * ty, ic, id_, -ic * tx - id_ * ty]
 
 
+Plan = namedtuple('Plan', 'canvases mix_r luts flipud fliplr out_hw')
+"""What the kernel needs for one sample: canvases (1 or 2), mixup ratio or None, (3,256) uint8 jitter tables or None, flips, and
+the output size (h, w)."""
+
+
 class _Canvas:
     """One virtual canvas: placed sources + optional affine crop (host-side description of `somi_aug_canvas`)."""
 
@@ -79,6 +85,24 @@ class _Canvas:
 
     def place(self, img_id, x1, y1, x2, y2, dx, dy):
         self.sources.append((img_id, x1, y1, x2, y2, dx, dy))
+
+
+def rect_batch_shapes(wh, batch_index, img_size, stride, pad):
+    """datasets.py:497-523: order the images by aspect ratio h/w and give every batch the smallest stride-multiple letterbox
+    shape that holds its images.  wh: (n,2) float64 (width, height).  -> (order, batch_shapes (nb,2) int [h, w])."""
+    ar = wh[:, 1] / wh[:, 0]
+    order = ar.argsort()
+    ar = ar[order]
+    nb = int(batch_index[-1]) + 1
+    shapes = [[1, 1]] * nb
+    for i in range(nb):
+        ari = ar[batch_index == i]
+        lo, hi = ari.min(), ari.max()
+        if hi < 1:
+            shapes[i] = [hi, 1]
+        elif lo > 1:
+            shapes[i] = [1, 1 / lo]
+    return order, np.ceil(np.array(shapes) * img_size / stride + pad).astype(int) * stride
 
 
 class DeviceImageCache:
@@ -90,21 +114,31 @@ class DeviceImageCache:
     `ds.batch(indices)` -> what `collate_fn` returns for those samples, from a single kernel launch.
     """
 
-    def __init__(self, imgs, labels, img_size=640, hyp=None, augment=True, rect=False, device='cuda:0'):
+    def __init__(self, imgs, labels, img_size=640, hyp=None, augment=True, rect=False, batch_size=16, stride=32, pad=0.0,
+                 shapes=None, device='cuda:0'):
+        """rect / batch_size / stride / pad as in `LoadImagesAndLabels.__init__` (datasets.py:405-414): with rect=True the samples
+        are re-ordered by aspect ratio and every run of `batch_size` of them shares one letterbox shape (val.py:129-138 uses
+        rect=True, pad=0.5).  shapes: the (n,2) original (width, height) of the files if they differ from the cached sizes."""
         if len(imgs) != len(labels) or not imgs:
             raise ValueError('need one label array per image')
-        if rect:
-            raise NotImplementedError('rectangular batches (val.py --rect) are not part of the device pipeline')
         self.hyp = dict(HYP_VISDRONE_AUGMENT if hyp is None else hyp)
         if self.hyp.get('copy_paste', 0.0) or self.hyp.get('perspective', 0.0):
             raise NotImplementedError('copy_paste / perspective are 0.0 in the reference configuration; not built')
-        self.img_size, self.augment, self.rect = int(img_size), bool(augment), False
-        self.mosaic = self.augment
+        self.img_size, self.augment, self.rect = int(img_size), bool(augment), bool(rect)
+        self.mosaic = self.augment and not self.rect
         self.mosaic_border = [-self.img_size // 2, -self.img_size // 2]
         self.device = torch.device(device)
         self.n = len(imgs)
         self.indices = range(self.n)
         self.labels = [np.asarray(l, dtype=np.float32).reshape(-1, 5) for l in labels]
+        self.batch_index = np.floor(np.arange(self.n) / batch_size).astype(int)                # datasets.py:477-479
+        self.order = np.arange(self.n)                                                    # position -> index into `imgs` as given
+        if self.rect:
+            wh = np.array([(im.shape[1], im.shape[0]) for im in imgs] if shapes is None else shapes,
+                          dtype=np.float64)
+            self.order, self.batch_shapes = rect_batch_shapes(wh, self.batch_index, self.img_size, stride, pad)
+            imgs = [imgs[i] for i in self.order]
+            self.labels = [self.labels[i] for i in self.order]
         self.img_hw, offsets, total = [], [], 0
         arrs = []
         for im in imgs:
@@ -212,22 +246,23 @@ class DeviceImageCache:
                 labels = np.concatenate((labels, labels2), 0)
         else:
             h, w = self.img_hw[index]
-            r = min(s / h, s / w)
+            sh, sw = (int(v) for v in self.batch_shapes[self.batch_index[index]]) if self.rect else (s, s)
+            r = min(sh / h, sw / w)
             if not self.augment:
                 r = min(r, 1.0)
             unpad = int(round(w * r)), int(round(h * r))
             if unpad != (w, h):
                 raise NotImplementedError('letterbox would resize: cache images at img_size (datasets.py:722-727)')
-            dw, dh = (s - unpad[0]) / 2, (s - unpad[1]) / 2
+            dw, dh = (sw - unpad[0]) / 2, (sh - unpad[1]) / 2
             top, left = int(round(dh - 0.1)), int(round(dw - 0.1))
-            canvas = _Canvas(s, s)
+            canvas = _Canvas(sh, sw)
             canvas.place(index, left, top, left + w, top + h, left, top)
             canvases.append(canvas)
             shapes = (h, w), ((1.0, 1.0), (dw, dh))
             labels = self.labels[index].copy()
             if labels.size:
                 labels[:, 1:] = xywhn2xyxy(labels[:, 1:], r * w, r * h, padw=dw, padh=dh)
-            size = (s, s)
+            size = (sh, sw)
             if self.augment:
                 labels, size = self._affine(canvas, labels, (0, 0))
         nl = len(labels)
@@ -248,11 +283,11 @@ class DeviceImageCache:
                 fliplr = True
                 if nl:
                     labels[:, 1] = 1 - labels[:, 1]
-        return (canvases, mix_r, luts, flipud, fliplr), labels, shapes
+        return Plan(canvases, mix_r, luts, flipud, fliplr, (int(size[0]), int(size[1]))), labels, shapes
 
     # ---------------------------------------------------------------- device side
     def _fill_record(self, rec, plan):
-        canvases, mix_r, luts, flipud, fliplr = plan
+        canvases, mix_r, luts, flipud, fliplr, _ = plan
         base = self.store.data_ptr()
         for ci, canvas in enumerate(canvases):
             c = rec.canvas[ci]
@@ -286,19 +321,23 @@ class DeviceImageCache:
             self._fill_record(rec, plan)
         return torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(self.device)
 
-    def launch(self, records, B, out=None):
-        """somi_augment_u8 on the current stream: uint8 (B, 3, s, s) RGB."""
-        s = self.img_size
+    def launch(self, records, B, out=None, out_hw=None):
+        """somi_augment_u8 on the current stream: uint8 (B, 3, h, w) RGB."""
+        h, w = out_hw or (self.img_size, self.img_size)
         if out is None:
-            out = torch.empty((B, 3, s, s), dtype=torch.uint8, device=self.device)
+            out = torch.empty((B, 3, h, w), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().somi_augment_u8(records.data_ptr(), B, s, s, FILL, out.data_ptr(),
+            _lib.check(_lib.lib().somi_augment_u8(records.data_ptr(), B, h, w, FILL, out.data_ptr(),
                                                   torch.cuda.current_stream().cuda_stream), 'somi_augment_u8')
         return out
 
     def render(self, plans):
-        """One launch: the uint8 (B, 3, s, s) RGB batch of `plans` (a list of the first element `plan` returns)."""
-        return self.launch(self.upload(plans), len(plans))
+        """One launch: the uint8 (B, 3, h, w) RGB batch of `plans` (a list of the first element `plan` returns); the samples of
+        one launch share their output size (always true for mosaic batches and for the batches of a rect loader)."""
+        sizes = {p.out_hw for p in plans}
+        if len(sizes) != 1:
+            raise RuntimeError(f'samples of one batch have different letterbox shapes {sorted(sizes)} (rect batches must not be mixed)')
+        return self.launch(self.upload(plans), len(plans), out_hw=sizes.pop())
 
     def __getitem__(self, index):
         plan, labels, shapes = self.plan(index)
