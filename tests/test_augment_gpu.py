@@ -181,3 +181,26 @@ def test_rect_batches_feed_the_eval_forward(golden):
     assert torch.equal(got_img.cpu(), want_img) and got_img.shape[2] != got_img.shape[3]
     with torch.no_grad():
         rel_close(mine(got_img)[0], ref(want_img.float() / 255)[0], what='z on a rect batch')
+
+
+@pytest.mark.parametrize('S,over', [(62, dict(mixup=0.5)),                                        # width % 4 != 0: the 1-pixel kernel
+                                    (100, dict(degrees=45.0, scale=0.9, shear=20.0, translate=0.3, flipud=0.5, mixup=0.3)),
+                                    (64, dict(mosaic=0.5, degrees=30.0, scale=0.5))])
+def test_many_random_samples_match_the_oracle(S, over):
+    """Breadth: 24 seeds per setting with extreme zoom / rotation / shear (crops that leave the canvas, footprints that straddle
+    mosaic seams and image borders), odd sizes, images smaller than the canvas quadrant - device vs oracle, bit for bit."""
+    from somi_amd.augment import DeviceImageCache
+    imgs, labs = synthetic_image_set(S, n=8, seed=S)
+    if over.get('mosaic', 1.0) == 1.0:                      # (a single-image sample would need cv2.resize to scale it up)
+        imgs[2] = np.ascontiguousarray(imgs[2][: max(4, S // 5), : max(4, S // 3)])      # a tiny image inside the mosaics
+    hyp = dict(HYP_AUGMENT, **over)
+    cpu, dev = CachedDataset(imgs, labs, S, hyp), DeviceImageCache(imgs, labs, S, hyp)
+    for seed in range(24):
+        picks = [(seed + k) % 8 for k in range(4)]
+        seed_all(1000 + seed)
+        want_img, want_lab, _ = collate([cpu[i] for i in picks])
+        seed_all(1000 + seed)
+        got_img, got_lab, _ = dev.batch(picks)
+        bad = int((got_img.cpu() != want_img).sum())
+        assert bad == 0, f'S={S} seed {seed}: {bad} bytes differ'
+        assert torch.equal(got_lab, want_lab), (S, seed)
