@@ -23,6 +23,7 @@ for p in (ROOT, os.path.join(ROOT, 'yolo-somi_amd')):
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+XGMI_LINKS, XGMI_LINK_GBPS = 7, 153  # per GPU: 7 point-to-point xGMI links of ~153 GB/s each (MI355X_MICROARCH.md)
 
 
 def somi_cfg_full():
@@ -185,6 +186,17 @@ def main():
     dt = timed_steps(step, args.steps, dist=dist, sync=torch.cuda.synchronize, device=dev)   # barrier+sync both sides, MAX over ranks
     ops.PROFILE = None
 
+    # the gradient exchange on its own (algorithmic and bus bandwidth against the xGMI links) - after the
+    # timed region, collective over all ranks
+    exchange = None
+    if world > 1 and args.mode == 'train' and trainer.buckets is not None:
+        secs, nbytes = trainer.buckets.measure_exchange(iters=5)
+        alg = nbytes / secs / 1e9
+        exchange = {'bytes': nbytes, 'buckets': sum(len(c) for c in trainer.buckets.buckets), 'ms': round(secs * 1e3, 3),
+                    'algbw_GBps': round(alg, 1), 'busbw_GBps': round(alg * 2 * (world - 1) / world, 1),
+                    'xgmi_peak_GBps_per_gpu': XGMI_LINKS * XGMI_LINK_GBPS, 'backend': backend,
+                    'note': 'bucketed SUM all-reduce of the flat fp32 gradient buffers, not overlapped with anything'}
+
     if rank == 0:
         # dominant kernel = the conv tile variant with the largest total time
         by = {}
@@ -218,6 +230,8 @@ def main():
                          'conv_share_of_step': round(all_secs / dt, 3)},
         }
         out['roofline']['traffic'] = pmc_traffic(name)
+        if exchange:
+            out['allreduce'] = exchange
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_train(args.size) if args.mode == 'train' else cpu_baseline(args.size)
         print(json.dumps(out), flush=True)

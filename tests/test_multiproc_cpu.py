@@ -74,7 +74,10 @@ def _ddp_worker(rank, world, port, q):
         gb.layer_done(layer)
         order.append(len(gb.launched))
     gb.finish()
-    q.put((rank, order, list(gb.launched), g0.clone(), g1.clone()))
+    res = (rank, order, list(gb.launched), g0.clone(), g1.clone())
+    secs, nbytes = gb.measure_exchange(iters=2)              # what bench.py reports as `allreduce` at N > 1 (collective)
+    assert secs > 0 and nbytes == 1010 * 4 and float(g0.abs().sum()) == 0.0 and gb.launched == []
+    q.put(res)
     dist.destroy_process_group()
 
 

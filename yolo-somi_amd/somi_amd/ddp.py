@@ -76,6 +76,30 @@ class GradBuckets:
         self.handles = []
 
 
+    def measure_exchange(self, iters=5, sync=None):
+        """The whole bucketed exchange on its own (nothing to overlap with), `iters` times: seconds per exchange and the bytes
+        one exchange reduces.  Collective: every rank has to call it.  The buffers are zeroed first (repeated SUMs of live
+        gradients would overflow) - call it outside the training loop only."""
+        import time
+        sync = sync or (torch.cuda.synchronize if self.flat[0].is_cuda else (lambda: None))
+        for buf in self.flat:
+            buf.zero_()
+        nbytes = sum(buf.numel() * buf.element_size() for buf in self.flat)
+        secs = []
+        for it in range(iters + 1):                               # first pass = warm-up (communicator / ring setup)
+            self.reset()
+            sync()
+            if self.dist is not None and self.dist.get_world_size() > 1:
+                self.dist.barrier()
+            t0 = time.perf_counter()
+            self.finish()
+            sync()
+            if it:
+                secs.append(time.perf_counter() - t0)
+        self.reset()
+        return sum(secs) / len(secs), nbytes
+
+
 def layer_offsets(model, optimizer):
     """For every flat group buffer: layer index -> smallest offset of that layer's (and all later layers') parameters.  Parameters are
     laid out in module order, so 'layer i and everything after it' is the tail of the buffer starting at that offset."""
