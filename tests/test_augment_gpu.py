@@ -24,7 +24,7 @@ def test_device_samples_match_the_reference_fixture(golden):
     for k, name, seed, idx, imgs, labs, S, hyp, augment in fixture_cases(g):
         ds = DeviceImageCache(imgs, labs, S, hyp, augment=augment)
         seed_all(seed)
-        img, lab, shapes = ds[idx]
+        img, lab, _, shapes = ds[idx]
         assert img.is_cuda and img.dtype == torch.uint8 and tuple(img.shape) == (3, S, S)
         bad = int((img.cpu().numpy() != g[f'out_img{k}']).sum())
         assert bad == 0, f'{name} seed {seed}: {bad} bytes differ'
@@ -44,7 +44,7 @@ def test_full_size_batch_matches_the_oracle(over):
     want_img, want_lab, _ = collate([CachedDataset(imgs, labs, S, hyp)[i] for i in picks])
     ds = DeviceImageCache(imgs, labs, S, hyp)
     seed_all(123)
-    got_img, got_lab, _ = ds.batch(picks)
+    got_img, got_lab, _, _ = ds.batch(picks)
     assert tuple(got_img.shape) == (8, 3, S, S)
     assert torch.equal(got_img.cpu(), want_img)
     assert torch.equal(got_lab, want_lab)
@@ -57,7 +57,8 @@ def test_validation_path_is_a_letterboxed_copy():
     imgs, labs = synthetic_image_set(S, n=4, seed=3)
     ds = DeviceImageCache(imgs, labs, S, augment=False)
     state = random.getstate()
-    out, targets, shapes = ds.batch([0, 1, 2, 3])
+    out, targets, paths, shapes = ds.batch([0, 1, 2, 3])
+    assert paths == (0, 1, 2, 3)
     assert random.getstate() == state
     for j, im in enumerate(imgs):
         h, w = im.shape[:2]
@@ -80,7 +81,8 @@ def test_rect_validation_batches_match_the_reference_fixture(golden):
                           pad=float(g['pad']))
     for b0 in range(0, n, bs):
         picks = list(range(b0, min(b0 + bs, n)))
-        out, targets, shapes = ds.batch(picks)
+        out, targets, paths, shapes = ds.batch(picks)
+        assert [int(g['order'][k]) for k in picks] == list(paths)
         assert tuple(out.shape[2:]) == tuple(g['batch_shapes'][b0 // bs])
         for j, k in enumerate(picks):
             assert np.array_equal(out[j].cpu().numpy(), g[f'out_img{k}']), k
@@ -98,7 +100,7 @@ def test_flips_and_identity_tables_are_pure_moves():
     for tag, over in (('none', {}), ('lr', dict(fliplr=1.0)), ('ud', dict(flipud=1.0)), ('both', dict(fliplr=1.0, flipud=1.0))):
         ds = DeviceImageCache(imgs, labs, S, dict(base, **over))
         seed_all(9)
-        outs[tag], lab, _ = ds.batch([0, 1, 2, 3])
+        outs[tag], lab, _, _ = ds.batch([0, 1, 2, 3])
         if tag == 'none':
             lab0 = lab
         elif tag == 'both':
@@ -153,7 +155,7 @@ def test_device_batches_drive_the_training_step():
         seed_all(50 + step)
         ci, ct, _ = collate([cpu_ds[i] for i in picks])
         seed_all(50 + step)
-        di, dt, _ = dev_ds.batch(picks)
+        di, dt, _, _ = dev_ds.batch(picks)
         assert torch.equal(di.cpu(), ci) and torch.equal(dt, ct)
         lr_, _ = crit(ref(ci.float() / 255), ct)
         opt.zero_grad()
@@ -177,7 +179,7 @@ def test_rect_batches_feed_the_eval_forward(golden):
     kw = dict(augment=False, rect=True, batch_size=bs, stride=int(g['stride']), pad=float(g['pad']))
     ref, mine = build(0.25, 0.33, SOMI_ANCHORS, seed=6)
     want_img, _, _ = collate([CachedDataset(imgs, labs, S, dict(HYP_AUGMENT), **kw)[k] for k in range(bs)])
-    got_img, _, _ = DeviceImageCache(imgs, labs, S, dict(HYP_AUGMENT), **kw).batch(range(bs))
+    got_img, _, _, _ = DeviceImageCache(imgs, labs, S, dict(HYP_AUGMENT), **kw).batch(range(bs))
     assert torch.equal(got_img.cpu(), want_img) and got_img.shape[2] != got_img.shape[3]
     with torch.no_grad():
         rel_close(mine(got_img)[0], ref(want_img.float() / 255)[0], what='z on a rect batch')
@@ -200,7 +202,7 @@ def test_many_random_samples_match_the_oracle(S, over):
         seed_all(1000 + seed)
         want_img, want_lab, _ = collate([cpu[i] for i in picks])
         seed_all(1000 + seed)
-        got_img, got_lab, _ = dev.batch(picks)
+        got_img, got_lab, _, _ = dev.batch(picks)
         bad = int((got_img.cpu() != want_img).sum())
         assert bad == 0, f'S={S} seed {seed}: {bad} bytes differ'
         assert torch.equal(got_lab, want_lab), (S, seed)

@@ -159,3 +159,13 @@ int run(const float *x, const float *w_packed, const float *bias, float *y, void
         assert r.returncode == 0, r.stderr
     finally:
         os.unlink(f.name)
+
+
+def test_fitness_uses_the_forks_weights():
+    """utils/metrics.py:15-18: 0.1 P + 0.1 R + 0.1 mAP@0.5 + 0.7 mAP@0.5:0.95."""
+    import numpy as np
+    import torch
+    from somi_amd.metrics import fitness
+    x = np.array([[0.5, 0.4, 0.3, 0.2, 9.0], [1.0, 1.0, 1.0, 1.0, 0.0]])
+    assert np.allclose(fitness(x), [0.5 * 0.1 + 0.4 * 0.1 + 0.3 * 0.1 + 0.2 * 0.7, 1.0])
+    assert torch.allclose(fitness(torch.from_numpy(x)), torch.tensor([0.26, 1.0], dtype=torch.float64))

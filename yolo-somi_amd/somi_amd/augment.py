@@ -110,15 +110,16 @@ class DeviceImageCache:
 
     imgs: list of (h, w, 3) BGR uint8 arrays (or tensors) whose longer side is `img_size` (what `load_image` caches,
     datasets.py:710-729); labels: list of (n, 5) float32 [cls, x, y, w, h] normalised (datasets.py:455).
-    `ds[i]` -> (img uint8 (3, s, s) RGB on the device, labels_out (nl, 6), shapes) like `__getitem__`;
+    `ds[i]` -> (img uint8 (3, s, s) RGB on the device, labels_out (nl, 6), path, shapes) like `__getitem__`;
     `ds.batch(indices)` -> what `collate_fn` returns for those samples, from a single kernel launch.
     """
 
     def __init__(self, imgs, labels, img_size=640, hyp=None, augment=True, rect=False, batch_size=16, stride=32, pad=0.0,
-                 shapes=None, device='cuda:0'):
+                 shapes=None, img_files=None, device='cuda:0'):
         """rect / batch_size / stride / pad as in `LoadImagesAndLabels.__init__` (datasets.py:405-414): with rect=True the samples
         are re-ordered by aspect ratio and every run of `batch_size` of them shares one letterbox shape (val.py:129-138 uses
-        rect=True, pad=0.5).  shapes: the (n,2) original (width, height) of the files if they differ from the cached sizes."""
+        rect=True, pad=0.5).  shapes: the (n,2) original (width, height) of the files if they differ from the cached sizes.
+        img_files: the paths `__getitem__` / `collate_fn` hand back as their third element (indices when not given)."""
         if len(imgs) != len(labels) or not imgs:
             raise ValueError('need one label array per image')
         self.hyp = dict(HYP_VISDRONE_AUGMENT if hyp is None else hyp)
@@ -133,12 +134,14 @@ class DeviceImageCache:
         self.labels = [np.asarray(l, dtype=np.float32).reshape(-1, 5) for l in labels]
         self.batch_index = np.floor(np.arange(self.n) / batch_size).astype(int)                # datasets.py:477-479
         self.order = np.arange(self.n)                                                    # position -> index into `imgs` as given
+        self.img_files = list(img_files) if img_files is not None else list(range(self.n))
         if self.rect:
             wh = np.array([(im.shape[1], im.shape[0]) for im in imgs] if shapes is None else shapes,
                           dtype=np.float64)
             self.order, self.batch_shapes = rect_batch_shapes(wh, self.batch_index, self.img_size, stride, pad)
             imgs = [imgs[i] for i in self.order]
             self.labels = [self.labels[i] for i in self.order]
+            self.img_files = [self.img_files[i] for i in self.order]
         self.img_hw, offsets, total = [], [], 0
         arrs = []
         for im in imgs:
@@ -344,17 +347,17 @@ class DeviceImageCache:
         out = torch.zeros((len(labels), 6))
         if len(labels):
             out[:, 1:] = torch.from_numpy(labels)
-        return self.render([plan])[0], out, shapes
+        return self.render([plan])[0], out, self.img_files[self.indices[index]], shapes
 
     def batch(self, indices):
         """`collate_fn(batch)` (datasets.py:675-680) of `[self[i] for i in indices]`: imgs (B,3,s,s) uint8 on the device,
-        targets (nt, 6) [sample, cls, x, y, w, h] (host tensor, as the loader yields it), shapes."""
-        plans, labs, shapes = [], [], []
+        targets (nt, 6) [sample, cls, x, y, w, h] (host tensor, as the loader yields it), paths, shapes."""
+        plans, labs, shapes, paths = [], [], [], []
         for j, i in enumerate(indices):
             plan, labels, shp = self.plan(i)
             block = torch.zeros((len(labels), 6))
             if len(labels):
                 block[:, 1:] = torch.from_numpy(labels)
             block[:, 0] = j
-            plans.append(plan), labs.append(block), shapes.append(shp)
-        return self.render(plans), torch.cat(labs, 0), tuple(shapes)
+            plans.append(plan), labs.append(block), shapes.append(shp), paths.append(self.img_files[self.indices[i]])
+        return self.render(plans), torch.cat(labs, 0), tuple(paths), tuple(shapes)

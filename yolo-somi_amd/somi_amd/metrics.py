@@ -15,6 +15,16 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+FITNESS_WEIGHTS = (0.1, 0.1, 0.1, 0.7)
+"""utils/metrics.py:16 - this fork weights P, R, mAP@0.5, mAP@0.5:0.95 as 0.1 / 0.1 / 0.1 / 0.7 (upstream YOLOv5: 0, 0, 0.1, 0.9)."""
+
+
+def fitness(x):
+    """utils/metrics.py:15-18: the scalar `train.py:304-305` ranks checkpoints by; x: (n, >=4) rows of [P, R, mAP@0.5, mAP@0.5:0.95, ...]
+    (numpy array or tensor) -> (n,)."""
+    return (x[:, :4] * x.new_tensor(FITNESS_WEIGHTS)).sum(1) if isinstance(x, torch.Tensor) else (x[:, :4] * FITNESS_WEIGHTS).sum(1)
+
+
 def process_batches(detections, labels, iouv):
     """detections: list of (N_b,6) x1,y1,x2,y2,conf,cls; labels: list of (M_b,5) cls,x1,y1,x2,y2 (GPU tensors, pixel units);
     iouv (T,) -> list of (N_b,T) bool tensors."""
