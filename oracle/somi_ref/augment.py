@@ -169,22 +169,16 @@ class CachedDataset:
         for q, idx in enumerate(picks):
             img = self.imgs[idx]
             h, w = img.shape[:2]
-            if q == 0:      # top left quadrant: the image's bottom-right corner sits on the centre
-                x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
-                x1b, y1b, x2b, y2b = w - (x2a - x1a), h - (y2a - y1a), w, h
-            elif q == 1:    # top right
-                x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, s * 2), yc
-                x1b, y1b, x2b, y2b = 0, h - (y2a - y1a), min(w, x2a - x1a), h
-            elif q == 2:    # bottom left
-                x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(s * 2, yc + h)
-                x1b, y1b, x2b, y2b = w - (x2a - x1a), 0, w, min(y2a - y1a, h)
-            else:           # bottom right
-                x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
-                x1b, y1b, x2b, y2b = 0, 0, min(w, x2a - x1a), min(y2a - y1a, h)
-            canvas[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]
+            # each image is anchored with one corner on the centre (quadrants 0..3 = top-left, top-right, bottom-left,
+            # bottom-right) and whatever sticks out of the canvas is cut off; this is what the reference's four explicit
+            # (x1a, y1a, x2a, y2a) / (x1b, y1b, x2b, y2b) cases compute
+            ox = xc - w if q % 2 == 0 else xc                 # canvas position of the image's own (0, 0)
+            oy = yc - h if q < 2 else yc
+            cx1, cy1, cx2, cy2 = max(ox, 0), max(oy, 0), min(ox + w, 2 * s), min(oy + h, 2 * s)
+            canvas[cy1:cy2, cx1:cx2] = img[cy1 - oy:cy2 - oy, cx1 - ox:cx2 - ox]
             lab = self.labels[idx].copy()
             if lab.size:
-                lab[:, 1:] = boxes_from_normalised(lab[:, 1:], w, h, x1a - x1b, y1a - y1b)
+                lab[:, 1:] = boxes_from_normalised(lab[:, 1:], w, h, ox, oy)
             boxes.append(lab)
         boxes = np.concatenate(boxes, 0)
         np.clip(boxes[:, 1:], 0, 2 * s, out=boxes[:, 1:])
