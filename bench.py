@@ -128,9 +128,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    rehearsal = world == 1 and os.environ.get('SOMI_DDP_SINGLE_RANK') == '1'    # one-rank RCCL group: exercises the N > 1 call pattern
+    if world > 1 or rehearsal:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if rehearsal:
+            os.environ.setdefault('MASTER_PORT', '29557'), os.environ.setdefault('RANK', '0'), os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI, one GPU per rank
         else:
@@ -189,7 +192,7 @@ def main():
     # the gradient exchange on its own (algorithmic and bus bandwidth against the xGMI links) - after the
     # timed region, collective over all ranks
     exchange = None
-    if world > 1 and args.mode == 'train' and trainer.buckets is not None:
+    if (world > 1 or rehearsal) and args.mode == 'train' and trainer.buckets is not None:
         secs, nbytes = trainer.buckets.measure_exchange(iters=5)
         alg = nbytes / secs / 1e9
         exchange = {'bytes': nbytes, 'buckets': sum(len(c) for c in trainer.buckets.buckets), 'ms': round(secs * 1e3, 3),

@@ -542,3 +542,24 @@ def test_bn_statistics_survive_a_large_channel_mean():
     ops.bn_act_backward(nhwc(dz).float().to(d), 0, xd, 0, C, mean, rstd, scale, shift, 'silu', 0, True, dx, 0, dg, db)
     rel_close(dg, bn.weight.grad, rel=2e-2, what='dgamma')
     rel_close(db, bn.bias.grad, rel=1e-3, what='dbeta')
+
+
+def test_rccl_call_pattern_single_rank_rehearsal():
+    """SOMI_DDP_SINGLE_RANK=1: bench.py's N > 1 path (RCCL init bound to the device, weight broadcast, bucketed asynchronous
+    all-reduces on the side stream, barriers, MAX over ranks, the `allreduce` report) on a one-rank `nccl` group - the call
+    pattern the driver's 8-GPU run uses, on the one GPU this box has."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOMI_DDP_SINGLE_RANK='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29563', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch', '4', '--size', '256',
+                        '--no-cpu-baseline', '--no-infer'], capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0
+    ar = line['allreduce']
+    assert ar['backend'] == 'nccl' and ar['bytes'] == 311747792 and ar['buckets'] >= 7 and ar['ms'] > 0

@@ -9,7 +9,13 @@ layer that owns a slice of it has finished its backward, so the exchange overlap
 step waits for the side stream.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): ~48 MB buckets keep each RCCL call large
 enough to use all links while leaving several buckets to overlap (310 MB of fp32 gradients -> 7 buckets).
 """
+import os
+
 import torch
+
+# SOMI_DDP_SINGLE_RANK=1: run the collectives even in a one-rank process group - a rehearsal of the RCCL call pattern (init,
+# broadcast, bucketed all-reduce on the side stream, barrier) on a box with a single GPU; results are unchanged by it.
+SINGLE_RANK_REHEARSAL = os.environ.get('SOMI_DDP_SINGLE_RANK') == '1'
 
 
 class GradBuckets:
@@ -41,7 +47,7 @@ class GradBuckets:
 
     def _launch(self, bi, start, end):
         self.launched.append((bi, start, end))
-        if self.dist is None or self.dist.get_world_size() == 1:
+        if self.dist is None or (self.dist.get_world_size() == 1 and not SINGLE_RANK_REHEARSAL):
             return
         view = self.flat[bi][start:end]
         if self.use_streams:
@@ -89,7 +95,7 @@ class GradBuckets:
         for it in range(iters + 1):                               # first pass = warm-up (communicator / ring setup)
             self.reset()
             sync()
-            if self.dist is not None and self.dist.get_world_size() > 1:
+            if self.dist is not None and (self.dist.get_world_size() > 1 or SINGLE_RANK_REHEARSAL):
                 self.dist.barrier()
             t0 = time.perf_counter()
             self.finish()

@@ -8,7 +8,7 @@ the hand-written reverse walk (conv dgrad / wgrad on MFMA, BN / attention / ODCo
 With more than one rank the flat gradient buffers are all-reduced (SUM) in buckets on a side stream while the backward walk is
 still running (ddp.GradBuckets) - DDP's semantics without the wrapper.  fp32 throughout (no GradScaler: nothing to scale).
 """
-from .ddp import GradBuckets, layer_offsets
+from .ddp import GradBuckets, SINGLE_RANK_REHEARSAL, layer_offsets
 from .loss import ComputeLoss
 from .optim import build_optimizer
 
@@ -53,7 +53,7 @@ class TrainStep:
         self.compute_loss = ComputeLoss(model)
         self.accumulate, self._since_step = max(int(accumulate), 1), 0
         self.buckets = None
-        if self.world > 1:
+        if self.world > 1 or (dist is not None and SINGLE_RANK_REHEARSAL):
             self.buckets = GradBuckets(self.optimizer.flat_grads, layer_offsets(model, self.optimizer), dist=dist,
                                        bucket_bytes=bucket_mb << 20)
             model.__dict__['_grad_hook'] = self.buckets.layer_done
