@@ -206,3 +206,16 @@ def test_many_random_samples_match_the_oracle(S, over):
         bad = int((got_img.cpu() != want_img).sum())
         assert bad == 0, f'S={S} seed {seed}: {bad} bytes differ'
         assert torch.equal(got_lab, want_lab), (S, seed)
+
+
+def test_training_through_the_device_loader_learns_the_task():
+    """tests/e2e_loader.py: a detector trained ONLY on the loader's augmented samples (mosaic, affine crop, mixup, jitter,
+    flips) finds the objects in plain rectangular validation batches - boxes and pixels stay aligned through the pipeline."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('e2e_loader', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'e2e_loader.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.main(steps=400)
+    assert res['loss_last'] < 0.5 * res['loss_first'], res
+    assert res['val']['mAP50'] > 0.6, res
