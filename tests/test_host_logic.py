@@ -169,3 +169,39 @@ def test_fitness_uses_the_forks_weights():
     x = np.array([[0.5, 0.4, 0.3, 0.2, 9.0], [1.0, 1.0, 1.0, 1.0, 0.0]])
     assert np.allclose(fitness(x), [0.5 * 0.1 + 0.4 * 0.1 + 0.3 * 0.1 + 0.2 * 0.7, 1.0])
     assert torch.allclose(fitness(torch.from_numpy(x)), torch.tensor([0.26, 1.0], dtype=torch.float64))
+
+
+def test_ctypes_mirrors_match_the_c_layout():
+    """The structs of include/somi_hip.h, compiled as C, have exactly the sizes and field offsets of their ctypes mirrors (the
+    sample records of the input pipeline are filled on the host and read by the kernel byte for byte)."""
+    import ctypes
+    import shutil
+    import subprocess
+    import tempfile
+    from somi_amd import _lib
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probes = [('somi_conv_desc', _lib.ConvDesc, ['y', 'B', 'per_sample_w', 'res2_cs', 'workspace', 'workspace_bytes', 'stat_pivot']),
+              ('somi_loss_desc', _lib.LossDesc, ['grad', 'nl', 'targets', 'balance', 'gr']),
+              ('somi_aug_source', _lib.AugSource, ['pixels', 'h', 'x1', 'dy']),
+              ('somi_aug_canvas', _lib.AugCanvas, ['src', 'nsrc', 'warp', 'minv']),
+              ('somi_aug_sample', _lib.AugSample, ['canvas', 'mix', 'fliplr', 'mix_r', 'lut'])]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "somi_hip.h"', 'int main(void) {']
+    for cname, _, fields in probes:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        lines += [f'  printf(" %zu", offsetof({cname}, {f}));' for f in fields]
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    with tempfile.TemporaryDirectory() as tmp:
+        src, exe = os.path.join(tmp, 'layout.c'), os.path.join(tmp, 'layout')
+        with open(src, 'w') as f:
+            f.write('\n'.join(lines))
+        r = subprocess.run([gcc, '-std=c99', '-I', os.path.join(root, 'include'), src, '-o', exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for (cname, ct, fields), line in zip(probes, out):
+        got = [int(v) for v in line.split()[1:]]
+        want = [ctypes.sizeof(ct)] + [getattr(ct, f).offset for f in fields]
+        assert got == want, (cname, got, want)
