@@ -38,7 +38,7 @@ def rectangles_dataset(n, S, nc, seed):
     return imgs, labels
 
 
-def main(steps=400, S=128, B=16, nc=4):
+def main(steps=500, S=128, B=16, nc=4, mosaic=0.8, settle=True):
     from somi_amd import val as V
     from somi_amd.augment import DeviceImageCache, HYP_VISDRONE_AUGMENT
     from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg
@@ -53,7 +53,9 @@ def main(steps=400, S=128, B=16, nc=4):
     tr = TrainStep(model, dict(HYP_VISDRONE), B)
     for g_ in tr.optimizer.param_groups:
         g_['lr'] = 2e-3
-    hyp = dict(HYP_VISDRONE_AUGMENT, hsv_h=0.01)                  # the classes differ by colour: keep the hue, jitter the rest
+    # the classes differ by colour: keep the hue, jitter the rest; one sample in five is a single letterboxed image (what
+    # validation looks like), the others are mosaics
+    hyp = dict(HYP_VISDRONE_AUGMENT, hsv_h=0.01, mosaic=mosaic)
     train_imgs, train_labels = rectangles_dataset(96, S, nc, 1)
     val_imgs, val_labels = rectangles_dataset(48, S, nc, 2)
     loader = DeviceImageCache(train_imgs, train_labels, S, hyp, augment=True)
@@ -61,6 +63,9 @@ def main(steps=400, S=128, B=16, nc=4):
     t0 = time.time()
     first = last = None
     for it in range(steps):
+        if settle and it == steps - steps // 4:                   # settle: the last quarter runs at a quarter of the rate
+            for g_ in tr.optimizer.param_groups:
+                g_['lr'] = 5e-4
         imgs, targets, _, _ = loader.batch([random.randrange(len(loader)) for _ in range(B)])
         loss, _ = tr.step(imgs, targets.cuda())
         first = float(loss) if it == 0 else first
