@@ -1,7 +1,11 @@
+#!/usr/bin/env python3
+"""Times the BatchNorm training kernels (statistics, affine + activation, backward reduce / apply) on single tensors of the
+step's largest shapes and prints the achieved TB/s.  usage: bn_probe.py  (runs on the MI355X)"""
+import os
 import sys
 
 import torch
-sys.path.insert(0, '/root/repo/yolo-somi_amd')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'yolo-somi_amd'))
 from somi_amd import ops
 d = torch.device('cuda')
 def timeit(fn, warm=3, iters=20):

@@ -1,5 +1,13 @@
-import sys, time, torch
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/yolo-somi_amd')
+#!/usr/bin/env python3
+"""How far the host runs ahead of the GPU in the training step: wall time of enqueueing four steps vs the time until they have
+executed (the step is GPU-bound when the first is well below the second).  usage: cpu_ahead_probe.py  (runs on the MI355X)"""
+import os
+import sys
+import time
+
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'yolo-somi_amd'))
 from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch
 from somi_amd.model import Model
 from somi_amd.train import TrainStep

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel measurements on the MI355X (HIP events on the launch stream): DCNv3 forward/backward achieved HBM GB/s
 against the algorithmic bytes of SURVEY.md section 8d, and the conv-backbone (layers 0-9, 640x640, batch 64) fp32-MFMA TFLOP/s
-that BASELINE.json's north_star targets.  Prints one JSON object per line."""
+that BASELINE.json's north_star targets; `val`: the validation-metric kernels at VisDrone-val scale; `augment`: the input-pipeline
+kernel at the training batch.  usage: kernel_bench.py [dcn] [backbone] [val] [augment]  - prints one JSON object per line."""
 import json
 import os
 import sys
