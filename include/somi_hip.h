@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 6
+#define SOMI_ABI_VERSION 7
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -427,6 +427,13 @@ int somi_wbf_f32(const float *boxes, const float *scores, const int32_t *labels,
  * their input order. */
 int somi_val_match_f32(const float *det, const int *det_off, const float *labels, const int *lab_off, const float *iouv, int T,
                        int B, int max_det, int max_labels, uint8_t *correct, somi_stream_t stream);
+/* somi_confusion_matrix_f32 = utils/metrics.py:98-142 `ConfusionMatrix.process_batch` (val.py:141,186) for a batch of images in
+ * the layout of somi_val_match_f32: detections above `conf` are matched to labels regardless of class (best label per detection,
+ * then best detection per label, IoU > iou_thres) and counted into matrix[(nc+1) x (nc+1)] int32, row = predicted class, column =
+ * true class, index nc = background; counts are ADDED (zero the matrix once).  An image's unmatched detections count only if the
+ * image has at least one match, as in the reference.  Classes outside [0, nc] are ignored. */
+int somi_confusion_matrix_f32(const float *det, const int *det_off, const float *labels, const int *lab_off, int B, int max_det,
+                              int max_labels, int nc, float conf, float iou_thres, int32_t *matrix, somi_stream_t stream);
 size_t somi_ap_per_class_workspace_bytes(long N, int T, int ncap);
 int somi_ap_per_class_f64(const uint8_t *tp, const float *conf, const float *pred_cls, const float *target_cls, long N, long M,
                           int T, int ncap, int *out_classes, int *out_n, double *out_ap, double *out_p, double *out_r,

@@ -329,6 +329,14 @@ def gen_val():
     tp, conf, pcls, tcls = [torch.cat(x, 0).numpy() for x in zip(*stats)]            # val.py:200
     p, r, ap, f1, cls_ = ref_ap(tp, conf, pcls, tcls, plot=False, names={})
     rec.update(nimg=nimg, tp=tp, conf=conf, pred_cls=pcls, target_cls=tcls, p=p, r=r, ap=ap, f1=f1, ap_class=cls_)
+    # the confusion matrix of val.py:141,186 (utils/metrics.py:98-142) over the same images; val.py only feeds it images that have
+    # both labels and predictions (val.py:171-186)
+    from utils.metrics import ConfusionMatrix as RefConfusion
+    cm = RefConfusion(nc=7)                                                          # detections carry classes 0..6
+    for b in range(nimg):
+        if len(rec[f'det{b}']) and len(rec[f'lab{b}']):
+            cm.process_batch(rec[f'det{b}'], rec[f'lab{b}'])
+    rec.update(confusion=cm.matrix, confusion_nc=7, confusion_conf=cm.conf, confusion_iou=cm.iou_thres)
     save('val_metrics', **rec)
 
 

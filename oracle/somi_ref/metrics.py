@@ -1,8 +1,8 @@
 """Oracle (test infrastructure): CPU restatement of the validation metrics that follow NMS in val.py.
 
-Follows val.py:50-71 (process_batch: which detections count as correct at the 10 IoU levels) and
+Follows val.py:50-71 (process_batch: which detections count as correct at the 10 IoU levels),
 utils/metrics.py:21-95 (ap_per_class, compute_ap: per-class precision / recall curves and the 101-point
-interpolated AP).  Pinned by tests/golden/val_metrics.npz, produced by the reference's own functions.
+interpolated AP) and utils/metrics.py:98-142 (ConfusionMatrix.process_batch).  Pinned by tests/golden/val_metrics.npz, produced by the reference's own functions.
 
 Ties: the reference orders candidate matches with `argsort()[::-1]` and detections with `np.argsort(-conf)`, both
 unstable sorts, so the outcome for *exactly equal* IoUs / confidences depends on numpy's sort internals.  This
@@ -82,3 +82,45 @@ def ap_per_class(tp, conf, pred_cls, target_cls):
     f1 = 2 * p * r / (p + r + 1e-16)
     i = f1.mean(0).argmax()
     return p[:, i], r[:, i], ap, f1[:, i], classes.astype('int32')
+
+
+class ConfusionMatrix:
+    """utils/metrics.py:98-142: matrix[predicted class, true class], row / column `nc` = background.
+
+    Detections above `conf` are matched to labels regardless of class: every detection picks the label of highest IoU (> iou_thres),
+    every label keeps the detection of highest IoU among those that picked it.  A label without a detection counts as
+    (background, class); a detection that matched nothing counts as (class, background) - but only in images where at least one
+    match exists (`if n:` :138), a quirk kept here.  Exact IoU ties (the reference's argsort is unstable) go to the lowest index.
+    """
+
+    def __init__(self, nc, conf=0.25, iou_thres=0.2):
+        self.matrix = np.zeros((nc + 1, nc + 1))
+        self.nc, self.conf, self.iou_thres = nc, conf, iou_thres
+
+    def process_batch(self, detections, labels):
+        detections, labels = torch.as_tensor(detections), torch.as_tensor(labels)
+        detections = detections[detections[:, 4] > self.conf]
+        gt = labels[:, 0].int().numpy()
+        dc = detections[:, 5].int().numpy()
+        iou = box_iou(labels[:, 1:], detections[:, :4]).numpy()               # (M, N)
+        M, N = iou.shape
+        ok = iou > self.iou_thres
+        det_of = np.full(M, -1)
+        if ok.any():
+            masked = np.where(ok, iou, -1.0)
+            pick = np.where(ok.any(0), masked.argmax(0), -1)                    # best label per detection (first maximum)
+            for l in range(M):
+                mine = np.nonzero(pick == l)[0]
+                if mine.size:
+                    det_of[l] = mine[np.argmax(iou[l, mine])]                   # best detection per label (first maximum)
+        any_match = (det_of >= 0).any()
+        for l in range(M):
+            if det_of[l] >= 0:
+                self.matrix[dc[det_of[l]], gt[l]] += 1
+            else:
+                self.matrix[self.nc, gt[l]] += 1
+        if any_match:
+            taken = set(det_of[det_of >= 0].tolist())
+            for d in range(N):
+                if d not in taken:
+                    self.matrix[dc[d], self.nc] += 1

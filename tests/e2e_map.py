@@ -87,12 +87,17 @@ def main(steps=300, S=128, B=16, nc=4, width=0.25, depth=0.33):
     torch.cuda.synchronize()
     t_train = time.time() - t0
     val_batches = [rect_batch(B, S, nc, 100 + i) for i in range(4)] + [rect_batch(B, S, nc, 900 + i) for i in range(2)]
-    mp, mr, m50, m, det = V.run(model, val_batches, conf_thres=0.001, iou_thres=0.6)
+    from somi_amd.metrics import ConfusionMatrix
+    cm = ConfusionMatrix(nc)
+    mp, mr, m50, m, det = V.run(model, val_batches, conf_thres=0.001, iou_thres=0.6, confusion_matrix=cm)
+    mat = cm.matrix                                               # trained detector: the mass sits on the diagonal
+    diag = float(np.trace(mat[:nc, :nc]) / max(mat[:, :nc].sum(), 1.0))
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     omp, omr, om50, om = oracle_eval(state, cfg, val_batches, 0.001, 0.6)
     res = {'width': width, 'depth': depth, 'imgsz': S, 'batch': B, 'train_steps': steps, 'train_seconds': round(t_train, 1), 'loss_first': round(first, 4), 'loss_last': round(last, 4),
            'product': {'P': mp, 'R': mr, 'mAP50': m50, 'mAP50_95': m}, 'oracle': {'P': omp, 'R': omr, 'mAP50': om50, 'mAP50_95': om},
-           'abs_diff_mAP50': abs(m50 - om50), 'abs_diff_mAP50_95': abs(m - om)}
+           'abs_diff_mAP50': abs(m50 - om50), 'abs_diff_mAP50_95': abs(m - om),
+           'confusion_diagonal_share_of_labels': round(diag, 4)}
     print(json.dumps(res))
     return res
 

@@ -100,3 +100,42 @@ def test_scale_coords_matches_reference_formula():
         want[:, [1, 3]] = ((want[:, [1, 3]] - pad[1]) / gain).clamp(0, img0[0])
         got = scale_coords(img1, boxes.clone().to(DEV), img0, rp)
         np.testing.assert_allclose(got.cpu().numpy(), want.float().numpy(), rtol=1e-6, atol=1e-4)
+
+
+def test_confusion_matrix_matches_the_reference_and_the_oracle(golden):
+    """val.py:141,186: the device confusion matrix over the golden images equals the reference class's matrix exactly, image by
+    image and as one batch; plus random images (many labels / detections, empty cases) against the oracle."""
+    from oracle.somi_ref.metrics import ConfusionMatrix as OCM
+    from somi_amd.metrics import ConfusionMatrix
+    g = golden('val_metrics')
+    nc, conf, thr = int(g['confusion_nc']), float(g['confusion_conf']), float(g['confusion_iou'])
+    dets = [torch.from_numpy(g[f'det{b}']).cuda() for b in range(int(g['nimg']))]
+    labs = [torch.from_numpy(g[f'lab{b}']).cuda() for b in range(int(g['nimg']))]
+    keep = [b for b in range(len(dets)) if len(dets[b]) and len(labs[b])]
+    one = ConfusionMatrix(nc, conf, thr)
+    for b in keep:
+        one.process_batch(dets[b], labs[b])
+    assert np.array_equal(one.matrix, g['confusion'])
+    batch = ConfusionMatrix(nc, conf, thr)
+    batch.process_batches([dets[b] for b in keep], [labs[b] for b in keep])
+    assert np.array_equal(batch.matrix, g['confusion'])
+    gen = torch.Generator().manual_seed(77)
+    ocm, dcm = OCM(12), ConfusionMatrix(12)
+    dl, ll = [], []
+    for i in range(40):
+        M = int(torch.randint(0, 120, (1,), generator=gen)) if i % 7 else 0
+        N = int(torch.randint(0, 300, (1,), generator=gen)) if i % 5 else 0
+        c, wh = torch.rand(M, 2, generator=gen) * 600 + 20, torch.rand(M, 2, generator=gen) * 90 + 5
+        lab = torch.cat((torch.randint(0, 12, (M, 1), generator=gen).float(), c - wh / 2, c + wh / 2), 1)
+        if M and N:
+            pick = torch.randint(0, M, (N,), generator=gen)
+            box = lab[pick, 1:] + (torch.rand(N, 4, generator=gen) - 0.5) * wh[pick].repeat(1, 2) * torch.rand(N, 1, generator=gen) * 1.5
+            cls = torch.where(torch.rand(N, generator=gen) < 0.7, lab[pick, 0], torch.randint(0, 12, (N,), generator=gen).float())
+        else:
+            cc, cw = torch.rand(N, 2, generator=gen) * 600 + 20, torch.rand(N, 2, generator=gen) * 90 + 5
+            box, cls = torch.cat((cc - cw / 2, cc + cw / 2), 1), torch.randint(0, 12, (N,), generator=gen).float()
+        det = torch.cat((box, torch.rand(N, 1, generator=gen), cls[:, None]), 1)
+        ocm.process_batch(det, lab)
+        dl.append(det.cuda()), ll.append(lab.cuda())
+    dcm.process_batches(dl, ll)
+    assert np.array_equal(dcm.matrix, ocm.matrix) and ocm.matrix.sum() > 2000

@@ -508,6 +508,7 @@ def test_end_to_end_training_reaches_map_and_matches_oracle():
     assert res['product']['mAP50'] > 0.8, res
     assert res['abs_diff_mAP50'] <= 1e-3 and res['abs_diff_mAP50_95'] <= 1e-3, res
     assert abs(res['product']['P'] - res['oracle']['P']) <= 1e-3 and abs(res['product']['R'] - res['oracle']['R']) <= 1e-3, res
+    assert res['confusion_diagonal_share_of_labels'] > 0.8, res     # val.py:186's confusion matrix, filled on the device by V.run
 
 
 def test_bn_statistics_survive_a_large_channel_mean():

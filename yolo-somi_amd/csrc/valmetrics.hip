@@ -65,6 +65,75 @@ __global__ __launch_bounds__(256) void val_match_kernel(const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ confusion matrix
+// utils/metrics.py:98-142 for a batch of images, one workgroup per image.  Class-agnostic matching: every detection above `conf`
+// takes the label of highest IoU (> iou_thres; ties: lowest label), every label keeps the detection of highest IoU among those
+// that took it (ties: lowest detection).  LDS: labels [Mcap][5], the label each detection took [Ncap], and per label a 64-bit
+// key (IoU bits << 32 | ~detection) maximised atomically.  Counts go to the global int32 matrix [pred][true] with integer atomics.
+__global__ __launch_bounds__(256) void confusion_kernel(const float *__restrict__ det, const int *__restrict__ det_off,
+                                                        const float *__restrict__ lab, const int *__restrict__ lab_off, int Ncap, int Mcap,
+                                                        int nc, float conf, float iou_thres, int *__restrict__ matrix) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(smem);          // [Mcap]
+    float *s_lab = reinterpret_cast<float *>(s_key + Mcap);                            // [Mcap][5]
+    int *s_took = reinterpret_cast<int *>(s_lab + (size_t)Mcap * 5);                   // [Ncap]
+    __shared__ int s_any;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int d0 = det_off[b], N = det_off[b + 1] - d0, l0 = lab_off[b], M = lab_off[b + 1] - l0;
+    if (M <= 0) return;                                                               // no label: nothing is counted (:132,138)
+    const int W = nc + 1;
+    for (int i = tid; i < M * 5; i += 256) s_lab[i] = lab[(size_t)l0 * 5 + i];
+    for (int i = tid; i < M; i += 256) s_key[i] = 0ull;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    for (int d = tid; d < N; d += 256) {
+        const float *dp = det + (size_t)(d0 + d) * 6;
+        int took = -2;                                                                // -2: below the confidence threshold (dropped, :111)
+        if (dp[4] > conf) {
+            const float x1 = dp[0], y1 = dp[1], x2 = dp[2], y2 = dp[3];
+            const float area2 = __fmul_rn(x2 - x1, y2 - y1);
+            float best = -1.f;
+            took = -1;
+            for (int l = 0; l < M; ++l) {
+                const float *lp = s_lab + l * 5;
+                const float iw = fmaxf(fminf(lp[3], x2) - fmaxf(lp[1], x1), 0.f), ih = fmaxf(fminf(lp[4], y2) - fmaxf(lp[2], y1), 0.f);
+                const float inter = __fmul_rn(iw, ih);
+                const float area1 = __fmul_rn(lp[3] - lp[1], lp[4] - lp[2]);
+                const float iou = __fdiv_rn(inter, (area1 + area2) - inter);
+                if (iou > iou_thres && iou > best) { best = iou; took = l; }
+            }
+            if (took >= 0)                                                            // IoU > 0: its float bits order like the value
+                atomicMax(&s_key[took], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0x7fffffff - d));
+        }
+        s_took[d] = took;
+    }
+    __syncthreads();
+    for (int l = tid; l < M; l += 256) {
+        const int gc = (int)s_lab[l * 5];
+        if (gc < 0 || gc > nc) continue;
+        const unsigned long long key = s_key[l];
+        if (key) {
+            const int d = 0x7fffffff - (int)(unsigned)(key & 0xffffffffu);
+            const int dc = (int)det[(size_t)(d0 + d) * 6 + 5];
+            if (dc >= 0 && dc <= nc) atomicAdd(&matrix[dc * W + gc], 1);
+            s_any = 1;
+        } else {
+            atomicAdd(&matrix[nc * W + gc], 1);                                       // missed label: (background, class)
+        }
+    }
+    __syncthreads();
+    if (!s_any) return;                                                               // `if n:` (:138): no match in the image, no false positives counted
+    for (int d = tid; d < N; d += 256) {
+        const int took = s_took[d];
+        if (took == -2) continue;
+        const bool matched = took >= 0 && (0x7fffffff - (int)(unsigned)(s_key[took] & 0xffffffffu)) == d;
+        if (!matched) {
+            const int dc = (int)det[(size_t)(d0 + d) * 6 + 5];
+            if (dc >= 0 && dc <= nc) atomicAdd(&matrix[dc * W + nc], 1);             // unmatched detection: (class, background)
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ ap_per_class
 struct ApArgs {
     const uint8_t *tp;        // [N][T]
@@ -290,6 +359,19 @@ extern "C" int somi_val_match_f32(const float *det, const int *det_off, const fl
     }
     hipLaunchKernelGGL(val_match_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, det, det_off, labels, lab_off, iouv, T, ncap, mcap, correct);
     return launch_status("somi_val_match_f32");
+}
+
+extern "C" int somi_confusion_matrix_f32(const float *det, const int *det_off, const float *labels, const int *lab_off, int B, int max_det,
+                                         int max_labels, int nc, float conf, float iou_thres, int32_t *matrix, somi_stream_t stream) {
+    SOMI_REQUIRE(det_off && lab_off && matrix && B > 0 && max_det >= 0 && max_labels >= 0 && nc > 0, SOMI_EINVAL,
+                 "confusion matrix: bad arguments");
+    SOMI_REQUIRE((det || max_det == 0) && (labels || max_labels == 0), SOMI_EINVAL, "confusion matrix: null boxes");
+    const int ncap = max_det > 0 ? max_det : 1, mcap = max_labels > 0 ? max_labels : 1;
+    const size_t lds = (size_t)mcap * 8 + (size_t)mcap * 5 * 4 + (size_t)ncap * 4;
+    SOMI_REQUIRE(lds <= 60 * 1024, SOMI_ENOTIMPL, "confusion matrix: %d detections x %d labels per image do not fit LDS", max_det, max_labels);
+    hipLaunchKernelGGL(confusion_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, det, det_off, labels, lab_off, ncap, mcap, nc, conf,
+                       iou_thres, matrix);
+    return launch_status("somi_confusion_matrix_f32");
 }
 
 extern "C" size_t somi_ap_per_class_workspace_bytes(long N, int T, int ncap) {

@@ -120,6 +120,7 @@ SIGNATURES = {
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),
     'somi_yolo_loss_f32': (I, [C.POINTER(LossDesc), P, P, Z, S]),
     'somi_val_match_f32': (I, [P, P, P, P, P, I, I, I, I, P, S]),
+    'somi_confusion_matrix_f32': (I, [P, P, P, P, I, I, I, I, F, F, P, S]),
     'somi_ap_per_class_workspace_bytes': (Z, [C.c_long, I, I]),
     'somi_ap_per_class_f64': (I, [P, P, P, P, C.c_long, C.c_long, I, I, P, P, P, P, P, P, P, Z, S]),
     'somi_repulsion_workspace_bytes': (Z, [I, I]),
@@ -143,7 +144,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != 6:
+        if L.somi_abi_version() != 7:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -76,3 +76,39 @@ def ap_per_class(tp, conf, pred_cls, target_cls, ncap=None):
                                   ws.data_ptr(), nbytes, _stream()), 'ap_per_class')
     n = int(out_n.item())
     return p[:n], r[:n], ap[:n], f1[:n], out_cls[:n]
+
+
+class ConfusionMatrix:
+    """utils/metrics.py:98-142 on the device: `ConfusionMatrix(nc, conf=0.25, iou_thres=0.2)`, `.process_batch(detections, labels)`
+    per image (val.py:186), `.matrix` -> (nc+1, nc+1) float64 numpy array [predicted, true] with index nc = background.  The counts
+    stay in an int32 device tensor; reading `.matrix` is the only synchronisation.  `process_batches` takes whole batches."""
+
+    def __init__(self, nc, conf=0.25, iou_thres=0.2, device='cuda:0'):
+        self.nc, self.conf, self.iou_thres = int(nc), float(conf), float(iou_thres)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('somi_amd.metrics runs on GPU tensors only (no CPU fallback)')
+        self.counts = torch.zeros((self.nc + 1, self.nc + 1), dtype=torch.int32, device=self.device)
+
+    def process_batches(self, detections, labels):
+        if len(detections) != len(labels):
+            raise RuntimeError('ConfusionMatrix: one label tensor per detection tensor')
+        if not detections:
+            return
+        dev = self.device
+        nd, nl = [int(d.shape[0]) for d in detections], [int(l.shape[0]) for l in labels]
+        det = torch.cat([d.reshape(-1, 6) for d in detections]).float().contiguous().to(dev) if sum(nd) else torch.zeros(0, 6, device=dev)
+        lab = torch.cat([l.reshape(-1, 5) for l in labels]).float().contiguous().to(dev) if sum(nl) else torch.zeros(0, 5, device=dev)
+        doff = torch.tensor([0] + nd, dtype=torch.int32).cumsum(0).to(torch.int32).to(dev)
+        loff = torch.tensor([0] + nl, dtype=torch.int32).cumsum(0).to(torch.int32).to(dev)
+        with torch.cuda.device(dev):
+            check(_lib.lib().somi_confusion_matrix_f32(det.data_ptr(), doff.data_ptr(), lab.data_ptr(), loff.data_ptr(), len(nd),
+                                                       max(nd), max(nl), self.nc, self.conf, self.iou_thres, self.counts.data_ptr(),
+                                                       _stream()), 'somi_confusion_matrix_f32')
+
+    def process_batch(self, detections, labels):
+        self.process_batches([detections], [labels])
+
+    @property
+    def matrix(self):
+        return self.counts.cpu().numpy().astype('float64')

@@ -43,8 +43,9 @@ def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
 
 
 @torch.no_grad()
-def run(model, batches, conf_thres=0.001, iou_thres=0.6, single_cls=False, device=None):
-    """-> (mp, mr, map50, map, dict(p, r, ap50, ap, ap_class, seen, nt)); val.py:148-212 with plots / saving off."""
+def run(model, batches, conf_thres=0.001, iou_thres=0.6, single_cls=False, device=None, confusion_matrix=None):
+    """-> (mp, mr, map50, map, dict(p, r, ap50, ap, ap_class, seen, nt)); val.py:148-212 with plots / saving off.
+    confusion_matrix: a `somi_amd.metrics.ConfusionMatrix` to fill as val.py:141,186 does when `plots` is on."""
     device = device or next(model.parameters()).device
     if device.type != 'cuda':
         raise RuntimeError('somi_amd.val runs on the MI355X only (no CPU fallback)')
@@ -76,6 +77,9 @@ def run(model, batches, conf_thres=0.001, iou_thres=0.6, single_cls=False, devic
             tclss.append(labels[:, 0])
         seen += nb
         corrects = process_batches(predn, labs, iouv)             # the whole batch in one launch (val.py:184 per image)
+        if confusion_matrix is not None:                          # val.py:185-186 (`if plots:`), only images with labels AND predictions
+            both = [i for i in range(nb) if len(predn[i]) and len(labs[i])]
+            confusion_matrix.process_batches([predn[i] for i in both], [labs[i] for i in both])
         for pred, correct in zip(out, corrects):
             tps.append(correct)
             confs.append(pred[:, 4])
