@@ -132,8 +132,7 @@ def test_unbuilt_options_raise():
     from somi_amd.augment import DeviceImageCache
     im = [np.zeros((8, 8, 3), np.uint8)]
     lab = [np.zeros((0, 5), np.float32)]
-    with pytest.raises(NotImplementedError):
-        DeviceImageCache(im, lab, 8, dict(HYP_AUGMENT, copy_paste=0.5), device='cpu')
+    DeviceImageCache(im, lab, 8, dict(HYP_AUGMENT, copy_paste=0.5), device='cpu')      # box labels only: copy_paste has nothing to paste
     with pytest.raises(NotImplementedError):
         DeviceImageCache(im, lab, 8, dict(HYP_AUGMENT, perspective=0.001), device='cpu')
     with pytest.raises(ValueError):

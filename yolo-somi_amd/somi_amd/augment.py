@@ -14,8 +14,8 @@ Random numbers are drawn from the module-level `random` / `np.random` generators
 centre y then x, three extra indices, shuffle, perspective x2, angle, scale, shear x2, translate x2, mixup?, partner index,
 second mosaic, beta, hsv gains, flipud?, fliplr?), so seeding them reproduces the reference's samples.
 
-`copy_paste` (hyp 0.0) and Albumentations (package absent -> no transform) do nothing in the reference's configuration
-and draw no random numbers; a non-zero `copy_paste` or `perspective` raises.
+`copy_paste` acts on segment labels only (box datasets have none: a no-op at any value) and Albumentations has no transform
+when the package is absent; neither draws a random number.  A non-zero `perspective` raises (0.0 in all the reference's files).
 """
 import ctypes as C
 import math
@@ -123,8 +123,10 @@ class DeviceImageCache:
         if len(imgs) != len(labels) or not imgs:
             raise ValueError('need one label array per image')
         self.hyp = dict(HYP_VISDRONE_AUGMENT if hyp is None else hyp)
-        if self.hyp.get('copy_paste', 0.0) or self.hyp.get('perspective', 0.0):
-            raise NotImplementedError('copy_paste / perspective are 0.0 in the reference configuration; not built')
+        if self.hyp.get('perspective', 0.0):
+            raise NotImplementedError('perspective is 0.0 in every hyper-parameter file of the reference; warpPerspective is not built')
+        # copy_paste needs segment labels (utils/augmentations.py:247 `if paste_prob and n` with n = len(segments)): box-only
+        # datasets have none, so any value is a no-op there - and draws no random number - exactly as in the reference
         self.img_size, self.augment, self.rect = int(img_size), bool(augment), bool(rect)
         self.mosaic = self.augment and not self.rect
         self.mosaic_border = [-self.img_size // 2, -self.img_size // 2]
