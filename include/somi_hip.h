@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 7
+#define SOMI_ABI_VERSION 8
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -364,12 +364,13 @@ int somi_pack_dgrad_weights_f32(const float *w_packed, float *w_dgrad, int Cout,
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.
  * Selection is bit-exact with the oracle: candidates in prediction order (row-major over (box, class) for
  * multi_label), stable sort by descending score, greedy suppression with IoU > iou_thres, class offset 4096.
- * classes_mask: bit c set = keep class c (0xFFFFFFFF.. = no filter).
+ * classes_mask: HOST pointer to ceil(nc/64) 64-bit words, bit (c % 64) of word c/64 set = keep class c (the `classes` argument,
+ * general.py:676-677); NULL = no filter.  nc <= 1024.
  * workspace bytes: somi_nms_workspace_bytes(B, n, nc, multi_label).
  */
 size_t somi_nms_workspace_bytes(int B, int n, int nc, int multi_label);
 int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_thres, float iou_thres, int multi_label,
-                 int agnostic, uint64_t classes_mask, int max_det, float *det, int32_t *count, void *workspace,
+                 int agnostic, const uint64_t *classes_mask, int max_det, float *det, int32_t *count, void *workspace,
                  size_t workspace_bytes, somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -50,6 +50,31 @@ def test_nms_matches_oracle_random(n, nc, conf, iou, ml):
         assert torch.equal(got[b].cpu(), want[b])
 
 
+@pytest.mark.parametrize('kw', [dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),       # val.sh benchmark setting on a COCO head
+                                dict(conf_thres=0.25, iou_thres=0.45),
+                                dict(conf_thres=0.05, iou_thres=0.5, multi_label=True, classes=[0, 17, 63, 64, 79]),
+                                dict(conf_thres=0.1, iou_thres=0.45, classes=[70]),
+                                dict(conf_thres=0.2, iou_thres=0.5, agnostic=True)])
+def test_nms_80_class_head(kw):
+    """nc = 80 (coco128, BASELINE target): the class filter is a bit array, not one 64-bit word."""
+    from oracle.somi_ref.nms import non_max_suppression as oracle
+    from somi_amd.nms import non_max_suppression
+    g = torch.Generator().manual_seed(80)
+    B, n, nc = 2, 3000, 80
+    pred = torch.rand(B, n, 5 + nc, generator=g)
+    pred[..., :2] *= 640
+    pred[..., 2:4] = pred[..., 2:4] * 150 + 4
+    pred[..., 4] = pred[..., 4] ** 2
+    pred[..., 5:] = pred[..., 5:] ** 6                       # a few confident classes per box, most below the threshold
+    pred[0, 50:90, :4] = pred[0, 50, :4] + torch.rand(40, 4, generator=g)
+    want = oracle(pred.clone(), **kw)
+    got = non_max_suppression(pred.cuda(), **kw)
+    for b in range(B):
+        assert got[b].shape == want[b].shape, (b, got[b].shape, want[b].shape)
+        assert torch.equal(got[b].cpu(), want[b])
+    assert sum(int(w.shape[0]) for w in want) > 0
+
+
 def test_nms_argument_errors():
     from somi_amd.nms import non_max_suppression
     p = torch.zeros(1, 10, 15, device='cuda')

@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
-"""Rehearsal of the data-parallel training step with N ranks sharing ONE GPU (gloo moves the buckets through the host): checks that
-the bucketed, stream-overlapped gradient exchange of somi_amd.ddp.GradBuckets gives exactly the sum of the per-rank gradients and
-that every rank ends a step with identical weights.  Launch:
+"""Rehearsal of the data-parallel training step with N ranks sharing ONE GPU (gloo moves the buckets through the host).
+
+Checks, against torch DDP's semantics restated with plain collectives (train.py:208-209,266-267: the loss is multiplied by
+WORLD_SIZE and DDP MEANs the gradients, so every rank steps on sum_r dL_r/dw):
+  1. the bucketed, stream-overlapped exchange of somi_amd.ddp.GradBuckets leaves exactly  mean_r( d(WORLD_SIZE * L_r)/dw )  in
+     every rank's gradient buffers;
+  2. gradient accumulation over 2 micro-batches exchanges once and gives the sum of both micro-batches over all ranks;
+  3. rank 0, alone, stepping on every rank's shard in turn (accumulate = world, no collectives) reaches the same gradients and
+     the same weights after the optimizer step as the N-rank step did;
+  4. every rank ends with bit-identical weights, and the BatchNorm running statistics start from rank 0's.
+Launch:
   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/ddp_rehearsal.py
 (the real multi-GPU run uses backend nccl = RCCL, one GPU per rank: bench.py --gpus N)."""
 import copy
@@ -20,61 +28,117 @@ from somi_amd.model import Model  # noqa: E402
 from somi_amd.train import TrainStep  # noqa: E402
 
 
+def ddp_expected(shadow, batches, world):
+    """What torch DDP leaves in .grad after the micro-batches `batches` (train.py:264-270): per micro-batch the local gradient of
+    loss * WORLD_SIZE is added to .grad and the buffers are all-reduced with MEAN."""
+    for p in shadow.parameters():
+        p.grad = None
+    crit = ComputeLoss(shadow)
+    for imgs, targets in batches:
+        loss, _ = crit(shadow(imgs), targets)
+        (loss * world).backward()
+        for p in shadow.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+            p.grad /= world
+    return [p.grad.detach().clone() for p in shadow.parameters()]
+
+
+def worst_error(model, want):
+    worst = 0.0
+    for p, g in zip(model.parameters(), want):
+        worst = max(worst, (p.grad - g).abs().max().item() / (g.abs().max().item() * 2e-5 + 1e-7))
+    return worst
+
+
 def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo')
     dev = torch.device('cuda:0')
     cfg = somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS)
-    model = fill_state(Model(cfg), 1 + rank).to(dev)             # different weights per rank: the broadcast must fix that
-    shadow = copy.deepcopy(model)                                # plain per-rank replica for the reference gradients
+    model = fill_state(Model(cfg), 1 + rank).to(dev)             # different weights AND statistics per rank: the broadcast must fix that
     tr = TrainStep(model, dict(HYP_VISDRONE), 2, dist=dist, bucket_mb=1)     # 1 MB buckets: several per buffer at this size
-    with torch.no_grad():                                        # the replica takes the broadcast weights too
-        for p, q in zip(shadow.parameters(), model.parameters()):
-            p.copy_(q)
-        for p, q in zip(shadow.buffers(), model.buffers()):
-            p.copy_(q)
+    for buf in (*tr.optimizer.flat_params, tr.optimizer.flat_buffers):       # 4. one set of weights and BN statistics after init
+        ref = buf.detach().clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(buf, ref), f'rank {rank}: initial state differs from rank 0'
+    start = copy.deepcopy(model.state_dict())
+    shadow = Model(cfg).to(dev)                                  # plain per-rank replica for the expected gradients
+    shadow.load_state_dict(start)
     shadow.train()
     shadow.hyp = dict(HYP_VISDRONE)
-    imgs, targets = synthetic_batch(2, 64, seed=10 + rank)
-    imgs, targets = imgs.to(dev), targets.to(dev)
+    shards = [[t.to(dev) for t in synthetic_batch(2, 64, seed=10 + r)] for r in range(world)]
+    extra = [[t.to(dev) for t in synthetic_batch(2, 64, seed=50 + r)] for r in range(world)]
+    imgs, targets = shards[rank]
 
-    # reference: local gradients of this rank's shard, summed over ranks with one blocking all-reduce per parameter
-    loss_s, _ = ComputeLoss(shadow)(shadow(imgs), targets)
-    (loss_s * world).backward()
-    want = []
-    for p in shadow.parameters():
-        g = p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        want.append(g)
-
-    # product path, stopped before the optimizer: forward, loss, reverse walk with bucketed exchange
+    # 1. one micro-batch, stopped before the optimizer: forward, loss, reverse walk with the bucketed exchange
+    want = ddp_expected(shadow, [shards[rank]], world)
     tr.buckets.reset()
     loss, _ = tr.compute_loss(model(imgs), targets)
-    (loss * world).backward()
+    loss.backward()
     tr.buckets.finish()
     torch.cuda.synchronize()
-    worst = 0.0
-    for (n, p), g in zip(model.named_parameters(), want):
-        err = (p.grad - g).abs().max().item()
-        worst = max(worst, err / (g.abs().max().item() * 1e-5 + 1e-7))
+    w1 = worst_error(model, want)
     nb = len(tr.buckets.launched)
-    assert worst <= 1.0, f'rank {rank}: bucketed gradients differ from the per-parameter all-reduce ({worst:.1f} x tolerance)'
+    assert w1 <= 1.0, f'rank {rank}: bucketed gradients differ from DDP semantics ({w1:.1f} x tolerance)'
     assert nb > len(tr.optimizer.flat_grads), f'expected several buckets, got {nb}'
     tr.optimizer.zero_grad()
 
-    # two full steps: identical weights on every rank afterwards
-    for _ in range(2):
-        loss, items = tr.step(imgs, targets)
+    # 2. accumulation over two micro-batches (running statistics restored first: step 1 advanced them)
+    model.load_state_dict(start), shadow.load_state_dict(start)
+    want2 = ddp_expected(shadow, [shards[rank], extra[rank]], world)
+    tr.accumulate, tr._since_step = 2, 0
+    hold = tr.optimizer.step
+    tr.optimizer.step = lambda: None                             # keep the gradients for the comparison
+    zg = tr.optimizer.zero_grad
+    tr.optimizer.zero_grad = lambda *a, **k: None
+    tr.step(*shards[rank])
+    assert tr.buckets.launched == [], 'a non-stepping micro-batch must not exchange'
+    tr.step(*extra[rank])
     torch.cuda.synchronize()
-    for buf in tr.optimizer.flat_params:
-        mine = buf.detach().clone()
-        ref = mine.clone()
+    w2 = worst_error(model, want2)
+    assert w2 <= 1.0, f'rank {rank}: accumulate=2 gradients differ from DDP semantics ({w2:.1f} x tolerance)'
+    tr.optimizer.step, tr.optimizer.zero_grad = hold, zg
+    tr.optimizer.zero_grad()
+    tr.accumulate, tr._since_step = 1, 0
+
+    # 3. one full N-rank step from the common start, against rank 0 alone accumulating every shard
+    model.load_state_dict(start)
+    tr.optimizer.reset_ema()
+    loss, items = tr.step(imgs, targets)
+    torch.cuda.synchronize()
+    after = [b.detach().clone() for b in tr.optimizer.flat_params]
+    w3 = 0.0
+    if rank == 0:
+        solo = Model(cfg).to(dev)
+        solo.load_state_dict(start)
+        st = TrainStep(solo, dict(HYP_VISDRONE), 2, dist=None, accumulate=world)
+        grads = None
+        for i, (im, tg) in enumerate(shards):
+            if i == world - 1:                                   # capture the accumulated gradients right before the step
+                real = st.optimizer.step
+                def spy():                                       # noqa: E306
+                    nonlocal grads
+                    grads = [g.detach().clone() for g in st.optimizer.flat_grads]
+                    real()
+                st.optimizer.step = spy
+            st.step(im, tg)
+        torch.cuda.synchronize()
+        for a, b in zip(after, st.optimizer.flat_params):
+            d = (a - b).abs()
+            w3 = max(w3, torch.quantile(d[:: max(1, d.numel() // 1_000_000)].float(), 0.999).item() / (3e-4 * 1e-2))
+        assert w3 <= 1.0, f'weights after one {world}-rank step differ from the single-process run on all shards ({w3:.1f} x tolerance)'
+        assert grads is not None
+    for buf in tr.optimizer.flat_params:                          # 4.
+        ref = buf.detach().clone()
         dist.broadcast(ref, src=0)
-        assert torch.equal(mine, ref), f'rank {rank}: weights diverged from rank 0'
+        assert torch.equal(buf, ref), f'rank {rank}: weights diverged from rank 0'
     assert torch.isfinite(loss).all()
     dist.barrier()
     if rank == 0:
-        print(f'ddp rehearsal ok: world {world}, {nb} buckets, gradient error {worst:.2f} x tolerance, loss {float(loss):.4f}')
+        print(f'ddp rehearsal ok: world {world}, {nb} buckets, gradient error {w1:.2f} / accumulate-2 {w2:.2f} x tolerance, '
+              f'weights vs single process {w3:.2f} x tolerance, loss {float(loss):.4f}')
     dist.destroy_process_group()
 
 

@@ -21,13 +21,14 @@ constexpr int MAX_NMS = 30000;       // utils/general.py:641
 constexpr float MAX_WH = 4096.f;     // utils/general.py:640
 constexpr int ROUND = 512;           // candidates per greedy round
 constexpr int MAX_DET_CAP = 1024;
+constexpr int NMS_MASK_WORDS = 16;   // class filter bit array: nc <= 1024
 
 struct NmsArgs {
     const float *pred;
     int B, n, nc, no;
     float conf_thres, iou_thres;
     int multi_label, agnostic, max_det;
-    uint64_t classes_mask;
+    uint64_t classes_mask[NMS_MASK_WORDS];   // bit c of word c/64 set = keep class c
     int nchunk, cap;                 // cap = candidate capacity per image
     int *chunk_cnt;                  // [B][nchunk]
     int *chunk_off;                  // [B][nchunk]
@@ -37,7 +38,7 @@ struct NmsArgs {
     int32_t *count;                  // [B]
 };
 
-__device__ __forceinline__ bool class_ok(uint64_t mask, int c) { return c >= 64 || ((mask >> c) & 1ull); }
+__device__ __forceinline__ bool class_ok(const uint64_t *mask, int c) { return (mask[c >> 6] >> (c & 63)) & 1ull; }
 
 // number of entries row r contributes; optionally writes them (keys/vals) starting at dst
 template <bool EMIT>
@@ -499,10 +500,10 @@ extern "C" size_t somi_nms_workspace_bytes(int B, int n, int nc, int multi_label
 }
 
 extern "C" int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_thres, float iou_thres, int multi_label,
-                            int agnostic, uint64_t classes_mask, int max_det, float *det, int32_t *count, void *workspace,
+                            int agnostic, const uint64_t *classes_mask, int max_det, float *det, int32_t *count, void *workspace,
                             size_t workspace_bytes, somi_stream_t stream) {
     SOMI_REQUIRE(pred && det && count && workspace, SOMI_EINVAL, "nms: null tensor");
-    SOMI_REQUIRE(B > 0 && n > 0 && nc > 0 && nc <= 64, SOMI_EINVAL, "nms: bad sizes (nc <= 64)");
+    SOMI_REQUIRE(B > 0 && n > 0 && nc > 0 && nc <= 64 * NMS_MASK_WORDS, SOMI_EINVAL, "nms: bad sizes (nc <= %d)", 64 * NMS_MASK_WORDS);
     SOMI_REQUIRE(conf_thres >= 0.f && conf_thres <= 1.f, SOMI_EINVAL,
                  "Invalid Confidence threshold %g, valid values are between 0.0 and 1.0", conf_thres);   // general.py:635
     SOMI_REQUIRE(iou_thres >= 0.f && iou_thres <= 1.f, SOMI_EINVAL, "Invalid IoU %g, valid values are between 0.0 and 1.0",
@@ -514,7 +515,9 @@ extern "C" int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_
     NmsArgs a;
     a.pred = pred; a.B = B; a.n = n; a.nc = nc; a.no = nc + 5;
     a.conf_thres = conf_thres; a.iou_thres = iou_thres; a.multi_label = multi_label; a.agnostic = agnostic;
-    a.max_det = max_det; a.classes_mask = classes_mask;
+    a.max_det = max_det;
+    for (int i = 0; i < NMS_MASK_WORDS; ++i)                     // host words, NULL = keep every class (general.py:676-677)
+        a.classes_mask[i] = classes_mask ? (i < (nc + 63) / 64 ? classes_mask[i] : 0ull) : ~0ull;
     a.nchunk = (n + NMS_CHUNK - 1) / NMS_CHUNK;
     a.cap = n * (multi_label ? nc : 1);
     char *w = static_cast<char *>(workspace);

@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')
 
+ABI_VERSION = 8          # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
 
@@ -116,7 +117,7 @@ SIGNATURES = {
     'somi_pack_dgrad_weights_f32': (I, [P, P, I, I, I, S]),
     'somi_axpby_f32': (I, [P, P, C.c_long, F, F, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),
-    'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, U64, I, P, P, P, Z, S]),
+    'somi_nms_f32': (I, [P, I, I, I, F, F, I, I, P, I, P, P, P, Z, S]),
     'somi_loss_workspace_bytes': (Z, [C.POINTER(LossDesc)]),
     'somi_yolo_loss_f32': (I, [C.POINTER(LossDesc), P, P, Z, S]),
     'somi_val_match_f32': (I, [P, P, P, P, P, I, I, I, I, P, S]),
@@ -144,7 +145,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != 7:
+        if L.somi_abi_version() != ABI_VERSION:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib

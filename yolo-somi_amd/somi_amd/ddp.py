@@ -2,7 +2,8 @@
 torch.distributed (backend "nccl" on ROCm), the reference's DDP semantics without the DDP wrapper.
 
 Reference (train.py:208-209,266-267): DDP averages gradients over ranks and the loss is multiplied by WORLD_SIZE, i.e. every
-rank ends up with the SUM of the per-rank gradients.  Here the gradients already live in the optimizer's flat per-group buffers
+rank ends up with the SUM over ranks of the gradients of the UNSCALED per-rank losses.  The caller (train.TrainStep) therefore
+back-propagates the unscaled loss and this module SUMs.  Here the gradients already live in the optimizer's flat per-group buffers
 (optim.FusedAdamEMA.flat_grads); they are all-reduced (SUM) in buckets cut from the END of each buffer, because the reverse
 layer walk finalises gradients from the last layer to the first.  A bucket is launched on a side HIP stream as soon as every
 layer that owns a slice of it has finished its backward, so the exchange overlaps the rest of the backward pass; the optimizer
@@ -40,6 +41,7 @@ class GradBuckets:
         self.layer_off = layer_start_offsets
         self.next = [0] * len(flat_grads)                        # next bucket to launch per buffer
         self.launched = []                                       # (buffer index, start, end) in launch order - for tests
+        self.enabled = True                                      # False: layer_done() is a no-op (a non-stepping micro-batch)
 
     def reset(self):
         self.next = [0] * len(self.flat)
@@ -61,6 +63,8 @@ class GradBuckets:
 
     def layer_done(self, layer_index):
         """Call after layer `layer_index` (and every later layer) has accumulated its parameter gradients."""
+        if not self.enabled:
+            return
         for bi, cuts in enumerate(self.buckets):
             final_from = self.layer_off[bi].get(layer_index)
             if final_from is None:

@@ -229,7 +229,10 @@ class Model(nn.Module):
                 a = m(a)
                 y.append(a if m.i in self.save else None)
         if self.training:
-            return list(_ModelGraph.apply(self._anchor(x.device), self, *a))
+            # the blocks keep what backward needs on themselves (one set): a later train-mode forward overwrites it, so the
+            # graph node remembers which forward it belongs to and refuses a stale backward instead of using wrong activations
+            gen = self.__dict__['_fwd_gen'] = self.__dict__.get('_fwd_gen', 0) + 1
+            return list(_ModelGraph.apply(self._anchor(x.device), self, gen, *a))
         return a
 
     def _anchor(self, dev):
@@ -244,11 +247,14 @@ class _ModelGraph(torch.autograd.Function):
     outputs, its backward hands their gradients to Model._backward_walk, which fills the parameters' .grad."""
 
     @staticmethod
-    def forward(ctx, anchor, model, *raws):
-        ctx.model = model
+    def forward(ctx, anchor, model, gen, *raws):
+        ctx.model, ctx.gen = model, gen
         return tuple(r.view_as(r) for r in raws)
 
     @staticmethod
     def backward(ctx, *draws):
+        if ctx.model.__dict__.get('_fwd_gen') != ctx.gen:
+            raise RuntimeError('backward of a stale forward: the model ran another train-mode forward since (saved activations are '
+                               'kept once per block); call backward before the next forward')
         ctx.model._backward_walk([d.contiguous() for d in draws])
-        return (None, None) + (None,) * len(draws)
+        return (None, None, None) + (None,) * len(draws)

@@ -24,11 +24,14 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     B, n, no = prediction.shape
     nc = no - 5
     ml = bool(multi_label) and nc > 1
-    mask = 0xFFFFFFFFFFFFFFFF
+    mask = None                                                  # NULL: keep every class
     if classes is not None:
-        mask = 0
+        import ctypes
+        words = [0] * ((nc + 63) // 64)
         for c in classes:
-            mask |= 1 << int(c)
+            if 0 <= int(c) < nc:
+                words[int(c) >> 6] |= 1 << (int(c) & 63)
+        mask = (ctypes.c_uint64 * len(words))(*words)
     L = _lib.lib()
     nbytes = L.somi_nms_workspace_bytes(B, n, nc, int(ml))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=prediction.device)

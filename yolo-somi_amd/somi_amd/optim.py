@@ -125,6 +125,11 @@ class FusedAdamEMA:
         """The flat parameter buffers (one per group)."""
         return [st['p'].data for st in self._flat]
 
+    @property
+    def flat_buffers(self):
+        """The flat buffer of the model's float buffers (BatchNorm running statistics)."""
+        return self._bflat.data[:self._bflat.n_pad]
+
     def reset_ema(self):
         """Restart the EMA shadow from the current weights (after the initial weights were broadcast)."""
         for st in self._flat:

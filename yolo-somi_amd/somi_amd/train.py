@@ -3,10 +3,17 @@
     pred = model(imgs); loss, items = compute_loss(pred, targets); loss *= WORLD_SIZE; loss.backward()
     optimizer.step(); optimizer.zero_grad(); ema.update(model)
 
+Gradient scale with N ranks.  The reference multiplies the loss by WORLD_SIZE (train.py:266-267) only to undo the MEAN that DDP's
+all-reduce applies, so every rank steps on  sum_r dL_r/dw  (L_r = the unscaled loss of rank r's shard).  Here the exchange is a SUM
+all-reduce, so the backward pass runs on the UNSCALED loss and the sum over ranks is exactly that gradient; only the returned
+(logged) loss carries the WORLD_SIZE factor, as the reference's does.
+
 Everything arithmetic runs in libsomi_hip.so: forward in training mode (batch-norm statistics), the fused loss (value + gradient),
 the hand-written reverse walk (conv dgrad / wgrad on MFMA, BN / attention / ODConv backward), the fused Adam + EMA update.
 With more than one rank the flat gradient buffers are all-reduced (SUM) in buckets on a side stream while the backward walk is
-still running (ddp.GradBuckets) - DDP's semantics without the wrapper.  fp32 throughout (no GradScaler: nothing to scale).
+still running (ddp.GradBuckets) - DDP's semantics without the wrapper.  With gradient accumulation the exchange happens once, on
+the micro-batch that steps the optimizer (the sum is linear, so this equals DDP re-averaging its already-averaged buffers on every
+micro-batch, and moves 1/accumulate of the bytes).  fp32 throughout (no GradScaler: nothing to scale).
 """
 from .ddp import GradBuckets, SINGLE_RANK_REHEARSAL, layer_offsets
 from .loss import ComputeLoss
@@ -59,23 +66,28 @@ class TrainStep:
             model.__dict__['_grad_hook'] = self.buckets.layer_done
             for buf in self.optimizer.flat_params:                # one set of initial weights (DDP broadcasts from rank 0)
                 dist.broadcast(buf, src=0)
+            # ... and of initial buffers (BatchNorm running statistics): DDP's broadcast_buffers (train.py:208) keeps them equal to
+            # rank 0's before every forward; here they are made equal once and then stay rank-local (batch statistics of the
+            # rank's own shard) - rank 0's are the ones the EMA / checkpoints / validation use, as in the reference
+            if self.optimizer.flat_buffers.numel():
+                dist.broadcast(self.optimizer.flat_buffers, src=0)
             self.optimizer.reset_ema()
             model.invalidate()
 
     def step(self, imgs, targets):
         """imgs: (B,3,H,W) uint8 on the GPU; targets (nt,6).  Returns (loss, loss_items) like train.py:265."""
+        stepping = self._since_step + 1 >= self.accumulate        # this micro-batch ends with optimizer.step()
         if self.buckets:
             self.buckets.reset()
+            self.buckets.enabled = stepping                       # local accumulation only on the others (DDP's no_sync)
         pred = self.model(imgs)
         loss, items = self.compute_loss(pred, targets)
-        if self.world > 1:
-            loss = loss * self.world                              # train.py:266-267
-        loss.backward()
-        if self.buckets:
+        loss.backward()                                           # unscaled: the SUM all-reduce supplies the WORLD_SIZE factor
+        if self.buckets and stepping:
             self.buckets.finish()
         self._since_step += 1
-        if self._since_step >= self.accumulate:
+        if stepping:
             self.optimizer.step()                                 # Adam + EMA, one pass
             self.optimizer.zero_grad()
             self._since_step = 0
-        return loss.detach(), items
+        return loss.detach() * self.world, items                  # the reported loss is scaled like train.py:266-267
