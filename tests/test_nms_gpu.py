@@ -29,7 +29,8 @@ def test_nms_matches_reference_vectors(golden, tag):
 @pytest.mark.parametrize('n,nc,conf,iou,ml', [(20000, 10, 0.001, 0.6, True),      # > 30000 candidates -> max_nms cap
                                               (5000, 3, 0.25, 0.45, False),
                                               (1500, 10, 0.1, 0.3, True),
-                                              (700, 1, 0.1, 0.5, True)])           # nc == 1 switches multi_label off
+                                              (700, 1, 0.1, 0.5, True),            # nc == 1 switches multi_label off
+                                              (900, 150, 0.3, 0.5, True)])         # head too wide for the LDS row staging
 def test_nms_matches_oracle_random(n, nc, conf, iou, ml):
     from oracle.somi_ref.nms import non_max_suppression as oracle
     from somi_amd.nms import non_max_suppression

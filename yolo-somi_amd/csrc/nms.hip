@@ -97,30 +97,37 @@ __device__ __forceinline__ int block_exscan_256(int v, int *tot, int *lds /* >= 
 // times: PMC showed 9.1 GB fetched for 0.26 GB of predictions); emitted (key, val) pairs are compacted in LDS and leave
 // as contiguous stores.
 constexpr int EMIT_STAGE = 4096;     // (key,val) pairs staged per chunk before falling back to direct stores
-template <bool EMIT>
+__global__ void nms_scan_kernel(const NmsArgs a);
+
+// RPT = rows per thread (chunk = 256 * RPT rows); STAGE = false reads the rows straight from HBM (heads too wide for the LDS
+// staging: nc > 110) and keeps only the emit staging in LDS.
+template <bool EMIT, int RPT, bool STAGE>
 __global__ __launch_bounds__(256) void nms_count_emit_kernel(const NmsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];     // [NMS_CHUNK][no], then the emit staging
+    extern __shared__ __attribute__((aligned(16))) float rows[];     // [256 * RPT][no] (STAGE), then the emit staging
     __shared__ int lds[4];
+    constexpr int CHUNK = 256 * RPT;
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int rbase = chunk * NMS_CHUNK;
-    const int nrow = min(NMS_CHUNK, a.n - rbase);
+    const int rbase = chunk * CHUNK;
+    const int nrow = min(CHUNK, a.n - rbase);
     const float *src = a.pred + ((size_t)b * a.n + rbase) * a.no;
-    const int nfl = nrow * a.no;
-    if (((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) {
-        for (int i = threadIdx.x * 4; i + 3 < nfl; i += 1024)
-            *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
-        for (int i = (nfl & ~3) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
-    } else {
-        for (int i = threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+    if (STAGE) {
+        const int nfl = nrow * a.no;
+        if (((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) {
+            for (int i = threadIdx.x * 4; i + 3 < nfl; i += 1024)
+                *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
+            for (int i = (nfl & ~3) + threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+        } else {
+            for (int i = threadIdx.x; i < nfl; i += 256) rows[i] = src[i];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    constexpr int RPT = NMS_CHUNK / 256;
+    const float *rsrc = STAGE ? rows : src;
     const int rl0 = threadIdx.x * RPT;
     int cnt[RPT], mine = 0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int rl = rl0 + i;
-        cnt[i] = rl < nrow ? row_entries<false>(a, rows + rl * a.no, rbase + rl, nullptr, nullptr, 0) : 0;
+        cnt[i] = rl < nrow ? row_entries<false>(a, rsrc + (size_t)rl * a.no, rbase + rl, nullptr, nullptr, 0) : 0;
         mine += cnt[i];
     }
     int tot;
@@ -132,12 +139,12 @@ __global__ __launch_bounds__(256) void nms_count_emit_kernel(const NmsArgs a) {
     const int gbase = a.chunk_off[b * a.nchunk + chunk];
     uint32_t *keys = a.keyA + (size_t)b * a.cap, *vals = a.valA + (size_t)b * a.cap;
     if (tot <= EMIT_STAGE) {
-        uint32_t *skey = reinterpret_cast<uint32_t *>(rows + NMS_CHUNK * a.no), *sval = skey + EMIT_STAGE;
+        uint32_t *skey = reinterpret_cast<uint32_t *>(rows + (STAGE ? CHUNK * a.no : 0)), *sval = skey + EMIT_STAGE;
         int dst = pre;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int rl = rl0 + i;
-            if (cnt[i]) row_entries<true>(a, rows + rl * a.no, rbase + rl, skey, sval, dst);
+            if (cnt[i]) row_entries<true>(a, rsrc + (size_t)rl * a.no, rbase + rl, skey, sval, dst);
             dst += cnt[i];
         }
         __syncthreads();
@@ -150,10 +157,28 @@ __global__ __launch_bounds__(256) void nms_count_emit_kernel(const NmsArgs a) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int rl = rl0 + i;
-            if (cnt[i]) row_entries<true>(a, rows + rl * a.no, rbase + rl, keys, vals, dst);
+            if (cnt[i]) row_entries<true>(a, rsrc + (size_t)rl * a.no, rbase + rl, keys, vals, dst);
             dst += cnt[i];
         }
     }
+}
+
+// rows per count/emit workgroup for a head of nc classes: the largest of 512 / 256 whose LDS image (+ emit staging) fits
+static int nms_chunk_rows(int nc) { return ((size_t)NMS_CHUNK * (nc + 5) * 4 + (size_t)EMIT_STAGE * 8 <= 150 * 1024) ? NMS_CHUNK : 256; }
+static bool nms_rows_staged(int nc) { return (size_t)nms_chunk_rows(nc) * (nc + 5) * 4 + (size_t)EMIT_STAGE * 8 <= 150 * 1024; }
+
+template <int RPT, bool STAGE>
+static void launch_count_emit(const NmsArgs &a, hipStream_t s) {
+    const size_t rows_lds = STAGE ? (size_t)256 * RPT * a.no * 4 : 0, emit_lds = rows_lds + (size_t)EMIT_STAGE * 8;
+    if (emit_lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_count_emit_kernel<false, RPT, STAGE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_count_emit_kernel<true, RPT, STAGE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds);
+    }
+    hipLaunchKernelGGL((nms_count_emit_kernel<false, RPT, STAGE>), dim3(a.nchunk, a.B), dim3(256), rows_lds, s, a);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((nms_count_emit_kernel<true, RPT, STAGE>), dim3(a.nchunk, a.B), dim3(256), emit_lds, s, a);
 }
 
 __global__ __launch_bounds__(256) void nms_scan_kernel(const NmsArgs a) {
@@ -491,7 +516,7 @@ using namespace somi;
 
 extern "C" size_t somi_nms_workspace_bytes(int B, int n, int nc, int multi_label) {
     if (B <= 0 || n <= 0 || nc <= 0) return 0;
-    const size_t nchunk = (size_t)(n + NMS_CHUNK - 1) / NMS_CHUNK;
+    const size_t nchunk = (size_t)(n + nms_chunk_rows(nc) - 1) / nms_chunk_rows(nc);
     const size_t cap = (size_t)n * (size_t)((multi_label && nc > 1) ? nc : 1);
     const size_t nsel_chunk = (cap + SEL_CHUNK - 1) / SEL_CHUNK;
     return align_up((size_t)B * nchunk * 4, 256) * 2 + align_up((size_t)B * 4, 256) + align_up((size_t)B * cap * 4, 256) * 4 +
@@ -518,7 +543,7 @@ extern "C" int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_
     a.max_det = max_det;
     for (int i = 0; i < NMS_MASK_WORDS; ++i)                     // host words, NULL = keep every class (general.py:676-677)
         a.classes_mask[i] = classes_mask ? (i < (nc + 63) / 64 ? classes_mask[i] : 0ull) : ~0ull;
-    a.nchunk = (n + NMS_CHUNK - 1) / NMS_CHUNK;
+    a.nchunk = (n + nms_chunk_rows(nc) - 1) / nms_chunk_rows(nc);
     a.cap = n * (multi_label ? nc : 1);
     char *w = static_cast<char *>(workspace);
     const size_t s_chunk = align_up((size_t)B * a.nchunk * 4, 256), s_tot = align_up((size_t)B * 4, 256);
@@ -536,17 +561,9 @@ extern "C" int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_
     uint32_t *sortV = reinterpret_cast<uint32_t *>(w);
     a.det = det; a.count = count;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t rows_lds = (size_t)NMS_CHUNK * a.no * 4;
-    SOMI_REQUIRE(rows_lds + (size_t)EMIT_STAGE * 8 <= 150 * 1024, SOMI_ENOTIMPL, "nms: nc = %d does not fit the LDS row staging", nc);
-    if (rows_lds + (size_t)EMIT_STAGE * 8 > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_count_emit_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)rows_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_count_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(rows_lds + (size_t)EMIT_STAGE * 8));
-    }
-    hipLaunchKernelGGL(nms_count_emit_kernel<false>, dim3(a.nchunk, B), dim3(256), rows_lds, s, a);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(nms_count_emit_kernel<true>, dim3(a.nchunk, B), dim3(256), rows_lds + (size_t)EMIT_STAGE * 8, s, a);
+    if (nms_chunk_rows(nc) == NMS_CHUNK) launch_count_emit<NMS_CHUNK / 256, true>(a, s);
+    else if (nms_rows_staged(nc)) launch_count_emit<1, true>(a, s);
+    else launch_count_emit<1, false>(a, s);
     // top-30000 select (every kernel exits at once for images with <= 30000 candidates)
     (void)hipMemsetAsync(st, 0, (size_t)B * sizeof(SelState), s);
     hipLaunchKernelGGL(nms_select_hist_kernel<1>, dim3(nsel_chunk, B), dim3(256), 0, s, a, st);
