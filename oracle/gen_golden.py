@@ -62,7 +62,7 @@ sys.path.insert(0, f'{REF}/models/ops_dcnv3')
 from functions.dcnv3_func import dcnv3_core_pytorch  # noqa: E402
 
 sys.path.insert(0, ROOT)
-from oracle.somi_ref.testing import fill_state, synthetic_batch, somi_cfg, SOMI_ANCHORS, HYP_VISDRONE  # noqa: E402
+from oracle.somi_ref.testing import fill_state, synthetic_batch, somi_cfg, yolov5_cfg, SOMI_ANCHORS, HYP_VISDRONE  # noqa: E402
 from oracle.somi_ref.nms import greedy_nms  # noqa: E402
 
 # the NMS core is third-party (torchvision): install the restated greedy NMS so the reference's
@@ -196,6 +196,80 @@ def gen_model():
             for i, t in enumerate(tr):
                 rec[f'train{i}'] = t
         save(f'model_{tag}', **rec)
+
+
+# ------------------------------------------------------------------------------------------------ stock YOLOv5 set
+def gen_stock():
+    """The stock YOLOv5 modules north_star names (BASELINE configs[0]) through the reference's own classes: Bottleneck, C3, SPP,
+    Focus, Concat (models/common.py:1494-1509,1541-1565,1806-1826,1973-1997,2085-2097), Detect (models/yolo.py:46-109), and two
+    whole graphs built by the reference's Model / parse_model from layer tables authored here (the reference ships no yolov5s.yaml):
+    '6.0' (6x6 stem, SPPF) and '5.0' (Focus stem, SPP) at width 0.25, plus the parameter count of full yolov5s."""
+    # Focus passes `act` positionally into Conv's dilation slot (models/common.py:1993 vs :55): dilation=True.  The reference's
+    # torch 1.13 runs that as dilation 1; torch 2.10's conv2d rejects a bool, so the harness rewrites the stored tuple to ints
+    # (same arithmetic, nothing else touched).
+    focus_init = RC.Focus.__init__
+
+    def _focus_init(self, *a, **k):
+        focus_init(self, *a, **k)
+        self.conv.conv.dilation = tuple(int(v) for v in self.conv.conv.dilation)
+    RC.Focus.__init__ = _focus_init
+    g = torch.Generator().manual_seed(700)
+    r = lambda *s: torch.randn(*s, generator=g)                       # noqa: E731
+    run_block('bottleneck_sc', RC.Bottleneck(16, 16, True, 1, k=((1, 1), (3, 3)), e=1.0), r(2, 16, 9, 11))
+    run_block('bottleneck_nosc', RC.Bottleneck(16, 24, True), r(2, 16, 8, 8))
+    run_block('c3_sc', RC.C3(32, 32, 2, True), r(2, 32, 10, 10))
+    run_block('c3_nosc', RC.C3(48, 32, 1, False), r(2, 48, 7, 9))
+    run_block('spp', RC.SPP(32, 32, (5, 9, 13)), r(2, 32, 11, 11))
+    run_block('focus', RC.Focus(3, 16, 3), r(2, 3, 12, 16))
+    run_block('conv6x6_s2', RC.Conv(3, 16, 6, 2, 2), r(2, 3, 20, 16))
+    cat = RC.Concat(1)
+    xs = [r(2, 8, 5, 5), r(2, 12, 5, 5)]
+    save('block_concat', in0=xs[0], in1=xs[1], out_eval=cat(xs))
+    det = RY.Detect(7, [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119]], [16, 24])
+    fill_state(det, 3)
+    det.stride = torch.tensor([8., 16.])
+    det.anchors /= det.stride.view(-1, 1, 1)
+    xs = [r(2, 16, 6, 6), r(2, 24, 3, 3)]
+    det.eval()
+    with torch.no_grad():
+        z, raw = det([t.clone() for t in xs])
+    save('block_detect', in0=xs[0], in1=xs[1], z=z, raw0=raw[0], raw1=raw[1], anchors=det.anchors, stride=det.stride)
+    for tag, version, B, S in (('yolov5_v6', '6.0', 2, 64), ('yolov5_v5', '5.0', 2, 64)):
+        m = RY.Model(yolov5_cfg(0.25, 0.33, nc=80, version=version))
+        fill_state(m, 1)
+        x = torch.rand(B, 3, S, S, generator=g)
+        m.eval()
+        with torch.no_grad():
+            z, raw = m(x.clone())
+        rec = dict(x=x, z=z, stride=m.stride, anchors=m.model[-1].anchors, nparams=np.int64(sum(p.numel() for p in m.parameters())))
+        for i, t in enumerate(raw):
+            rec[f'raw{i}'] = t
+        from copy import deepcopy
+        mf = deepcopy(m).eval().fuse()
+        with torch.no_grad():
+            rec['z_fused'] = mf(x.clone())[0]
+        # one training step's worth of numbers: train-mode outputs, the loss the reference's ComputeLoss gives for them, and the
+        # gradients of a few parameters spread over the graph (autograd through the reference's modules)
+        m.train()
+        m.hyp = dict(HYP_VISDRONE)
+        m.zero_grad()
+        _, targets = synthetic_batch(B, S, nc=80, seed=7)
+        tr = m(x.clone())
+        loss, items = RefComputeLoss(m)(tr, targets)
+        loss.backward()
+        for i, t in enumerate(tr):
+            rec[f'train{i}'] = t
+        rec.update(targets=targets, loss=loss, loss_items=items)
+        names = [n for n, p in m.named_parameters() if p.grad is not None]
+        pick = names[:: max(1, len(names) // 24)] + names[-2:]
+        rec['grad_names'] = np.array(pick)
+        pd = dict(m.named_parameters())
+        for i, n in enumerate(pick):
+            rec[f'grad{i}'] = pd[n].grad
+        save(f'model_{tag}', **rec)
+    full = RY.Model(yolov5_cfg())                                     # yolov5s: depth 0.33, width 0.50, nc 80
+    save('model_yolov5s_meta', nparams=np.int64(sum(p.numel() for p in full.parameters())),
+         nlayers=np.int64(len(list(full.modules()))), stride=full.stride, anchors=full.model[-1].anchors)
 
 
 # ------------------------------------------------------------------------------------------------ loss
@@ -415,6 +489,6 @@ def gen_augment():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'loss', 'nms', 'val', 'augment']
+    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'stock', 'loss', 'nms', 'val', 'augment']
     for w in which:
         globals()[f'gen_{w}']()

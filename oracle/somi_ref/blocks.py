@@ -15,6 +15,7 @@ __all__ = [
     'C2fCBAM', 'SPPF', 'Swish', 'BiFPN', 'ODConv2d_3rd', 'ODConv_3rd', 'Residual', 'SEAM',
     'Decouple', 'DecoupledDetect', 'fuse_conv_and_bn', 'initialize_weights',
     'check_anchor_order', 'make_divisible',
+    'Bottleneck', 'C3', 'SPP', 'Focus', 'Concat', 'Detect',
 ]
 
 
@@ -360,6 +361,114 @@ class DecoupledDetect(nn.Module):
                 xy = (y[..., 0:2] * 2 + self.grid[i]) * self.stride[i]
                 wh = (y[..., 2:4] * 2) ** 2 * self.anchor_grid[i]
                 z.append(torch.cat((xy, wh, y[..., 4:]), 4).view(bs, -1, self.no))
+        return x if self.training else (torch.cat(z, 1), x)
+
+
+# ---------------------------------------------------------------------------------------------- stock YOLOv5 module set
+class Bottleneck(nn.Module):
+    """cv1 (k[0]) -> cv2 (k[1]) with an identity shortcut when shapes allow (models/common.py:1494-1509)."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        y = self.cv2(self.cv1(x))
+        return x + y if self.add else y
+
+
+class C3(nn.Module):
+    """CSP bottleneck with three 1x1 convs (models/common.py:1541-1565): cv3(cat(m(cv1(x)), cv2(x))); the inner bottlenecks are
+    1x1 -> 3x3 with expansion 1 (kernel sizes are passed as tuples, :1558)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=((1, 1), (3, 3)), e=1.0) for _ in range(n)))
+
+    def forward(self, x):
+        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), dim=1))
+
+
+class SPP(nn.Module):
+    """1x1 -> parallel k x k / s1 max-pools -> cat -> 1x1 (models/common.py:1806-1826)."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+
+    def forward(self, x):
+        x = self.cv1(x)
+        return self.cv2(torch.cat([x] + [m(x) for m in self.m], 1))
+
+
+class Focus(nn.Module):
+    """Space-to-depth (row parity, column parity) = (0,0), (1,0), (0,1), (1,1) then Conv (models/common.py:1973-1997)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = Conv(c1 * 4, c2, k, s, p, g, act=act)
+
+    def forward(self, x):
+        return self.conv(torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1))
+
+
+class Concat(nn.Module):
+    """torch.cat along `dimension` (models/common.py:2085-2097)."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        return torch.cat(x, self.d)
+
+
+class Detect(nn.Module):
+    """The anchor head of stock YOLOv5 (models/yolo.py:46-109): one 1x1 conv per level producing na*(5+nc) channels.
+    Eval decode: xy = (2*sigmoid - 0.5 + cell) * stride, wh = (2*sigmoid)^2 * anchor_px."""
+    stride = None
+
+    def __init__(self, nc=10, anchors=(), ch=(), inplace=False):
+        super().__init__()
+        self.nc, self.no = nc, nc + 5
+        self.nl, self.na = len(anchors), len(anchors[0]) // 2
+        self.grid = [torch.zeros(1)] * self.nl
+        self.anchor_grid = [torch.zeros(1)] * self.nl
+        self.register_buffer('anchors', torch.tensor(anchors).float().view(self.nl, -1, 2))
+        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
+        self.inplace = inplace
+
+    def _make_grid(self, nx, ny, i):
+        d = self.anchors[i].device
+        yv, xv = torch.meshgrid(torch.arange(ny, device=d), torch.arange(nx, device=d), indexing='ij')
+        grid = torch.stack((xv, yv), 2).expand((1, self.na, ny, nx, 2)).float()
+        anchor_grid = (self.anchors[i].clone() * self.stride[i]).view((1, self.na, 1, 1, 2)).expand((1, self.na, ny, nx, 2)).float()
+        return grid, anchor_grid
+
+    def forward(self, x):
+        x = list(x)
+        z = []
+        for i in range(self.nl):
+            t = self.m[i](x[i])
+            bs, _, ny, nx = t.shape
+            x[i] = t.view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+            if not self.training:
+                if self.grid[i].shape[2:4] != x[i].shape[2:4]:
+                    self.grid[i], self.anchor_grid[i] = self._make_grid(nx, ny, i)
+                y = x[i].sigmoid()
+                xy = (y[..., 0:2] * 2 - 0.5 + self.grid[i]) * self.stride[i]
+                wh = (y[..., 2:4] * 2) ** 2 * self.anchor_grid[i]
+                z.append(torch.cat((xy, wh, y[..., 4:]), -1).view(bs, -1, self.no))
         return x if self.training else (torch.cat(z, 1), x)
 
 

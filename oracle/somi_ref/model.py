@@ -1,6 +1,7 @@
 """Oracle (test infrastructure): yaml -> layer list -> forward, restating models/yolo.py.
 
-Only the module names SURVEY.md section 8a lists are accepted; anything else raises.
+Accepted module names: the SOMI set of SURVEY.md section 8a plus the stock YOLOv5 set north_star names (Bottleneck, C3, SPP,
+Focus, Concat, Detect - BASELINE configs[0]); anything else raises.
 """
 import math
 from copy import deepcopy
@@ -12,8 +13,9 @@ import yaml
 from . import blocks as B
 
 # module name in yaml -> class; names that take (c1, c2, ...) with width scaling
-_CH_MODULES = {'Conv': B.Conv, 'SPPF': B.SPPF, 'C2fCBAM': B.C2fCBAM, 'SEAM': B.SEAM}
-_REPEAT_INSIDE = {'C2fCBAM'}
+_CH_MODULES = {'Conv': B.Conv, 'SPPF': B.SPPF, 'C2fCBAM': B.C2fCBAM, 'SEAM': B.SEAM, 'Bottleneck': B.Bottleneck, 'C3': B.C3, 'SPP': B.SPP,
+               'Focus': B.Focus}                                      # models/yolo.py:1472-1479
+_REPEAT_INSIDE = {'C2fCBAM', 'C3'}                                    # :1487-1492
 # SURVEY "five facts" #2: C2fEACBAM is undefined in the reference; the documented substitution
 _ALIASES = {'C2fEACBAM': 'C2fCBAM'}
 
@@ -53,8 +55,11 @@ def parse_model(d, ch):
         elif name == 'nn.Upsample':
             m = nn.Upsample
             c2 = ch[f]
-        elif name == 'DecoupledDetect':                               # :1616-1619
-            m = B.DecoupledDetect
+        elif name == 'Concat':                                        # :1589-1591
+            m = B.Concat
+            c2 = sum(ch[x] for x in f)
+        elif name in ('DecoupledDetect', 'Detect'):                   # :1606-1610, :1616-1619
+            m = B.DecoupledDetect if name == 'DecoupledDetect' else B.Detect
             args.append([ch[x] for x in f])
             if isinstance(args[1], int):
                 args[1] = [list(range(args[1] * 2))] * len(f)
@@ -72,7 +77,7 @@ def parse_model(d, ch):
 
 
 class Model(nn.Module):
-    """models/yolo.py:1164-1450 restricted to the DecoupledDetect head."""
+    """models/yolo.py:1164-1450 restricted to the DecoupledDetect and plain Detect heads."""
 
     def __init__(self, cfg, ch=3, nc=None, anchors=None):
         super().__init__()
@@ -98,6 +103,14 @@ class Model(nn.Module):
             det.anchors /= det.stride.view(-1, 1, 1)
             self.stride = det.stride
             self._initialize_dh_biases()
+        elif isinstance(det, B.Detect):                               # :1196-1207 (anchors are scaled BEFORE the order check here)
+            s = 256
+            det.inplace = self.inplace
+            det.stride = torch.tensor([s / x.shape[-2] for x in self.forward(torch.zeros(1, ch, s, s))])
+            det.anchors /= det.stride.view(-1, 1, 1)
+            B.check_anchor_order(det)
+            self.stride = det.stride
+            self._initialize_biases()
         B.initialize_weights(self)                                    # :1240
 
     def forward(self, x, augment=False, profile=False, visualize=False):
@@ -127,6 +140,15 @@ class Model(nn.Module):
             b = mi.c3.bias.data
             b += math.log(0.6 / (det.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
             mi.c3.bias = nn.Parameter(b, requires_grad=True)
+
+    def _initialize_biases(self, cf=None):
+        """obj / cls bias priors of the plain Detect head (models/yolo.py:1355-1366)."""
+        det = self.model[-1]
+        for mi, s in zip(det.m, det.stride):
+            b = mi.bias.view(det.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (det.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
+            mi.bias = nn.Parameter(b.view(-1), requires_grad=True)
 
     def fuse(self):
         """Fold Conv+BN pairs for inference (models/yolo.py:1413-1428): only `Conv` instances."""
