@@ -360,6 +360,31 @@ int somi_axpby_f32(float *y, const float *x, long n, float a, float b, somi_stre
 int somi_pack_dgrad_weights_f32(const float *w_packed, float *w_dgrad, int Cout, int taps, int Cin, somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Stock YOLOv5 module set (north_star "CSP/Darknet backbone, PANet/FPN neck, anchor-based detection head"; BASELINE configs[0]).
+ * Bottleneck / C3 / SPP (models/common.py:1494-1509,1541-1565,1806-1826) are compositions of the convolution entry points above
+ * (C3's torch.cat never materialises: cv2 and the last bottleneck write the two halves of cv3's input; SPP's parallel 5/9/13
+ * pools equal SPPF's chained 5x5 pools exactly and share somi_sppf_pool_nhwc_f32).  What needs kernels of its own:
+ *
+ * somi_resample_slice_nhwc_f32 - `Concat` (models/common.py:2085-2097) of inputs that cannot be produced in place, with
+ *   `nn.Upsample(None, 2, 'nearest')` folded into the copy.
+ *     reduce = 0:  dst[b, h, w, dst_coff + c] = src[b, h >> up, w >> up, src_coff + c]      src (B,Hs,Ws,src_cs) -> dst (B,Hs<<up,Ws<<up,dst_cs)
+ *     reduce = 1:  dst[b, h, w, dst_coff + c] (+)= sum_{i,j < 2^up} src[b, (h<<up)+i, (w<<up)+j, src_coff + c]   (the adjoint; fixed order)
+ *   C, the strides and the offsets are multiples of 4, bases 16-byte aligned.
+ * somi_space_to_depth_nhwc_f32 - `Focus` (models/common.py:1996): y[b,h,w,q*C+c] = x[b, 2h+(q&1), 2w+(q>>1), c], q = 0..3;
+ *   inverse = 1: x is the gradient in y's layout (B,Ho,Wo,x_cs), y receives the gradient in the image layout (B,2Ho,2Wo,y_cs).
+ * somi_detect_plain_decode_f32 - `Detect.forward` (models/yolo.py:66-98): t (B,ny,nx,t_cs >= na*no) = the level's 1x1 conv output ->
+ *   raw (B,na,ny,nx,no) and, if z != NULL, rows [row_off, row_off + na*ny*nx) of z (B,total,no):
+ *   xy = (2*sigmoid - 0.5 + cell)*stride (that operation order), wh = (2*sigmoid)^2 * anchors_px, rest sigmoid.
+ * somi_detect_plain_raw_bwd_f32 - the adjoint of the view/permute: d raw -> d t (pad channels zeroed). */
+int somi_resample_slice_nhwc_f32(const float *src, int src_cs, int src_coff, float *dst, int dst_cs, int dst_coff, int B, int Hs,
+                                 int Ws, int C, int up, int reduce, int accumulate, somi_stream_t stream);
+int somi_space_to_depth_nhwc_f32(const float *x, int x_cs, int x_coff, float *y, int y_cs, int y_coff, int B, int Ho, int Wo, int C,
+                                 int inverse, somi_stream_t stream);
+int somi_detect_plain_decode_f32(const float *t, int t_cs, const float *anchors_px_host, float stride, float *raw, float *z, int B,
+                                 int ny, int nx, int na, int nc, int total, int row_off, somi_stream_t stream);
+int somi_detect_plain_raw_bwd_f32(const float *draw, float *dt, int t_cs, int B, int ny, int nx, int na, int nc, somi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.
  * Selection is bit-exact with the oracle: candidates in prediction order (row-major over (box, class) for

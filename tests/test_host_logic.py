@@ -50,6 +50,28 @@ def test_model_parameter_layout_matches_reference(width, depth, anchors):
         assert sum(p.numel() for p in mine.parameters()) == 77537610
 
 
+@pytest.mark.parametrize('version', ['6.0', '5.0'])
+def test_stock_yolov5_parameter_layout_matches_reference(version):
+    """BASELINE configs[0]: the stock graphs (C3 / Bottleneck / Concat / SPP(F) / Focus / Detect) build with the reference's
+    state_dict layout, strides, scaled anchors, bias priors and save list."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import yolov5_cfg
+    from somi_amd.model import Model
+    cfg = yolov5_cfg(version=version)
+    ref, mine = OModel(cfg), Model(cfg)
+    rs, ms = ref.state_dict(), mine.state_dict()
+    assert list(rs) == list(ms)
+    for k in rs:
+        assert rs[k].shape == ms[k].shape, k
+    assert torch.equal(ref.stride, mine.stride) and torch.equal(ref.model[-1].anchors, mine.model[-1].anchors)
+    assert ref.save == mine.save
+    mine.load_state_dict(rs)
+    for a, b in zip(ref.model[-1].m, mine.model[-1].m):
+        assert torch.equal(a.bias, b.bias)
+    if version == '6.0':
+        assert sum(p.numel() for p in mine.parameters()) == 7235389
+
+
 def test_product_refuses_cpu_tensors():
     from oracle.somi_ref.testing import somi_cfg
     from somi_amd.model import Model
@@ -62,7 +84,7 @@ def test_unknown_module_is_rejected():
     from oracle.somi_ref.testing import somi_cfg
     from somi_amd.model import Model
     cfg = somi_cfg(0.25, 0.33)
-    cfg['backbone'][0][2] = 'Focus'
+    cfg['backbone'][0][2] = 'C3TR'
     with pytest.raises(NotImplementedError, match='outside the SOMI hot path'):
         Model(cfg)
 
@@ -74,6 +96,7 @@ def test_product_config_data_matches_oracle_copy():
     from somi_amd import configs as P
     assert O.somi_cfg(0.5, 0.67) == P.somi_cfg(0.5, 0.67)
     assert O.SOMI_ANCHORS == P.SOMI_ANCHORS and O.HYP_VISDRONE == P.HYP_VISDRONE
+    assert O.COCO_ANCHORS == P.COCO_ANCHORS and all(O.yolov5_cfg(version=v) == P.yolov5_cfg(version=v) for v in ('6.0', '5.0'))
     a, b = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8)), nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8))
     O.fill_state(a, 3), P.fill_state(b, 3)
     for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):

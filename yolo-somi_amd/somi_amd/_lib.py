@@ -104,6 +104,10 @@ SIGNATURES = {
     'somi_attn_mlp_bwd_f32': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
     'somi_pool_bwd_add_nhwc_f32': (I, [P, I, I, P, P, P, I, I, I, S]),
     'somi_detect_raw_bwd_f32': (I, [P, P, I, P, I, I, I, I, I, I, S]),
+    'somi_resample_slice_nhwc_f32': (I, [P, I, I, P, I, I, I, I, I, I, I, I, I, S]),
+    'somi_space_to_depth_nhwc_f32': (I, [P, I, I, P, I, I, I, I, I, I, I, S]),
+    'somi_detect_plain_decode_f32': (I, [P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
+    'somi_detect_plain_raw_bwd_f32': (I, [P, P, I, I, I, I, I, I, S]),
     'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, I, I, I, I, I, I, S]),
     'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), P, F, I, P, P, P, I, I, I, I, S]),
     'somi_dwconv3x3_bwd_workspace_floats': (Z, [I, I, I]),

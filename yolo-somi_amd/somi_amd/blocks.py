@@ -147,6 +147,10 @@ class Conv(_Packed):
         super().__init__()
         if g != 1 or d != 1:
             raise NotImplementedError('grouped / dilated Conv is not on the SOMI path')
+        if isinstance(k, (tuple, list)):                         # C3 hands its bottlenecks (1, 1) / (3, 3) (models/common.py:1558)
+            if len(k) != 2 or k[0] != k[1]:
+                raise NotImplementedError('square kernels only')
+            k = int(k[0])
         self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
         self.bn = nn.BatchNorm2d(c2)
         self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
@@ -921,3 +925,197 @@ class DecoupledDetect(nn.Module):
             dbox, dcls = ops.detect_raw_backward(draws[i].contiguous(), widths[i][0], widths[i][1], self.na, self.nc)
             outs.append(self.m[i].backward(dbox, dcls))
         return outs
+
+
+# ================================================================================================ stock YOLOv5 module set
+# north_star: "CSP/Darknet conv backbone, PANet/FPN neck, anchor-based detection head"; BASELINE configs[0] (yolov5s).
+class Bottleneck(nn.Module):
+    """cv1 -> cv2 (+x) (models/common.py:1494-1509); the shortcut rides cv2's epilogue (forward) and cv1's dgrad epilogue (backward)."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x, out=None):
+        return self.cv2(self.cv1(x), out=out, residual=x if self.add else None)
+
+    def backward(self, dout, dx_out=None, accumulate=False, need_dx=True):
+        d = self.cv2.backward(dout)
+        c1 = self.cv1.conv.in_channels
+        fuse = self.add and pad4(c1) == c1 and dout.coff % 4 == 0
+        dx = self.cv1.backward(d, dx_out=dx_out, accumulate=accumulate, need_dx=need_dx, also_add=dout if fuse else None)
+        if self.add and not fuse and dx is not None:
+            ops.add_(dx.t, dx.coff, dout.t, dout.coff, c1)
+        return dx
+
+
+class C3(nn.Module):
+    """cv3(cat(m(cv1(x)), cv2(x))) (models/common.py:1541-1565).  The concatenation never materialises: the last bottleneck and cv2
+    write the two halves of cv3's input buffer; in backward the halves of cv3's data gradient are read in place."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=((1, 1), (3, 3)), e=1.0) for _ in range(n)))
+
+    def forward(self, x):
+        c_ = self.cv1.conv.out_channels
+        if c_ % 4:
+            raise NotImplementedError('C3 hidden width must be a multiple of 4 on the MI355X path')
+        B, H, W, _ = x.shape
+        cat = Act(torch.empty(B, H, W, 2 * c_, device=x.t.device, dtype=torch.float32))
+        n = len(self.m)
+        t = self.cv1(x, out=cat.slice(0, c_) if n == 0 else None)
+        for i, blk in enumerate(self.m):
+            t = blk(t, out=cat.slice(0, c_) if i == n - 1 else None)
+        self.cv2(x, out=cat.slice(c_, c_))
+        return self.cv3(cat)
+
+    def backward(self, dout, dx_out=None, accumulate=False, need_dx=True):
+        c_ = self.cv1.conv.out_channels
+        dcat = self.cv3.backward(dout)
+        dx = self.cv2.backward(dcat.slice(c_, c_), dx_out=dx_out, accumulate=accumulate, need_dx=need_dx)
+        d = dcat.slice(0, c_)
+        for blk in reversed(self.m):
+            d = blk.backward(d)
+        self.cv1.backward(d, dx_out=dx, accumulate=True, need_dx=need_dx)
+        return dx
+
+
+class SPP(nn.Module):
+    """models/common.py:1806-1826 with the stock kernel sizes (5, 9, 13): a stride-1 max-pool of window 9 (13) is exactly two (three)
+    chained 5x5 pools, so the three parallel pools are the same single kernel SPPF uses, writing the concat slices; likewise the
+    gradient (every pooled value's gradient ends at the arg-max pixel of its window whichever way it is routed)."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        if tuple(k) != (5, 9, 13):
+            raise NotImplementedError('SPP kernel sizes (5, 9, 13) only')
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])    # parameter-free; kept for state_dict / repr parity
+
+    forward = SPPF.forward
+    backward = SPPF.backward
+
+
+class Focus(nn.Module):
+    """Space-to-depth + Conv (models/common.py:1973-1997)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        if act is not True:
+            raise NotImplementedError("the reference passes `act` into Conv's dilation slot (models/common.py:1993); only act=True runs there")
+        self.conv = Conv(c1 * 4, c2, k, s, p, g)
+
+    def forward(self, x):
+        if x.shape[1] % 2 or x.shape[2] % 2:
+            raise RuntimeError('Focus needs even height and width')
+        deep = ops.space_to_depth(x.t, x.coff, x.c)
+        return self.conv(Act(deep, 0, 4 * x.c))
+
+    def backward(self, dout, dx_out=None, accumulate=False, need_dx=True):
+        d = self.conv.backward(dout, need_dx=need_dx)
+        if not need_dx:
+            return None
+        if dx_out is not None or accumulate:
+            raise NotImplementedError('Focus writes its own input gradient')
+        c = self.conv.conv.in_channels // 4
+        return Act(ops.space_to_depth(d.t, d.coff, c, inverse=True), 0, c)
+
+
+class Concat(nn.Module):
+    """torch.cat(x, 1) (models/common.py:2085-2097) of NHWC channel slices; an input that is a 2x nearest-upsampled view
+    (`Upsample` only sets a flag) is expanded by the same copy.  Backward hands out slices of the incoming gradient (no copy) and
+    block-sums the slice of an upsampled input."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        if dimension != 1:
+            raise NotImplementedError('channel concatenation only')
+        self.d = dimension
+
+    def forward(self, xs):
+        B, H, W = xs[0].shape[0], xs[0].shape[1] << xs[0].up, xs[0].shape[2] << xs[0].up
+        for a in xs:
+            if a.c % 4 or a.coff % 4:
+                raise NotImplementedError('Concat inputs must be channel slices with offsets and widths that are multiples of 4')
+            if (a.shape[0], a.shape[1] << a.up, a.shape[2] << a.up) != (B, H, W):
+                raise RuntimeError(f'Sizes of tensors must match except in dimension 1. Got {[tuple(v.shape) for v in xs]}')
+        out = Act(torch.empty(B, H, W, sum(a.c for a in xs), device=xs[0].t.device, dtype=torch.float32))
+        off = 0
+        for a in xs:
+            ops.resample_slice(a.t, a.coff, out.t, off, a.c, up=a.up)
+            off += a.c
+        if self.training:
+            self.__dict__['_ctx'] = [(a.c, a.up, a.shape) for a in xs]
+        return out
+
+    def backward(self, dout):
+        ctx = self.__dict__.pop('_ctx')
+        outs, off = [], 0
+        for c, up, shp in ctx:
+            if up == 0:
+                outs.append(dout.slice(off, c))
+            else:
+                lo = torch.empty(shp[0], shp[1], shp[2], c, device=dout.t.device, dtype=torch.float32)
+                ops.resample_slice(dout.t, dout.coff + off, lo, 0, c, up=up, reduce=True)
+                outs.append(Act(lo, 0, c))
+            off += c
+        return outs
+
+
+class Detect(nn.Module):
+    """The stock anchor head (models/yolo.py:46-109): one 1x1 conv (+bias) per level, the view/permute and the eval decode in one
+    kernel.  forward returns (z, [raw_i]) in eval and [raw_i] in training like the reference; raw_i is (B,na,ny,nx,no)."""
+    stride = None
+
+    def __init__(self, nc=80, anchors=(), ch=(), inplace=True):
+        super().__init__()
+        self.nc, self.no = nc, nc + 5
+        self.nl, self.na = len(anchors), len(anchors[0]) // 2
+        self.register_buffer('anchors', torch.tensor(anchors).float().view(self.nl, -1, 2))
+        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
+        self.inplace = inplace
+        self.__dict__['_runners'] = [PlainConv(m) for m in self.m]      # share the parameters, stay out of state_dict
+
+    def invalidate(self):
+        self.__dict__.pop('_anchors_host', None)
+        for r in self._runners:
+            r.invalidate()
+
+    def forward(self, xs):
+        B, dev = xs[0].shape[0], xs[0].t.device
+        total = sum(self.na * a.shape[1] * a.shape[2] for a in xs)
+        z = None if self.training else torch.empty(B, total, self.no, device=dev, dtype=torch.float32)
+        anchors = self.__dict__.get('_anchors_host')
+        if anchors is None:                                   # cached host copy: no device sync per forward
+            anchors = self.__dict__['_anchors_host'] = self.anchors.detach().float().cpu()
+        raws, row, widths = [], 0, []
+        for i, run in enumerate(self._runners):
+            run.conv = self.m[i]                                 # _initialize_biases replaces the bias Parameter, the module stays
+            run.train(self.training)
+            t = run(xs[i])
+            _, ny, nx, cs = t.shape
+            raw = torch.empty(B, self.na, ny, nx, self.no, device=dev, dtype=torch.float32)
+            stride = float(self.stride[i])
+            ops.detect_plain_decode(t.t, (anchors[i] * stride).flatten().tolist(), stride, self.na, self.nc, raw=raw, z=z, total=total,
+                                    row_off=row)
+            raws.append(raw)
+            widths.append(cs)
+            row += self.na * ny * nx
+        if self.training:
+            self.__dict__['_ctx'] = widths
+        return raws if self.training else (z, raws)
+
+    def backward(self, draws):
+        widths = self.__dict__.pop('_ctx')
+        return [run.backward(ops.detect_plain_raw_backward(draws[i].contiguous(), widths[i], self.na, self.nc))
+                for i, run in enumerate(self._runners)]

@@ -81,3 +81,30 @@ def somi_cfg(width=1.0, depth=1.0, nc=10, anchors=4):
     import copy
     return dict(nc=nc, depth_multiple=depth, width_multiple=width, anchors=copy.deepcopy(anchors),
                 backbone=copy.deepcopy(bb), head=copy.deepcopy(hd))
+
+
+COCO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+"""The stock YOLOv5 P3-P5 anchors (upstream yolov5s.yaml; the reference ships no yolov5s.yaml, SURVEY section 2 #21)."""
+
+
+def yolov5_cfg(width=0.50, depth=0.33, nc=80, anchors=None, version='6.0'):
+    """Stock YOLOv5 layer tables authored here (BASELINE configs[0]; the reference ships none): version '6.0' = Conv 6x6 stem + SPPF
+    (upstream yolov5s.yaml of the release this fork is based on); '5.0' = Focus stem + SPP(5,9,13), which exercises the remaining
+    stock modules.  Defaults are yolov5s (depth 0.33, width 0.50, 80 classes -> 7,235,389 parameters for '6.0')."""
+    import copy
+    if version == '6.0':
+        bb = [[-1, 1, 'Conv', [64, 6, 2, 2]], [-1, 1, 'Conv', [128, 3, 2]], [-1, 3, 'C3', [128]], [-1, 1, 'Conv', [256, 3, 2]],
+              [-1, 6, 'C3', [256]], [-1, 1, 'Conv', [512, 3, 2]], [-1, 9, 'C3', [512]], [-1, 1, 'Conv', [1024, 3, 2]],
+              [-1, 3, 'C3', [1024]], [-1, 1, 'SPPF', [1024, 5]]]
+    else:
+        bb = [[-1, 1, 'Focus', [64, 3]], [-1, 1, 'Conv', [128, 3, 2]], [-1, 3, 'C3', [128]], [-1, 1, 'Conv', [256, 3, 2]],
+              [-1, 9, 'C3', [256]], [-1, 1, 'Conv', [512, 3, 2]], [-1, 9, 'C3', [512]], [-1, 1, 'Conv', [1024, 3, 2]],
+              [-1, 1, 'SPP', [1024, [5, 9, 13]]], [-1, 3, 'C3', [1024, False]]]
+    up = [-1, 1, 'nn.Upsample', [None, 2, 'nearest']]
+    hd = [[-1, 1, 'Conv', [512, 1, 1]], up, [[-1, 6], 1, 'Concat', [1]], [-1, 3, 'C3', [512, False]],
+          [-1, 1, 'Conv', [256, 1, 1]], up, [[-1, 4], 1, 'Concat', [1]], [-1, 3, 'C3', [256, False]],
+          [-1, 1, 'Conv', [256, 3, 2]], [[-1, 14], 1, 'Concat', [1]], [-1, 3, 'C3', [512, False]],
+          [-1, 1, 'Conv', [512, 3, 2]], [[-1, 10], 1, 'Concat', [1]], [-1, 3, 'C3', [1024, False]],
+          [[17, 20, 23], 1, 'Detect', ['nc', 'anchors']]]
+    return dict(nc=nc, depth_multiple=depth, width_multiple=width, anchors=copy.deepcopy(anchors or COCO_ANCHORS),
+                backbone=copy.deepcopy(bb), head=copy.deepcopy(hd))

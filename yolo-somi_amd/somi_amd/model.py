@@ -3,8 +3,8 @@
 Same constructor (`Model(cfg, ch=3, nc=None, anchors=None)`), same attributes callers use (`.stride`, `.names`, `.nc`,
 `.hyp`, `.yaml`, `.model[-1].{nl,na,nc,anchors,stride}`, `.fuse()`), same outputs: eval -> `(z (B,N,no), [raw_l])`,
 raw_l = (B,na,ny,nx,no).  Input is the reference's `(B,3,H,W)` NCHW batch, either float32 already divided by 255
-(train.py:249) or uint8 (the /255 then happens in the ingest kernel).  Only module names SURVEY.md section 8a lists
-are accepted.
+(train.py:249) or uint8 (the /255 then happens in the ingest kernel).  Accepted module names: the SOMI set of SURVEY.md
+section 8a and the stock YOLOv5 set north_star names (Bottleneck, C3, SPP, Focus, Concat, Detect - BASELINE configs[0]).
 """
 import math
 from copy import deepcopy
@@ -21,7 +21,9 @@ def make_divisible(x, divisor):
     return math.ceil(x / divisor) * divisor
 
 
-_CH = {'Conv': B.Conv, 'SPPF': B.SPPF, 'C2fCBAM': B.C2fCBAM, 'SEAM': B.SEAM}
+_CH = {'Conv': B.Conv, 'SPPF': B.SPPF, 'C2fCBAM': B.C2fCBAM, 'SEAM': B.SEAM, 'Bottleneck': B.Bottleneck, 'C3': B.C3, 'SPP': B.SPP,
+       'Focus': B.Focus}                                        # models/yolo.py:1472-1479
+_REPEAT_INSIDE = ('C2fCBAM', 'C3')                              # models/yolo.py:1487-1492
 _ALIASES = {'C2fEACBAM': 'C2fCBAM'}     # undefined in the reference (SURVEY "five facts" #2); documented substitution
 
 
@@ -42,7 +44,7 @@ def parse_model(d, ch):
             if c2 != no:
                 c2 = make_divisible(c2 * gw, 8)
             args = [c1, c2, *args[1:]]
-            if name == 'C2fCBAM':
+            if name in _REPEAT_INSIDE:
                 args.insert(2, n)
                 n = 1
         elif name == 'ODConv_3rd':
@@ -57,13 +59,18 @@ def parse_model(d, ch):
         elif name == 'nn.Upsample':
             m = B.Upsample
             c2 = ch[f]
-        elif name == 'DecoupledDetect':
-            m = B.DecoupledDetect
+        elif name == 'Concat':                                    # models/yolo.py:1589-1591
+            m = B.Concat
+            c2 = sum(ch[x] for x in f)
+        elif name in ('DecoupledDetect', 'Detect'):               # models/yolo.py:1606-1610, 1616-1619
+            m = B.DecoupledDetect if name == 'DecoupledDetect' else B.Detect
             args.append([ch[x] for x in f])
             if isinstance(args[1], int):
                 args[1] = [list(range(args[1] * 2))] * len(f)
         else:
             raise NotImplementedError(f'module {name!r} is outside the SOMI hot path (SURVEY.md section 8a)')
+        if n > 1:
+            raise NotImplementedError(f'{n} repeats of {name!r} as an nn.Sequential are not on the path (no shipped or stock graph has them)')
         m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
         m_.i, m_.f, m_.type = i, f, name
         m_.np = sum(p.numel() for p in m_.parameters())
@@ -95,15 +102,22 @@ class Model(nn.Module):
         self.nc = self.yaml['nc']
         self.inplace = self.yaml.get('inplace', False)
         det = self.model[-1]
-        if not isinstance(det, B.DecoupledDetect):
-            raise NotImplementedError('only the DecoupledDetect head is on the SOMI path')
-        # the reference probes strides with a 256x256 zero image (models/yolo.py:1209-1216); the SOMI graph's strides
+        if not isinstance(det, (B.DecoupledDetect, B.Detect)):
+            raise NotImplementedError('only the DecoupledDetect and plain Detect heads are on the path')
+        # the reference probes strides with a 256x256 zero image (models/yolo.py:1197-1216); the graph's strides
         # follow from its stride-2 layers, computed here without a device
         det.stride = torch.tensor(self._probe_strides())
-        self._check_anchor_order(det)
-        det.anchors /= det.stride.view(-1, 1, 1)
-        self.stride = det.stride
-        self._initialize_dh_biases()
+        det.inplace = self.inplace
+        if isinstance(det, B.DecoupledDetect):                   # models/yolo.py:1209-1216: order check, then scaling
+            self._check_anchor_order(det)
+            det.anchors /= det.stride.view(-1, 1, 1)
+            self.stride = det.stride
+            self._initialize_dh_biases()
+        else:                                                    # models/yolo.py:1196-1207: scaling, then order check
+            det.anchors /= det.stride.view(-1, 1, 1)
+            self._check_anchor_order(det)
+            self.stride = det.stride
+            self._initialize_biases()
         for m in self.modules():                                 # utils/torch_utils.py:165-174
             if type(m) is nn.BatchNorm2d:
                 m.eps, m.momentum = 1e-3, 0.03
@@ -116,6 +130,8 @@ class Model(nn.Module):
             r = 1.0 if m.i == 0 else (red[m.i - 1] if src == -1 else red[src])
             if isinstance(m, B.Conv):
                 r *= m.conv.stride[0]
+            elif isinstance(m, B.Focus):
+                r *= 2 * m.conv.conv.stride[0]
             elif isinstance(m, B.ODConv_3rd):
                 r *= m.conv.stride
             elif isinstance(m, B.Upsample):
@@ -141,6 +157,15 @@ class Model(nn.Module):
             b = mi.c3.bias.data
             b += math.log(0.6 / (det.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
             mi.c3.bias = nn.Parameter(b, requires_grad=True)
+
+    def _initialize_biases(self, cf=None):
+        """models/yolo.py:1355-1366 (plain Detect)."""
+        det = self.model[-1]
+        for mi, s in zip(det.m, det.stride):
+            b = mi.bias.view(det.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (det.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
+            mi.bias = nn.Parameter(b.view(-1), requires_grad=True)
 
     # ---------------------------------------------------------------------------------------------- state handling
     def invalidate(self):
@@ -185,8 +210,9 @@ class Model(nn.Module):
             if src not in grads:
                 grads[src] = d
             else:
-                g = grads[src]
-                ops.add_(g.t, g.coff, d.t, d.coff, g.t.shape[3] - g.coff)
+                g = grads[src]                                    # whole padded tensors add their pads too; slices add exactly c
+                whole = all(a.coff == 0 and a.t.shape[3] == B.pad4(a.c) for a in (g, d))
+                ops.add_(g.t, g.coff, d.t, d.coff, g.t.shape[3] if whole else g.c)
         det = self.model[-1]
         hook = self.__dict__.get('_grad_hook')                   # called with a layer index once that layer's gradients are final
         for src, d in zip(self._sources(det), det.backward(draws)):
@@ -198,14 +224,14 @@ class Model(nn.Module):
             if g is None:
                 raise RuntimeError(f'layer {m.i} ({m.type}) received no gradient')
             srcs = self._sources(m)
-            if isinstance(m, B.BiFPN):
+            if isinstance(m, (B.BiFPN, B.Concat)):
                 for src, d in zip(srcs, m.backward(g)):
                     give(src, d)
             elif srcs[0] < 0:
                 m.backward(g, need_dx=False)
             else:
                 have = grads.get(srcs[0])
-                if (have is not None and isinstance(m, (B.Conv, B.C2fCBAM)) and have.coff == 0 and
+                if (have is not None and isinstance(m, (B.Conv, B.C2fCBAM, B.C3, B.SPPF, B.SPP)) and have.coff == 0 and
                         have.t.shape[3] == B.pad4(have.c) and have.t.is_contiguous()):
                     # the input already holds another consumer's gradient: the data-gradient epilogue adds to it in place
                     m.backward(g, dx_out=have, accumulate=True)

@@ -222,6 +222,52 @@ def detect_decode(box, cls, anchors_px, stride, na, nc, raw=None, z=None, total=
                                             _ptr(raw), _ptr(z), B, ny, nx, na, nc, total, row_off, _stream()), 'detect_decode')
 
 
+def detect_plain_decode(t, anchors_px, stride, na, nc, raw=None, z=None, total=0, row_off=0):
+    """Plain `Detect` (models/yolo.py:66-98): t (B,ny,nx,>=na*no) -> raw (B,na,ny,nx,no) and rows of z."""
+    B, ny, nx, t_cs = t.shape
+    a = (C.c_float * (na * 2))(*[float(v) for v in anchors_px])
+    check(_lib.lib().somi_detect_plain_decode_f32(_ptr(_f32c(t)), t_cs, a, float(stride), _ptr(raw), _ptr(z), B, ny, nx, na, nc, total,
+                                                  row_off, _stream()), 'detect_plain_decode')
+
+
+def detect_plain_raw_backward(draw, t_cs, na, nc):
+    B, _, ny, nx, _ = draw.shape
+    dt = torch.empty(B, ny, nx, t_cs, device=draw.device, dtype=torch.float32)
+    check(_lib.lib().somi_detect_plain_raw_bwd_f32(_ptr(_f32c(draw)), _ptr(dt), t_cs, B, ny, nx, na, nc, _stream()), 'detect_plain_raw_bwd')
+    return dt
+
+
+def resample_slice(src, src_coff, dst, dst_coff, c, up=0, reduce=False, accumulate=False):
+    """reduce=False: dst[b,h,w,dst_coff+c] = src[b,h>>up,w>>up,src_coff+c] (Concat copy with nn.Upsample folded in);
+    reduce=True: the adjoint, dst (low resolution) (+)= block sums of src."""
+    lo = dst if reduce else src
+    B, Hs, Ws, _ = lo.shape
+    hi = src if reduce else dst
+    if hi.shape[1] != Hs << up or hi.shape[2] != Ws << up or hi.shape[0] != B:
+        raise RuntimeError(f'resample_slice: shapes {tuple(src.shape)} / {tuple(dst.shape)} do not differ by 2^{up}')
+    check(_lib.lib().somi_resample_slice_nhwc_f32(_ptr(_f32c(src)), src.shape[3], src_coff, _ptr(_f32c(dst)), dst.shape[3], dst_coff, B, Hs, Ws,
+                                                  c, up, int(reduce), int(accumulate), _stream()), 'resample_slice')
+    return dst
+
+
+def space_to_depth(x, x_coff, c, out=None, inverse=False):
+    """Focus (models/common.py:1996): (B,2Ho,2Wo,.) slice of c channels -> (B,Ho,Wo,4c); inverse=True maps a gradient in the deep
+    layout back to the image layout (out must then be given or is allocated with pad4(c) channels)."""
+    if not inverse:
+        B, H, W, _ = x.shape
+        out = torch.empty(B, H // 2, W // 2, (4 * c + 3) // 4 * 4, device=x.device, dtype=torch.float32) if out is None else out
+        if 4 * c < out.shape[3]:
+            out[..., 4 * c:].zero_()
+        check(_lib.lib().somi_space_to_depth_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, _ptr(_f32c(out)), out.shape[3], 0, B, H // 2, W // 2, c, 0,
+                                                      _stream()), 'space_to_depth')
+        return out
+    B, Ho, Wo, _ = x.shape
+    out = torch.zeros(B, 2 * Ho, 2 * Wo, (c + 3) // 4 * 4, device=x.device, dtype=torch.float32) if out is None else out
+    check(_lib.lib().somi_space_to_depth_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, _ptr(_f32c(out)), out.shape[3], 0, B, Ho, Wo, c, 1, _stream()),
+          'space_to_depth (inverse)')
+    return out
+
+
 def odconv_weights(gap, fc_w, fc_b, pk, wout, bout, cin, cin_pad, cout, kk, K):
     """Attention heads + per-sample weight synthesis of ODConv (models/common.py:4557-4590), outer BN folded in."""
     B = gap.shape[0]
