@@ -302,24 +302,28 @@ int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, const float *
 /* D: amaxp[b,c] = first pixel index of max_p x[b,p,c]. workspace: 2*B*nchunk*C 4-byte words */
 int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int32_t *amaxp, void *workspace,
                               somi_stream_t stream);
-/* E: backward of somi_attn_mlp_f32 (same modes); dW1/db1/dW2/db2 ACCUMULATED (db* may be NULL), davg / dmax overwritten */
+/* E: backward of somi_attn_mlp_f32 (same modes); dW1/db1/dW2/db2 ACCUMULATED (db* may be NULL), davg / dmax overwritten.
+ *    The sum over samples runs in ascending order (no atomics).  workspace: somi_attn_mlp_bwd_workspace_floats(B, C, mid) floats. */
+size_t somi_attn_mlp_bwd_workspace_floats(int B, int C, int mid);
 int somi_attn_mlp_bwd_f32(int mode, const float *dout, const float *out, const float *avg, const float *mx, const float *W1,
                           const float *b1, const float *W2, float *dW1, float *db1, float *dW2, float *db2, float *davg,
-                          float *dmax, int B, int C, int mid, somi_stream_t stream);
+                          float *dmax, float *workspace, int B, int C, int mid, somi_stream_t stream);
 /* F: dt[p,c] += davg[b,c]/HW + [p==amaxp[b,c]]*dmax[b,c]  (dmax / amaxp may be NULL: average pool only) */
 int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff, const float *davg, const float *dmax, const int32_t *amaxp,
                                int B, int HW, int C, somi_stream_t stream);
 
 /* Backward of the remaining layer kernels (train_blocks.hip).
  * detect: d raw (B,na,ny,nx,no) -> d box (B,ny,nx,box_cs), d cls (B,ny,nx,cls_cs) (inverse of the interleave; pads zeroed).
- * sppf:   dbuf slices 1..3 (the 5/9/13 pools) are routed to the arg-max positions and ADDED into slice 0 of dbuf.
+ * sppf:   dbuf slices 1..3 (the 5/9/13 pools) are routed to the arg-max positions and ADDED into slice 0 of dbuf (gather form,
+ *         fixed summation order).
  * bifpn:  dsrc_i = wn_i*dout (2x2 sum for an upsampled source, dsrc_i low-res); dw ACCUMULATED incl. the normalisation's chain
  *         rule.  workspace: 3*2048 floats.
  * dwconv: dx (+dx_accumulate), dw [3][3][C] and dbias ACCUMULATED.  workspace: ceil(B*H*W/512)*10*C floats.
  * scale:  y = x*s[b][c]: dx = dout*s, ds[b,c] = sum_p dout*x.  workspace: B*nchunk*C floats. */
 int somi_detect_raw_bwd_f32(const float *draw, float *dbox, int box_cs, float *dcls, int cls_cs, int B, int ny, int nx, int na,
                             int nc, somi_stream_t stream);
-int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream);
+int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, void *workspace, int B, int H, int W, int C, int cs, int x_coff,
+                                somi_stream_t stream);   /* workspace: 3*B*H*W*C bytes (arg-max codes) */
 int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *w_dev,
                             float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
                             int W, int C, somi_stream_t stream);
@@ -343,8 +347,12 @@ int somi_linear_bwd_f32(const float *x, int ldx, const float *W, const float *dy
                         somi_stream_t stream);
 int somi_odconv_synth_f32(const float *attn, const float *Wk, const float *biask, float *wout, float *bout, int B, int Cin, int Cin_pad,
                           int Cout, int kk, int K, somi_stream_t stream);
+/* dWk / dbiask ACCUMULATED, dattn overwritten; fixed summation orders (no atomics).
+ * workspace: somi_odconv_synth_bwd_workspace_floats(B, Cin, Cout, kk, K) floats. */
+size_t somi_odconv_synth_bwd_workspace_floats(int B, int Cin, int Cout, int kk, int K);
 int somi_odconv_synth_bwd_f32(const float *dWb, const float *attn, const float *Wk, const float *biask, const float *dbias_b, float *dWk,
-                              float *dbiask, float *dattn, int B, int Cin, int Cin_pad, int Cout, int kk, int K, somi_stream_t stream);
+                              float *dbiask, float *dattn, float *workspace, int B, int Cin, int Cin_pad, int Cout, int kk, int K,
+                              somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam step (train.py:134-140,271) fused with the ModelEMA update
@@ -402,7 +410,8 @@ int somi_nms_f32(const float *pred, int B, int n, int nc, float conf_thres, floa
  * Loss: ComputeLoss.__call__ + build_targets (utils/loss.py:142-262) with CIoU (utils/metrics.py:476-518).
  * p[l] (B,na,ny_l,nx_l,no) for l < nl<=4; targets (nt,6) [img,cls,x,y,w,h]; anchors (nl,na,2) in grid units.
  * out[0..3] = total*bs, lbox, lobj, lcls (already multiplied by the hyp gains, like loss_items).
- * grad[l] (optional, may be NULL): d(out[0])/d p[l], fully overwritten.
+ * grad[l] (optional, may be NULL): d(out[0])/d p[l], fully overwritten.  Cells hit by several targets sum their entries in
+ * ascending (level, anchor, target, offset) order: value and gradient are run-to-run bit-identical.
  * workspace bytes: somi_loss_workspace_bytes(B, na, nl, ny[], nx[], nt).
  */
 typedef struct somi_loss_desc {

@@ -564,3 +564,85 @@ def test_rccl_call_pattern_single_rank_rehearsal():
     assert line['n_gpus'] == 1 and line['value'] > 0
     ar = line['allreduce']
     assert ar['backend'] == 'nccl' and ar['bytes'] == 311747792 and ar['buckets'] >= 7 and ar['ms'] > 0
+
+
+def _optimizer_snapshot(opt):
+    st = [{k: (v.data.clone() if hasattr(v, 'data') and not torch.is_tensor(v) else (v.clone() if torch.is_tensor(v) else v))
+           for k, v in d.items()} for d in opt._flat]
+    return dict(flat=st, bufs=opt._bflat.data.clone(), buf_ema=None if opt._buf_ema is None else opt._buf_ema.clone(), steps=opt.steps,
+                updates=opt.updates)
+
+
+def _optimizer_restore(opt, snap, model):
+    with torch.no_grad():
+        for d, s in zip(opt._flat, snap['flat']):
+            d['p'].data.copy_(s['p'])
+            d['g'].data.copy_(s['g'])
+            d['m'].copy_(s['m'])
+            d['v'].copy_(s['v'])
+            if d['ema'] is not None:
+                d['ema'].copy_(s['ema'])
+        opt._bflat.data.copy_(snap['bufs'])
+        if opt._buf_ema is not None:
+            opt._buf_ema.copy_(snap['buf_ema'])
+    opt.steps, opt.updates = snap['steps'], snap['updates']
+    for m in model.modules():                                    # BatchNorm step counters live outside the flat buffers
+        if isinstance(m, nn.BatchNorm2d):
+            m.num_batches_tracked.zero_()
+    model.invalidate()
+
+
+@pytest.mark.parametrize('graph', ['somi_w025', 'somi_full', 'yolov5s'])
+def test_training_step_is_bit_reproducible(graph):
+    """The same TrainStep from the same state, twice: gradients (captured right before the optimizer), BatchNorm statistics, weights,
+    Adam moments and the EMA shadow must be bit-identical - every reduction on the path has a fixed order (stream-K fix-up, wgrad
+    splits, BN partial sums, the loss's per-cell entry lists, attention / ODConv parameter gradients, SPPF routing).  A difference
+    names the first tensor that moved, i.e. the kernel to look at; run-to-run noise can then no longer hide a race."""
+    from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch, yolov5_cfg
+    from somi_amd.model import Model
+    from somi_amd.train import TrainStep
+    cfg, B, S, nc = {'somi_w025': (somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS), 4, 128, 10),
+                     'somi_full': (somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS), 4, 160, 10),
+                     'yolov5s': (yolov5_cfg(), 4, 256, 80)}[graph]
+    model = fill_state(Model(cfg), 5).cuda()
+    tr = TrainStep(model, dict(HYP_VISDRONE), B)
+    imgs, targets = synthetic_batch(B, S, nc=nc, seed=8)
+    targets = torch.cat([targets, targets[:7]])                  # duplicate targets: several entries per loss cell
+    imgs, targets = imgs.cuda(), targets.cuda()
+    tr.step(imgs, targets)                                       # one step first, so the moments / EMA / statistics are non-trivial
+    torch.cuda.synchronize()
+    snap = _optimizer_snapshot(tr.optimizer)
+    names = {}
+    for st in tr.optimizer._flat:
+        for p, o in zip(st['p'].tensors, st['p'].offsets):
+            names[(id(st), o)] = next(n for n, q in model.named_parameters() if q is p)
+    runs = []
+    for _ in range(2):
+        _optimizer_restore(tr.optimizer, snap, model)
+        grads = []
+        real = tr.optimizer.step
+
+        def spy(real=real, grads=grads):
+            grads.extend(g.clone() for g in tr.optimizer.flat_grads)
+            real()
+        tr.optimizer.step = spy
+        loss, items = tr.step(imgs, targets)
+        tr.optimizer.step = real
+        torch.cuda.synchronize()
+        runs.append(dict(loss=loss.clone(), items=items.clone(), grads=grads, params=[p.clone() for p in tr.optimizer.flat_params],
+                         bufs=tr.optimizer.flat_buffers.clone(), m=[st['m'].clone() for st in tr.optimizer._flat],
+                         v=[st['v'].clone() for st in tr.optimizer._flat], ema=[st['ema'].clone() for st in tr.optimizer._flat]))
+    a, b = runs
+
+    def first_difference(x, y, st):
+        idx = int((x != y).nonzero()[0])
+        offs = sorted(o for (sid, o) in names if sid == id(st))
+        owner = max(o for o in offs if o <= idx)
+        return f'{names[(id(st), owner)]} (+{idx - owner}): {float(x[idx])!r} vs {float(y[idx])!r}, {int((x != y).sum())} elements differ'
+    assert torch.equal(a['loss'], b['loss']) and torch.equal(a['items'], b['items']), 'loss differs between two identical runs'
+    for gi, st in enumerate(tr.optimizer._flat):
+        assert torch.equal(a['grads'][gi], b['grads'][gi]), 'gradient of ' + first_difference(a['grads'][gi], b['grads'][gi], st)
+    assert torch.equal(a['bufs'], b['bufs']), 'BatchNorm running statistics differ'
+    for key in ('params', 'm', 'v', 'ema'):
+        for gi, st in enumerate(tr.optimizer._flat):
+            assert torch.equal(a[key][gi], b[key][gi]), f'{key} of ' + first_difference(a[key][gi], b[key][gi], st)

@@ -7,8 +7,12 @@
 //               (forward-mode duals give d(1-CIoU)/d logits), the class BCE, and
 //                 - stores 1-CIoU and the class-BCE sum in the entry's slot (deterministic reduction later),
 //                 - atomicMax's clamp(CIoU,0,1) into the objectness target map (the reference sorts by IoU and lets
-//                   the last write win, utils/loss.py:174-178: the surviving value is the per-cell maximum),
-//                 - atomically adds the unscaled box / class gradients into grad (cells can be hit more than once).
+//                   the last write win, utils/loss.py:174-178: the surviving value is the per-cell maximum; an integer
+//                   max, so the result does not depend on the order),
+//                 - pushes the entry onto its cell's list (an integer exchange on a per-cell head index).
+//   1b. scatter one lane per entry; the lane whose entry heads a cell's list walks the list in ASCENDING entry order
+//               (cells can be hit more than once: duplicate / clamped targets) and writes the summed unscaled box / class
+//               gradients with plain stores - a fixed summation order, so the gradient is run-to-run bit-identical.
 //   2. count    per-level number of entries (needed to scale the means) - folded into the dense pass below.
 //   3. dense    one streaming pass over every prediction element: objectness BCE against the target map (partial
 //               sums per workgroup) and, when gradients are wanted, the objectness gradient plus the 1/n scaling of
@@ -32,6 +36,8 @@ struct LossArgs {
     unsigned *tobj;         // [sum cells] float bits (>= 0), zeroed
     float *slots;           // [nl][na*nt*NOFF][2] = {1-ciou or -1 (invalid), cls bce sum}
     int *nent;              // [4] entries per level, zeroed
+    int *head;              // [sum cells] last entry pushed onto the cell's list, -1 = none (only with gradients)
+    int *next;              // [nl][na*nt*NOFF] list links
     float *partial;         // [sum nblk] obj-BCE partial sums
 };
 
@@ -84,6 +90,57 @@ __device__ __forceinline__ float bce_logits_grad(float x, float y, float pw) {
 }
 
 // ------------------------------------------------------------------------------------------------ 1. match
+// One (level, anchor, target) triple: the anchor-ratio test and the neighbour-cell offsets of build_targets (utils/loss.py:233-245)
+struct Triple {
+    bool ok;
+    int b, cls, nx, ny;
+    float gx, gy, gw, gh, aw, ah;
+    bool use[NOFF];
+};
+__device__ __forceinline__ Triple load_triple(const somi_loss_desc &d, int l, int an, int t) {
+    Triple r;
+    r.nx = d.nx[l];
+    r.ny = d.ny[l];
+    const float *tg = d.targets + (size_t)t * 6;
+    r.b = (int)tg[0];
+    r.cls = (int)tg[1];
+    r.gx = tg[2] * (float)r.nx; r.gy = tg[3] * (float)r.ny; r.gw = tg[4] * (float)r.nx; r.gh = tg[5] * (float)r.ny;
+    r.aw = d.anchors[(l * d.na + an) * 2];
+    r.ah = d.anchors[(l * d.na + an) * 2 + 1];
+    const float rw = r.gw / r.aw, rh = r.gh / r.ah;
+    r.ok = fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh)) < d.anchor_t;                  // utils/loss.py:233-235
+    const float g = 0.5f;
+    const float gxi = (float)r.nx - r.gx, gyi = (float)r.ny - r.gy;
+    r.use[0] = true;
+    r.use[1] = (fmodf(r.gx, 1.f) < g) && r.gx > 1.f;
+    r.use[2] = (fmodf(r.gy, 1.f) < g) && r.gy > 1.f;
+    r.use[3] = (fmodf(gxi, 1.f) < g) && gxi > 1.f;
+    r.use[4] = (fmodf(gyi, 1.f) < g) && gyi > 1.f;
+    return r;
+}
+// One entry (triple, offset k): its cell, the decoded box, CIoU with the derivatives w.r.t. the four box logits
+struct Entry {
+    size_t cell;
+    Dual c;
+    float s0, s1, s2, s3;
+};
+__device__ __forceinline__ Entry eval_entry(const somi_loss_desc &d, int no, const float *pl, const Triple &r, int an, int k) {
+    const float offx[NOFF] = {0.f, 0.5f, 0.f, -0.5f, 0.f}, offy[NOFF] = {0.f, 0.f, 0.5f, 0.f, -0.5f};
+    int gi = (int)(r.gx - offx[k]), gj = (int)(r.gy - offy[k]);                           // .long(): truncation
+    gi = min(max(gi, 0), r.nx - 1);                                                       // clamp_ (also feeds tbox)
+    gj = min(max(gj, 0), r.ny - 1);
+    const float tbx = r.gx - (float)gi, tby = r.gy - (float)gj;
+    Entry e;
+    e.cell = (((size_t)r.b * d.na + an) * r.ny + gj) * r.nx + gi;
+    const float *ps = pl + e.cell * no;
+    e.s0 = 1.f / (1.f + expf(-ps[0])); e.s1 = 1.f / (1.f + expf(-ps[1]));
+    e.s2 = 1.f / (1.f + expf(-ps[2])); e.s3 = 1.f / (1.f + expf(-ps[3]));
+    const float pxv = e.s0 * 2.f - 0.5f, pyv = e.s1 * 2.f - 0.5f;
+    const float pwv = (e.s2 * 2.f) * (e.s2 * 2.f) * r.aw, phv = (e.s3 * 2.f) * (e.s3 * 2.f) * r.ah;
+    e.c = ciou_xywh(dvar(pxv, 0), dvar(pyv, 1), dvar(pwv, 2), dvar(phv, 3), tbx, tby, r.gw, r.gh);
+    return e;
+}
+
 __global__ __launch_bounds__(256) void loss_match_kernel(const LossArgs a) {
     const somi_loss_desc &d = a.d;
     const int l = blockIdx.y;
@@ -91,58 +148,77 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= per_level) return;
     const int an = idx / d.nt, t = idx % d.nt;                 // anchor-major like targets.repeat(na,1,1)
-    const int nx = d.nx[l], ny = d.ny[l];
     float *slot = a.slots + ((size_t)l * per_level + idx) * NOFF * 2;
     for (int k = 0; k < NOFF; ++k) slot[k * 2] = -1.f;         // invalid
-    const float *tg = d.targets + (size_t)t * 6;
-    const int b = (int)tg[0], cls = (int)tg[1];
-    const float gx = tg[2] * (float)nx, gy = tg[3] * (float)ny, gw = tg[4] * (float)nx, gh = tg[5] * (float)ny;
-    const float aw = d.anchors[(l * d.na + an) * 2], ah = d.anchors[(l * d.na + an) * 2 + 1];
-    const float rw = gw / aw, rh = gh / ah;
-    if (!(fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh)) < d.anchor_t)) return;          // utils/loss.py:233-235
-    const float g = 0.5f;
-    const float gxi = (float)nx - gx, gyi = (float)ny - gy;
-    const bool fj = (fmodf(gx, 1.f) < g) && gx > 1.f, fk = (fmodf(gy, 1.f) < g) && gy > 1.f;
-    const bool fl = (fmodf(gxi, 1.f) < g) && gxi > 1.f, fm = (fmodf(gyi, 1.f) < g) && gyi > 1.f;
-    const bool use[NOFF] = {true, fj, fk, fl, fm};
-    const float offx[NOFF] = {0.f, g, 0.f, -g, 0.f}, offy[NOFF] = {0.f, 0.f, g, 0.f, -g};
+    const Triple r = load_triple(d, l, an, t);
+    if (!r.ok) return;
     const float *pl = d.p[l];
-    float *gl = d.grad[l];
     int emitted = 0;
     for (int k = 0; k < NOFF; ++k) {
-        if (!use[k]) continue;
-        int gi = (int)(gx - offx[k]), gj = (int)(gy - offy[k]);                           // .long(): truncation
-        gi = min(max(gi, 0), nx - 1);                                                     // clamp_ (also feeds tbox)
-        gj = min(max(gj, 0), ny - 1);
-        const float tbx = gx - (float)gi, tby = gy - (float)gj;
-        const size_t cell = (((size_t)b * d.na + an) * ny + gj) * nx + gi;
-        const float *ps = pl + cell * a.no;
-        const float s0 = 1.f / (1.f + expf(-ps[0])), s1 = 1.f / (1.f + expf(-ps[1]));
-        const float s2 = 1.f / (1.f + expf(-ps[2])), s3 = 1.f / (1.f + expf(-ps[3]));
-        const float pxv = s0 * 2.f - 0.5f, pyv = s1 * 2.f - 0.5f;
-        const float pwv = (s2 * 2.f) * (s2 * 2.f) * aw, phv = (s3 * 2.f) * (s3 * 2.f) * ah;
-        const Dual c = ciou_xywh(dvar(pxv, 0), dvar(pyv, 1), dvar(pwv, 2), dvar(phv, 3), tbx, tby, gw, gh);
-        slot[k * 2] = 1.f - c.v;
-        const float iou01 = fminf(fmaxf(c.v, 0.f), 1.f);
-        atomicMax(a.tobj + a.cell_off[l] + cell, __float_as_uint((1.f - d.gr) + d.gr * iou01));
+        if (!r.use[k]) continue;
+        const Entry e = eval_entry(d, a.no, pl, r, an, k);
+        slot[k * 2] = 1.f - e.c.v;
+        const float iou01 = fminf(fmaxf(e.c.v, 0.f), 1.f);
+        atomicMax(a.tobj + a.cell_off[l] + e.cell, __float_as_uint((1.f - d.gr) + d.gr * iou01));
         float csum = 0.f;
         if (d.nc > 1) {
-            for (int j = 0; j < d.nc; ++j) {
-                const float y = j == cls ? d.cp : d.cn;
-                csum += bce_logits(ps[5 + j], y, d.cls_pw);
-                if (gl) atomicAdd(gl + cell * a.no + 5 + j, bce_logits_grad(ps[5 + j], y, d.cls_pw));
-            }
+            const float *ps = pl + e.cell * a.no;
+            for (int j = 0; j < d.nc; ++j) csum += bce_logits(ps[5 + j], j == r.cls ? d.cp : d.cn, d.cls_pw);
         }
         slot[k * 2 + 1] = csum;
-        if (gl) {                                                                          // d(1-ciou)/d logits, unscaled
-            atomicAdd(gl + cell * a.no + 0, -c.g[0] * 2.f * s0 * (1.f - s0));
-            atomicAdd(gl + cell * a.no + 1, -c.g[1] * 2.f * s1 * (1.f - s1));
-            atomicAdd(gl + cell * a.no + 2, -c.g[2] * 8.f * s2 * s2 * (1.f - s2) * aw);
-            atomicAdd(gl + cell * a.no + 3, -c.g[3] * 8.f * s3 * s3 * (1.f - s3) * ah);
+        if (d.grad[l]) {                                        // push onto the cell's list; 1b sums the list in a fixed order
+            const int ent = ((int)l * per_level + idx) * NOFF + k;
+            a.next[ent] = atomicExch(a.head + a.cell_off[l] + e.cell, ent);
         }
         ++emitted;
     }
     if (emitted) atomicAdd(a.nent + l, emitted);
+}
+
+// ------------------------------------------------------------------------------------------------ 1b. gradient of the matched entries
+__global__ __launch_bounds__(256) void loss_scatter_kernel(const LossArgs a) {
+    const somi_loss_desc &d = a.d;
+    const int l = blockIdx.y;
+    const int per_level = d.na * d.nt;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float *gl = d.grad[l];
+    if (idx >= per_level || !gl) return;
+    const int an = idx / d.nt, t = idx % d.nt;
+    const Triple r = load_triple(d, l, an, t);
+    if (!r.ok) return;
+    const float *pl = d.p[l];
+    const int base = (int)l * per_level * NOFF;
+    for (int k = 0; k < NOFF; ++k) {
+        if (!r.use[k]) continue;
+        const Entry own = eval_entry(d, a.no, pl, r, an, k);
+        const int ent = base + idx * NOFF + k;
+        const int *head = a.head + a.cell_off[l] + own.cell;
+        if (*head != ent) continue;                              // exactly one entry per hit cell heads its list
+        float *g = gl + own.cell * a.no;
+        float gb[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < d.nc && d.nc > 1; ++j) g[5 + j] = 0.f;
+        // ascending entry order: repeatedly take the smallest list member above the last one (lists hold 1-3 entries)
+        for (int last = -1;;) {
+            int m = 0x7fffffff;
+            for (int q = *head; q >= 0; q = a.next[q])
+                if (q > last && q < m) m = q;
+            if (m == 0x7fffffff) break;
+            last = m;
+            const int rel = m - base, k2 = rel % NOFF, idx2 = rel / NOFF;
+            const int an2 = idx2 / d.nt, t2 = idx2 % d.nt;       // same level, same anchor (the cell index contains it)
+            const Triple r2 = load_triple(d, l, an2, t2);
+            const Entry e = eval_entry(d, a.no, pl, r2, an2, k2);
+            gb[0] += -e.c.g[0] * 2.f * e.s0 * (1.f - e.s0);     // d(1-ciou)/d logits, unscaled
+            gb[1] += -e.c.g[1] * 2.f * e.s1 * (1.f - e.s1);
+            gb[2] += -e.c.g[2] * 8.f * e.s2 * e.s2 * (1.f - e.s2) * r2.aw;
+            gb[3] += -e.c.g[3] * 8.f * e.s3 * e.s3 * (1.f - e.s3) * r2.ah;
+            if (d.nc > 1) {
+                const float *ps = pl + own.cell * a.no;
+                for (int j = 0; j < d.nc; ++j) g[5 + j] += bce_logits_grad(ps[5 + j], j == r2.cls ? d.cp : d.cn, d.cls_pw);
+            }
+        }
+        g[0] = gb[0]; g[1] = gb[1]; g[2] = gb[2]; g[3] = gb[3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ 3. dense pass
@@ -256,7 +332,8 @@ extern "C" size_t somi_loss_workspace_bytes(const somi_loss_desc *d) {
     const size_t tobj = align_up((size_t)(a.cell_off[d->nl - 1] + a.cells[d->nl - 1]) * 4, 256);
     const size_t slots = align_up((size_t)d->nl * d->na * (d->nt > 0 ? d->nt : 1) * NOFF * 2 * 4, 256);
     const size_t part = align_up((size_t)(a.blk_off[d->nl - 1] + a.nblk[d->nl - 1]) * 4, 256);
-    return tobj + 256 + slots + part;
+    const size_t next = align_up((size_t)d->nl * d->na * (d->nt > 0 ? d->nt : 1) * NOFF * 4, 256);
+    return tobj + 256 + slots + part + tobj + next;      // + the per-cell list heads and the entry links of the gradient pass
 }
 
 extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *workspace, size_t workspace_bytes,
@@ -274,12 +351,19 @@ extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *w
     a.tobj = reinterpret_cast<unsigned *>(w); w += tobj_b;
     a.nent = reinterpret_cast<int *>(w); w += 256;
     a.slots = reinterpret_cast<float *>(w); w += align_up((size_t)d.nl * d.na * (d.nt > 0 ? d.nt : 1) * NOFF * 2 * 4, 256);
-    a.partial = reinterpret_cast<float *>(w);
+    a.partial = reinterpret_cast<float *>(w); w += align_up((size_t)(a.blk_off[d.nl - 1] + a.nblk[d.nl - 1]) * 4, 256);
+    a.head = reinterpret_cast<int *>(w); w += tobj_b;
+    a.next = reinterpret_cast<int *>(w);
+    bool any_grad = false;
+    for (int l = 0; l < d.nl; ++l) any_grad = any_grad || d.grad[l];
     (void)hipMemsetAsync(a.tobj, 0, tobj_b + 256, s);                       // target maps + entry counters
+    if (any_grad && d.nt > 0) (void)hipMemsetAsync(a.head, 0xFF, tobj_b, s);   // -1: empty lists
     for (int l = 0; l < d.nl; ++l)
         if (d.grad[l]) (void)hipMemsetAsync(d.grad[l], 0, (size_t)a.cells[l] * a.no * 4, s);
-    if (d.nt > 0)
+    if (d.nt > 0) {
         hipLaunchKernelGGL(loss_match_kernel, dim3(cdiv((long)d.na * d.nt, 256), d.nl), dim3(256), 0, s, a);
+        if (any_grad) hipLaunchKernelGGL(loss_scatter_kernel, dim3(cdiv((long)d.na * d.nt, 256), d.nl), dim3(256), 0, s, a);
+    }
     for (int l = 0; l < d.nl; ++l) hipLaunchKernelGGL(loss_dense_kernel, dim3(a.nblk[l]), dim3(256), 0, s, a, l);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, a, out4);
     return launch_status("somi_yolo_loss_f32");

@@ -223,16 +223,19 @@ __global__ __launch_bounds__(256) void pool_argmax_stage2(const float *__restric
 // ------------------------------------------------------------------------------------------------ E
 // one workgroup per sample.  mode 0 (CBAM): out = sigmoid(o_avg + o_max), o_x = W2 relu(W1 x + b1) + b2
 //                            mode 1 (SEAM): out = exp(sigmoid(W2 relu(W1 avg)))               (no biases)
-// dout = gradient w.r.t. `out`.  Weight gradients are accumulated with float atomics across samples.
+// dout = gradient w.r.t. `out`.  Stage 1 (this kernel) produces the data gradients and leaves the per-sample factors of the
+// weight gradients in `ws` = [B][C + 3*mid]: dov (C), ra (mid), dh_avg (mid), dh_max (mid); stage 2 sums the outer products
+// over the samples in ascending order (no atomics: run-to-run bit-identical).
 __global__ __launch_bounds__(256) void attn_mlp_bwd_kernel(int mode, const float *__restrict__ dout, const float *__restrict__ out,
                                                            const float *__restrict__ avg, const float *__restrict__ mx,
                                                            const float *__restrict__ W1, const float *__restrict__ b1,
-                                                           const float *__restrict__ W2, float *dW1, float *db1, float *dW2, float *db2,
+                                                           const float *__restrict__ W2, float *__restrict__ ws,
                                                            float *__restrict__ davg, float *__restrict__ dmax, int C, int mid) {
     __shared__ float h_avg[64], h_max[64], dh_avg[64], dh_max[64];
     __shared__ float dov[1024];                                          // d(pre-activation of the second layer), C <= 1024
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *va = avg + (long)b * C, *vm = mx ? mx + (long)b * C : nullptr;
+    float *wb = ws + (long)b * (C + 3 * mid);
     for (int j = wave; j < mid; j += 4) {
         float sa = 0.f, sm = 0.f;
         for (int c = lane; c < C; c += 64) {
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256) void attn_mlp_bwd_kernel(int mode, const float
             const float bb = b1 ? b1[j] : 0.f;
             h_avg[j] = sa + bb;                                          // pre-ReLU
             h_max[j] = sm + bb;
+            wb[C + j] = fmaxf(sa + bb, 0.f) + (mode == 0 ? fmaxf(sm + bb, 0.f) : 0.f);      // ra
         }
     }
     __syncthreads();
@@ -254,11 +258,7 @@ __global__ __launch_bounds__(256) void attn_mlp_bwd_kernel(int mode, const float
         if (mode == 0) d = g * o * (1.f - o);                            // sigmoid'
         else { const float sg = logf(o); d = g * o * sg * (1.f - sg); }  // out = exp(s), s = sigmoid(.): d/dpre = out * s(1-s)
         dov[c] = d;
-        if (db2) atomicAdd(db2 + c, mode == 0 ? 2.f * d : d);
-        for (int j = 0; j < mid; ++j) {
-            const float ra = fmaxf(h_avg[j], 0.f) + (mode == 0 ? fmaxf(h_max[j], 0.f) : 0.f);
-            atomicAdd(dW2 + (long)c * mid + j, d * ra);
-        }
+        wb[c] = d;
     }
     __syncthreads();
     for (int j = wave; j < mid; j += 4) {                                // dh = W2^T dov, gated by the ReLU
@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void attn_mlp_bwd_kernel(int mode, const float
         if (lane == 0) {
             dh_avg[j] = h_avg[j] > 0.f ? s : 0.f;
             dh_max[j] = (mode == 0 && h_max[j] > 0.f) ? s : 0.f;
-            if (db1) atomicAdd(db1 + j, dh_avg[j] + dh_max[j]);
+            wb[C + mid + j] = dh_avg[j];
+            wb[C + 2 * mid + j] = dh_max[j];
         }
     }
     __syncthreads();
@@ -278,10 +279,38 @@ __global__ __launch_bounds__(256) void attn_mlp_bwd_kernel(int mode, const float
             const float w = W1[(long)j * C + c];
             da += w * dh_avg[j];
             dm += w * dh_max[j];
-            atomicAdd(dW1 + (long)j * C + c, dh_avg[j] * va[c] + (vm ? dh_max[j] * vm[c] : 0.f));
         }
         davg[(long)b * C + c] = da;
         if (dmax) dmax[(long)b * C + c] = dm;
+    }
+}
+
+// stage 2: one lane per (j, c) pair of the two weight matrices (+ the bias lanes); samples summed in ascending order, ADDED to the outputs
+__global__ __launch_bounds__(256) void attn_mlp_bwd_weights_kernel(int mode, const float *__restrict__ ws, const float *__restrict__ avg,
+                                                                   const float *__restrict__ mx, float *dW1, float *db1, float *dW2, float *db2,
+                                                                   int B, int C, int mid) {
+    const int stride = C + 3 * mid;
+    const long n = (long)C * mid;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < n; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C), j = (int)(it / C);                  // consecutive lanes: consecutive channels
+        float s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float *wb = ws + (long)b * stride;
+            s2 += wb[c] * wb[C + j];
+            s1 += wb[C + mid + j] * avg[(long)b * C + c] + (mx ? wb[C + 2 * mid + j] * mx[(long)b * C + c] : 0.f);
+        }
+        dW2[(long)c * mid + j] += s2;
+        dW1[(long)j * C + c] += s1;
+        if (j == 0 && db2) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += ws[(long)b * stride + c];
+            db2[c] += mode == 0 ? 2.f * s : s;
+        }
+        if (c == 0 && db1) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += ws[(long)b * stride + C + mid + j] + ws[(long)b * stride + C + 2 * mid + j];
+            db1[j] += s;
+        }
     }
 }
 
@@ -361,14 +390,19 @@ extern "C" int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, i
     return launch_status("somi_pool_argmax_nhwc_f32");
 }
 
+extern "C" size_t somi_attn_mlp_bwd_workspace_floats(int B, int C, int mid) { return (size_t)B * (C + 3 * mid); }
+
 extern "C" int somi_attn_mlp_bwd_f32(int mode, const float *dout, const float *out, const float *avg, const float *mx, const float *W1,
                                      const float *b1, const float *W2, float *dW1, float *db1, float *dW2, float *db2, float *davg,
-                                     float *dmax, int B, int C, int mid, somi_stream_t stream) {
-    SOMI_REQUIRE(dout && out && avg && W1 && W2 && dW1 && dW2 && davg && B > 0 && C > 0 && C <= 1024 && mid > 0 && mid <= 64, SOMI_EINVAL,
-                 "attn mlp bwd: bad arguments (C <= 1024, mid <= 64)");
+                                     float *dmax, float *workspace, int B, int C, int mid, somi_stream_t stream) {
+    SOMI_REQUIRE(dout && out && avg && W1 && W2 && dW1 && dW2 && davg && workspace && B > 0 && C > 0 && C <= 1024 && mid > 0 && mid <= 64,
+                 SOMI_EINVAL, "attn mlp bwd: bad arguments (C <= 1024, mid <= 64)");
     SOMI_REQUIRE((mode == 0 && mx && dmax) || mode == 1, SOMI_EINVAL, "attn mlp bwd: mode 0 needs max inputs/outputs");
-    hipLaunchKernelGGL(attn_mlp_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mode, dout, out, avg, mode == 0 ? mx : nullptr, W1, b1, W2,
-                       dW1, db1, dW2, db2, davg, mode == 0 ? dmax : nullptr, C, mid);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_mlp_bwd_kernel, dim3(B), dim3(256), 0, s, mode, dout, out, avg, mode == 0 ? mx : nullptr, W1, b1, W2, workspace, davg,
+                       mode == 0 ? dmax : nullptr, C, mid);
+    hipLaunchKernelGGL(attn_mlp_bwd_weights_kernel, dim3(cdiv((long)C * mid, 256)), dim3(256), 0, s, mode, workspace, avg, mode == 0 ? mx : nullptr, dW1,
+                       db1, dW2, db2, B, C, mid);
     return launch_status("somi_attn_mlp_bwd_f32");
 }
 
@@ -409,9 +443,12 @@ __global__ __launch_bounds__(256) void detect_raw_bwd_kernel(const float *__rest
     }
 }
 
-// ---- SPPF: the three pooled slices' gradients are routed to the arg-max of their 5/9/13 windows in slice 0 (atomics; tiny maps)
-__global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const float *__restrict__ buf, float *__restrict__ dbuf, int B, int H, int W, int C,
-                                                            int cs, int x_coff) {
+// ---- SPPF / SPP: the gradients of the three pooled slices (5 / 9 / 13 windows of slice 0) go to the arg-max pixel of their window.
+// Gather form, no atomics (run-to-run bit-identical): pass 1 records, per (pixel, channel, window), WHERE the maximum sits as one
+// byte (dh+6)*13 + (dw+6), first maximum in row-major order like torch's max_pool2d; pass 2 lets every slice-0 element collect, in
+// a fixed order, the gradients of the window outputs that point at it.
+__global__ __launch_bounds__(256) void sppf_pool_argmax_kernel(const float *__restrict__ buf, uint8_t *__restrict__ arg, int B, int H, int W, int C,
+                                                               int cs, int x_coff) {
     const long items = (long)B * H * W * C;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
         const int c = (int)(it % C);
@@ -419,7 +456,7 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const float *__restr
         const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
         const long b = pix / ((long)W * H);
         float m[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
-        long mi[3] = {0, 0, 0};
+        int mi[3] = {84, 84, 84};                                        // the centre; every window contains it
         for (int dh = -6; dh <= 6; ++dh) {
             const int hi = hv + dh;
             if ((unsigned)hi >= (unsigned)H) continue;
@@ -429,15 +466,40 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const float *__restr
                 if ((unsigned)wi >= (unsigned)W) continue;
                 const int aw = dw < 0 ? -dw : dw;
                 const int rad = ah > aw ? ah : aw;
-                const long q = (b * H + hi) * W + wi;
-                const float v = buf[q * cs + x_coff + c];
-                if (v > m[2]) { m[2] = v; mi[2] = q; }
-                if (rad <= 4 && v > m[1]) { m[1] = v; mi[1] = q; }
-                if (rad <= 2 && v > m[0]) { m[0] = v; mi[0] = q; }
+                const float v = buf[((b * H + hi) * W + wi) * cs + x_coff + c];
+                const int code = (dh + 6) * 13 + (dw + 6);
+                if (v > m[2]) { m[2] = v; mi[2] = code; }
+                if (rad <= 4 && v > m[1]) { m[1] = v; mi[1] = code; }
+                if (rad <= 2 && v > m[0]) { m[0] = v; mi[0] = code; }
             }
         }
-#pragma unroll
-        for (int l = 0; l < 3; ++l) atomicAdd(dbuf + mi[l] * cs + x_coff + c, dbuf[pix * cs + x_coff + (l + 1) * C + c]);
+        for (int l = 0; l < 3; ++l) arg[((long)l * B * H * W + pix) * C + c] = (uint8_t)mi[l];
+    }
+}
+
+__global__ __launch_bounds__(256) void sppf_pool_bwd_gather_kernel(const uint8_t *__restrict__ arg, float *__restrict__ dbuf, int B, int H, int W, int C,
+                                                                   int cs, int x_coff) {
+    const long items = (long)B * H * W * C, plane = (long)B * H * W;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C);
+        const long pix = it / C;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        float acc = dbuf[pix * cs + x_coff + c];
+        for (int l = 0; l < 3; ++l) {
+            const int R = 2 + 2 * l;
+            for (int dh = -R; dh <= R; ++dh) {                           // o = p + (dh, dw) points back at p when its code is (-dh, -dw)
+                const int ho = hv + dh;
+                if ((unsigned)ho >= (unsigned)H) continue;
+                for (int dw = -R; dw <= R; ++dw) {
+                    const int wo = wv + dw;
+                    if ((unsigned)wo >= (unsigned)W) continue;
+                    const long o = (b * H + ho) * W + wo;
+                    if (arg[((long)l * plane + o) * C + c] == (uint8_t)((6 - dh) * 13 + (6 - dw))) acc += dbuf[o * cs + x_coff + (l + 1) * C + c];
+                }
+            }
+        }
+        dbuf[pix * cs + x_coff + c] = acc;
     }
 }
 
@@ -645,9 +707,13 @@ extern "C" int somi_detect_raw_bwd_f32(const float *draw, float *dbox, int box_c
     return launch_status("somi_detect_raw_bwd_f32");
 }
 
-extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream) {
-    SOMI_REQUIRE(buf && dbuf && B > 0 && H > 0 && W > 0 && C > 0 && x_coff + 4 * C <= cs, SOMI_EINVAL, "sppf bwd: bad arguments");
-    hipLaunchKernelGGL(sppf_pool_bwd_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, buf, dbuf, B, H, W, C, cs, x_coff);
+extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, void *workspace, int B, int H, int W, int C, int cs, int x_coff,
+                                           somi_stream_t stream) {
+    SOMI_REQUIRE(buf && dbuf && workspace && B > 0 && H > 0 && W > 0 && C > 0 && x_coff + 4 * C <= cs, SOMI_EINVAL, "sppf bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *arg = static_cast<uint8_t *>(workspace);                    // 3*B*H*W*C bytes
+    hipLaunchKernelGGL(sppf_pool_argmax_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, s, buf, arg, B, H, W, C, cs, x_coff);
+    hipLaunchKernelGGL(sppf_pool_bwd_gather_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, s, arg, dbuf, B, H, W, C, cs, x_coff);
     return launch_status("somi_sppf_pool_bwd_nhwc_f32");
 }
 

@@ -115,61 +115,128 @@ __global__ __launch_bounds__(256) void odconv_synth_fwd_kernel(const float *__re
     }
 }
 
-// backward synthesis: one workgroup per (n, b); lanes sweep (t, c)
-__global__ __launch_bounds__(256) void odconv_synth_bwd_kernel(const float *__restrict__ dWb, const float *__restrict__ ws, const float *__restrict__ Wk,
-                                                               const float *__restrict__ biask, const float *__restrict__ dbias_b, float *dWk,
-                                                               float *dbiask, float *__restrict__ da, int Cin, int Cin_pad, int Cout, int kk, int K) {
-    __shared__ float red[4];
-    __shared__ float dsk[64];                                            // da_s partials per tap (kk <= 49)
-    __shared__ float dwk_s[16];
-    const int n = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int na = Cout + kk + Cin + K;
-    const float *at = ws + (long)b * na, *aw = at + Cout + kk + Cin;
-    float *dat = da + (long)b * na;
-    const long set = (long)Cout * kk * Cin_pad;
-    const float af = at[n];
-    if (tid < 64) dsk[tid] = 0.f;
-    if (tid < 16) dwk_s[tid] = 0.f;
-    __syncthreads();
-    float d_af = 0.f;
-    float d_aw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < kk * Cin; e += 256) {
-        const int t = e / Cin, c = e % Cin;
+// Backward of the synthesis  W_b[n,t,c] = a_f[b,n] a_s[b,t] a_c[b,c] sum_q a_w[b,q] Wk[q,n,t,c]  without atomics (run-to-run
+// bit-identical), in three kernels:
+//   candidates  one lane per 4 weights (n,t,c..c+3): dWk[q] += sum_b G a_f a_s a_c a_w[q], samples in ascending order; the lanes of
+//               (t=0,c=0) also own dbiask[q,n] += sum_b a_w[b,q] dbias_b[b,n]
+//   partials    one workgroup per (n, b) sweeps the (t, c) plane of G = dW_b and M = sum_q a_w Wk: da_f[b,n] is final here;
+//               P_s[b,n,t] = sum_c G M a_c, P_c[b,n,c] = sum_t G M a_s, P_w[b,n,q] = sum_{t,c} G a_s a_c Wk[q] go to the workspace
+//               (each lane owns whole (t-column, channel) runs, block sums are fixed-shape trees)
+//   finish      one workgroup per sample: da_s[t] = sum_n a_f P_s, da_c[c] = sum_n a_f P_c, da_w[q] = sum_n (a_f P_w + dbias_b biask[q]),
+//               n ascending
+__global__ __launch_bounds__(256) void odconv_synth_bwd_cand_kernel(const float *__restrict__ dWb, const float *__restrict__ ws, const float *__restrict__ biask,
+                                                                    const float *__restrict__ dbias_b, float *dWk, float *dbiask, int B, int Cin,
+                                                                    int Cin_pad, int Cout, int kk, int K) {
+    const int C4 = Cin_pad >> 2, na = Cout + kk + Cin + K;
+    const long per = (long)Cout * kk * C4, set = (long)Cout * kk * Cin_pad;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < per; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4, t = (int)((it / C4) % kk), n = (int)(it / ((long)C4 * kk));
         const long idx = ((long)n * kk + t) * Cin_pad + c;
-        const float G = dWb[(long)b * set + idx];
-        const float as = at[Cout + t], ac = at[Cout + kk + c];
-        float M = 0.f;
-        const float GP = G * af * as * ac;
-        for (int q = 0; q < K; ++q) {
-            const float wv = Wk[q * set + idx];
-            M += aw[q] * wv;
-            if (q < 8) d_aw[q] += GP * wv;
-            atomicAdd(dWk + q * set + idx, GP * aw[q]);
+        f32x4 acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool bias_lane = biask && t == 0 && c == 0;
+        for (int b = 0; b < B; ++b) {
+            const float *at = ws + (long)b * na, *aw = at + Cout + kk + Cin;
+            const float fs = at[n] * at[Cout + t];
+            f32x4 ac;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ac[e] = (c + e < Cin) ? at[Cout + kk + c + e] : 0.f;
+            const f32x4 gp = *reinterpret_cast<const f32x4 *>(dWb + (long)b * set + idx) * (fs * ac);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < K) acc[q] += gp * aw[q];
+            if (bias_lane) {
+                const float dbb = dbias_b[(long)b * Cout + n];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < K) bacc[q] += aw[q] * dbb;
+            }
         }
-        const float GM = G * M;
-        d_af += GM * as * ac;
-        atomicAdd(&dsk[t], GM * af * ac);
-        atomicAdd(dat + Cout + kk + c, GM * af * as);                     // da_c: summed over n by the atomics
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < K) {
+                float *o = dWk + q * set + idx;
+                *reinterpret_cast<f32x4 *>(o) = *reinterpret_cast<const f32x4 *>(o) + acc[q];
+                if (bias_lane) dbiask[q * Cout + n] += bacc[q];
+            }
+        }
     }
-    // block reductions
-    for (int o = 32; o > 0; o >>= 1) d_af += __shfl_down(d_af, o);
-    if ((tid & 63) == 0) red[tid >> 6] = d_af;
-    for (int q = 0; q < K && q < 8; ++q) {
-        float v = d_aw[q];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if ((tid & 63) == 0) atomicAdd(&dwk_s[q], v);
-    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *red /* >= 4 floats */) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads();                                                     // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (tid == 0) {
-        dat[n] = (red[0] + red[1]) + (red[2] + red[3]);                  // da_f[b,n]: this workgroup owns it
-        const float dbb = dbias_b ? dbias_b[(long)b * Cout + n] : 0.f;
-        for (int q = 0; q < K; ++q) {
-            float v = dwk_s[q];
-            if (biask) { v += dbb * biask[q * Cout + n]; atomicAdd(dbiask + q * Cout + n, aw[q] * dbb); }
-            atomicAdd(dat + Cout + kk + Cin + q, v);                      // da_w: summed over n
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void odconv_synth_bwd_part_kernel(const float *__restrict__ dWb, const float *__restrict__ ws, const float *__restrict__ Wk,
+                                                                    float *__restrict__ da, float *__restrict__ part, int Cin, int Cin_pad, int Cout,
+                                                                    int kk, int K) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int na = Cout + kk + Cin + K, np = kk + Cin + K;
+    const float *at = ws + (long)b * na, *aw = at + Cout + kk + Cin;
+    float *pb = part + ((long)b * Cout + n) * np;                        // [P_s (kk) | P_c (Cin) | P_w (K)]
+    const long set = (long)Cout * kk * Cin_pad;
+    float d_af = 0.f, d_aw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float pc[4] = {0.f, 0.f, 0.f, 0.f};                                  // a lane owns channels tid, tid+256, ... (Cin <= 1024): P_c needs no exchange
+    for (int t = 0; t < kk; ++t) {
+        const float as = at[Cout + t];
+        float pst = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            if (c < Cin) {
+                const float ac = at[Cout + kk + c];
+                const long idx = ((long)n * kk + t) * Cin_pad + c;
+                const float G = dWb[(long)b * set + idx];
+                float M = 0.f;
+                for (int q = 0; q < K; ++q) {
+                    const float wv = Wk[q * set + idx];
+                    M += aw[q] * wv;
+                    d_aw[q] += G * as * ac * wv;
+                }
+                const float GM = G * M;
+                d_af += GM * as * ac;
+                pst += GM * ac;
+                pc[i] += GM * as;
+            }
+        }
+        const float v = block_sum_256(pst, red);
+        if (tid == 0) pb[t] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (tid + 256 * i < Cin) pb[kk + tid + 256 * i] = pc[i];
+    const float f = block_sum_256(d_af, red);
+    if (tid == 0) da[(long)b * na + n] = f;                              // da_f[b,n]: this workgroup owns it
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (q < K) {
+            const float v = block_sum_256(d_aw[q], red);
+            if (tid == 0) pb[kk + Cin + q] = v;
         }
     }
-    if (tid < kk) atomicAdd(dat + Cout + tid, dsk[tid]);                  // da_s: summed over n
+}
+
+__global__ __launch_bounds__(256) void odconv_synth_bwd_finish_kernel(const float *__restrict__ ws, const float *__restrict__ part, const float *__restrict__ biask,
+                                                                      const float *__restrict__ dbias_b, float *__restrict__ da, int Cin, int Cout, int kk,
+                                                                      int K) {
+    const int b = blockIdx.x, na = Cout + kk + Cin + K, np = kk + Cin + K;
+    const float *at = ws + (long)b * na;
+    for (int i = threadIdx.x; i < np; i += 256) {                        // i indexes [da_s | da_c | da_w] exactly like the partial rows
+        float s = 0.f;
+        const bool is_w = i >= kk + Cin;
+        for (int n = 0; n < Cout; ++n) {
+            s += at[n] * part[((long)b * Cout + n) * np + i];
+            if (is_w && biask) s += dbias_b[(long)b * Cout + n] * biask[(i - kk - Cin) * Cout + n];
+        }
+        da[(long)b * na + Cout + i] = s;
+    }
 }
 
 static inline int ew_grid(long items) {
@@ -211,13 +278,19 @@ extern "C" int somi_odconv_synth_f32(const float *attn, const float *Wk, const f
     return launch_status("somi_odconv_synth_f32");
 }
 
+extern "C" size_t somi_odconv_synth_bwd_workspace_floats(int B, int Cin, int Cout, int kk, int K) { return (size_t)B * Cout * (kk + Cin + K); }
+
 extern "C" int somi_odconv_synth_bwd_f32(const float *dWb, const float *attn, const float *Wk, const float *biask, const float *dbias_b, float *dWk,
-                                         float *dbiask, float *dattn, int B, int Cin, int Cin_pad, int Cout, int kk, int K, somi_stream_t stream) {
-    SOMI_REQUIRE(dWb && attn && Wk && dWk && dattn && B > 0 && Cin > 0 && Cin_pad >= Cin && Cout > 0 && kk > 0 && kk <= 64 && K > 0 && K <= 8, SOMI_EINVAL,
-                 "odconv synth bwd: bad arguments (K <= 8, kk <= 64)");
+                                         float *dbiask, float *dattn, float *workspace, int B, int Cin, int Cin_pad, int Cout, int kk, int K,
+                                         somi_stream_t stream) {
+    SOMI_REQUIRE(dWb && attn && Wk && dWk && dattn && workspace && B > 0 && Cin > 0 && Cin_pad >= Cin && Cin_pad % 4 == 0 && Cout > 0 && kk > 0 &&
+                     kk <= 64 && K > 0 && K <= 8 && Cin <= 1024 && aligned16(dWb) && aligned16(dWk), SOMI_EINVAL,
+                 "odconv synth bwd: bad arguments (K <= 8, kk <= 64, Cin <= 1024)");
     SOMI_REQUIRE(!biask || (dbias_b && dbiask), SOMI_EINVAL, "odconv synth bwd: bias gradients missing");
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(dattn, 0, (size_t)B * (Cout + kk + Cin + K) * 4, s);
-    hipLaunchKernelGGL(odconv_synth_bwd_kernel, dim3(Cout, B), dim3(256), 0, s, dWb, attn, Wk, biask, dbias_b, dWk, dbiask, dattn, Cin, Cin_pad, Cout, kk, K);
+    hipLaunchKernelGGL(odconv_synth_bwd_cand_kernel, dim3(ew_grid((long)Cout * kk * (Cin_pad / 4))), dim3(256), 0, s, dWb, attn, biask, dbias_b, dWk, dbiask,
+                       B, Cin, Cin_pad, Cout, kk, K);
+    hipLaunchKernelGGL(odconv_synth_bwd_part_kernel, dim3(Cout, B), dim3(256), 0, s, dWb, attn, Wk, dattn, workspace, Cin, Cin_pad, Cout, kk, K);
+    hipLaunchKernelGGL(odconv_synth_bwd_finish_kernel, dim3(B), dim3(256), 0, s, attn, workspace, biask, dbias_b, dattn, Cin, Cout, kk, K);
     return launch_status("somi_odconv_synth_bwd_f32");
 }

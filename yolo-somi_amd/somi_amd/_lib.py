@@ -101,14 +101,15 @@ SIGNATURES = {
     'somi_spatial_attn_bwd_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, S]),
     'somi_cbam_bwd_chan_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, I, I, I, S]),
     'somi_pool_argmax_nhwc_f32': (I, [P, I, I, I, I, I, P, P, S]),
-    'somi_attn_mlp_bwd_f32': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    'somi_attn_mlp_bwd_workspace_floats': (Z, [I, I, I]),
+    'somi_attn_mlp_bwd_f32': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
     'somi_pool_bwd_add_nhwc_f32': (I, [P, I, I, P, P, P, I, I, I, S]),
     'somi_detect_raw_bwd_f32': (I, [P, P, I, P, I, I, I, I, I, I, S]),
     'somi_resample_slice_nhwc_f32': (I, [P, I, I, P, I, I, I, I, I, I, I, I, I, S]),
     'somi_space_to_depth_nhwc_f32': (I, [P, I, I, P, I, I, I, I, I, I, I, S]),
     'somi_detect_plain_decode_f32': (I, [P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
     'somi_detect_plain_raw_bwd_f32': (I, [P, P, I, I, I, I, I, I, S]),
-    'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, I, I, I, I, I, I, S]),
+    'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, P, I, I, I, I, I, I, S]),
     'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), P, F, I, P, P, P, I, I, I, I, S]),
     'somi_dwconv3x3_bwd_workspace_floats': (Z, [I, I, I]),
     'somi_dwconv3x3_bwd_nhwc_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, S]),
@@ -116,7 +117,8 @@ SIGNATURES = {
     'somi_linear_f32': (I, [P, I, P, P, I, P, I, I, I, I, I, S]),
     'somi_linear_bwd_f32': (I, [P, I, P, P, P, I, I, I, P, P, P, I, I, P, I, I, I, S]),
     'somi_odconv_synth_f32': (I, [P, P, P, P, P, I, I, I, I, I, I, S]),
-    'somi_odconv_synth_bwd_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, S]),
+    'somi_odconv_synth_bwd_workspace_floats': (Z, [I, I, I, I, I]),
+    'somi_odconv_synth_bwd_f32': (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, S]),
     'somi_adam_ema_step_f32': (I, [P, P, P, P, P, C.c_long, F, F, F, F, F, I, F, S]),
     'somi_pack_dgrad_weights_f32': (I, [P, P, I, I, I, S]),
     'somi_axpby_f32': (I, [P, P, C.c_long, F, F, S]),

@@ -506,8 +506,10 @@ def attn_mlp_backward(mode, dout, out, avg, mx, W1, b1, W2, dW1, db1, dW2, db2):
     B, Cc = avg.shape
     davg = torch.empty_like(avg)
     dmax = torch.empty_like(avg) if mode == 0 else None
-    check(_lib.lib().somi_attn_mlp_bwd_f32(mode, _ptr(dout), _ptr(out), _ptr(avg), _ptr(mx), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(dW1),
-                                           _ptr(db1), _ptr(dW2), _ptr(db2), _ptr(davg), _ptr(dmax), B, Cc, W1.shape[0], _stream()),
+    L = _lib.lib()
+    ws = torch.empty(L.somi_attn_mlp_bwd_workspace_floats(B, Cc, W1.shape[0]), device=avg.device, dtype=torch.float32)
+    check(L.somi_attn_mlp_bwd_f32(mode, _ptr(dout), _ptr(out), _ptr(avg), _ptr(mx), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(dW1),
+                                  _ptr(db1), _ptr(dW2), _ptr(db2), _ptr(davg), _ptr(dmax), _ptr(ws), B, Cc, W1.shape[0], _stream()),
           'attn_mlp_bwd')
     return davg, dmax
 
@@ -530,7 +532,8 @@ def detect_raw_backward(draw, box_cs, cls_cs, na, nc):
 
 def sppf_pool_backward_(buf, dbuf, c, x_coff=0):
     B, H, W, cs = buf.shape
-    check(_lib.lib().somi_sppf_pool_bwd_nhwc_f32(_ptr(_f32c(buf)), _ptr(_f32c(dbuf)), B, H, W, c, cs, x_coff, _stream()), 'sppf_pool_bwd')
+    ws = torch.empty(3 * B * H * W * c, device=buf.device, dtype=torch.uint8)
+    check(_lib.lib().somi_sppf_pool_bwd_nhwc_f32(_ptr(_f32c(buf)), _ptr(_f32c(dbuf)), _ptr(ws), B, H, W, c, cs, x_coff, _stream()), 'sppf_pool_bwd')
     return dbuf
 
 
@@ -597,6 +600,8 @@ def odconv_synth(attn, Wk, biask, cin, cin_pad, cout, kk, K):
 def odconv_synth_backward(dWb, attn, Wk, biask, dbias_b, dWk, dbiask, cin, cin_pad, cout, kk, K):
     B = attn.shape[0]
     dattn = torch.empty_like(attn)
-    check(_lib.lib().somi_odconv_synth_bwd_f32(_ptr(_f32c(dWb)), _ptr(attn), _ptr(Wk), _ptr(biask), _ptr(dbias_b), _ptr(dWk), _ptr(dbiask),
-                                               _ptr(dattn), B, cin, cin_pad, cout, kk, K, _stream()), 'odconv_synth_bwd')
+    L = _lib.lib()
+    ws = torch.empty(L.somi_odconv_synth_bwd_workspace_floats(B, cin, cout, kk, K), device=attn.device, dtype=torch.float32)
+    check(L.somi_odconv_synth_bwd_f32(_ptr(_f32c(dWb)), _ptr(attn), _ptr(Wk), _ptr(biask), _ptr(dbias_b), _ptr(dWk), _ptr(dbiask),
+                                      _ptr(dattn), _ptr(ws), B, cin, cin_pad, cout, kk, K, _stream()), 'odconv_synth_bwd')
     return dattn
