@@ -272,6 +272,80 @@ def gen_stock():
          nlayers=np.int64(len(list(full.modules()))), stride=full.stride, anchors=full.model[-1].anchors)
 
 
+# ------------------------------------------------------------------------------------------------ DCNv3 module + graph wiring
+def _ref_dcn_yolo_class():
+    """DCNv3 -> BN -> SiLU around the reference's own `DCNv3_pytorch` module (models/ops_dcnv3/modules/dcnv3.py:95-219).  The
+    reference wires DCNv3 into no graph; this wrapper is the harness's statement of the build's wiring, so that
+    the reference's Model / parse_model (generic branch, models/yolo.py:1647-1648: channels pass through, yaml args verbatim) can
+    build the whole graph around the reference's module."""
+    from models.ops_dcnv3.modules.dcnv3 import DCNv3_pytorch
+
+    class DCNv3_YOLO(nn.Module):
+        def __init__(self, c, k=3, s=1, g=4, offset_scale=1.0, center_feature_scale=False):
+            super().__init__()
+            self.dcnv3 = DCNv3_pytorch(c, kernel_size=k, stride=s, pad=k // 2, group=g, offset_scale=offset_scale,
+                                       center_feature_scale=center_feature_scale)
+            self.bn = nn.BatchNorm2d(c)
+            self.act = nn.SiLU()
+
+        def forward(self, x):
+            return self.act(self.bn(self.dcnv3(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)))
+    return DCNv3_pytorch, DCNv3_YOLO
+
+
+def gen_dcn():
+    import warnings
+    warnings.simplefilter('ignore')
+    RefDCN, RefDCNYolo = _ref_dcn_yolo_class()
+    g = torch.Generator().manual_seed(800)
+    # the module itself (NHWC in / out), forward + every gradient, with and without the centre feature scale
+    for tag, cfs, C, G, osc in (('plain', False, 32, 4, 1.0), ('cfs', True, 32, 4, 2.0), ('g8', False, 64, 8, 1.0)):
+        m = RefDCN(C, kernel_size=3, stride=1, pad=1, group=G, offset_scale=osc, center_feature_scale=cfs)
+        fill_state(m, 11)
+        x = torch.randn(2, 9, 11, C, generator=g, requires_grad=True)
+        y = m(x)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        rec = dict(x=x, y=y, dy=dy, dx=x.grad, cfg=np.array([C, G, int(cfs)]), offset_scale=np.float64(osc))
+        for n, p in m.named_parameters():
+            rec['grad.' + n] = p.grad
+        save(f'dcnv3_module_{tag}', **rec)
+    # the wired block: eval and train-mode forward
+    run_block('dcnv3_yolo', RefDCNYolo(32, 3, 1, 4), torch.randn(2, 32, 10, 12, generator=g), seed=2)
+    # the whole SOMI graph with the two DCNv3 sites, built by the reference's Model (width 0.25: 64 channels, 8 groups of 8)
+    RY.DCNv3_YOLO = RefDCNYolo
+    cfg = somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS, dcn=True)
+    for l in cfg['head']:
+        if l[2] == 'DCNv3_YOLO':
+            l[3][0] = 64                                         # the reference's generic branch passes yaml args verbatim
+    m = RY.Model(cfg)
+    fill_state(m, 1)
+    B, S = 2, 64
+    x = torch.rand(B, 3, S, S, generator=g)
+    m.eval()
+    with torch.no_grad():
+        z, raw = m(x.clone())
+    rec = dict(x=x, z=z, stride=m.stride, nparams=np.int64(sum(p.numel() for p in m.parameters())))
+    for i, t in enumerate(raw):
+        rec[f'raw{i}'] = t
+    m.train()
+    m.hyp = dict(HYP_VISDRONE)
+    m.zero_grad()
+    _, targets = synthetic_batch(B, S, seed=9)
+    tr = m(x.clone())
+    loss, items = RefComputeLoss(m)(tr, targets)
+    loss.backward()
+    for i, t in enumerate(tr):
+        rec[f'train{i}'] = t
+    rec.update(targets=targets, loss=loss, loss_items=items)
+    names = [n for n, p in m.named_parameters() if p.grad is not None and ('dcnv3' in n or n.startswith('model.10.') or n.startswith('model.2.cv1'))]
+    rec['grad_names'] = np.array(names)
+    pd = dict(m.named_parameters())
+    for i, n in enumerate(names):
+        rec[f'grad{i}'] = pd[n].grad
+    save('model_w025_dcn', **rec)
+
+
 # ------------------------------------------------------------------------------------------------ loss
 def gen_loss():
     m = build_ref_model(0.25, 0.33, SOMI_ANCHORS)
@@ -489,6 +563,6 @@ def gen_augment():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'stock', 'loss', 'nms', 'val', 'augment']
+    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'stock', 'dcn', 'loss', 'nms', 'val', 'augment']
     for w in which:
         globals()[f'gen_{w}']()

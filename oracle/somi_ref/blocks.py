@@ -15,7 +15,7 @@ __all__ = [
     'C2fCBAM', 'SPPF', 'Swish', 'BiFPN', 'ODConv2d_3rd', 'ODConv_3rd', 'Residual', 'SEAM',
     'Decouple', 'DecoupledDetect', 'fuse_conv_and_bn', 'initialize_weights',
     'check_anchor_order', 'make_divisible',
-    'Bottleneck', 'C3', 'SPP', 'Focus', 'Concat', 'Detect',
+    'Bottleneck', 'C3', 'SPP', 'Focus', 'Concat', 'Detect', 'DCNv3_YOLO',
 ]
 
 
@@ -470,6 +470,24 @@ class Detect(nn.Module):
                 wh = (y[..., 2:4] * 2) ** 2 * self.anchor_grid[i]
                 z.append(torch.cat((xy, wh, y[..., 4:]), -1).view(bs, -1, self.no))
         return x if self.training else (torch.cat(z, 1), x)
+
+
+# ---------------------------------------------------------------------------------------------- DCNv3 wired into a graph
+class DCNv3_YOLO(nn.Module):
+    """The build's wiring of the reference's DCNv3 layer into an NCHW YOLO graph (the reference vendors models/ops_dcnv3 but wires
+    it into no model, SURVEY fact 3 / section 7 "hard parts"): NCHW -> NHWC -> DCNv3 (modules/dcnv3.py:222-379) -> NCHW ->
+    BatchNorm2d -> SiLU, channel-preserving.  `c` is nominal in a yaml (parse_model substitutes the incoming width)."""
+
+    def __init__(self, c, k=3, s=1, g=4, offset_scale=1.0, center_feature_scale=False):
+        super().__init__()
+        from .dcnv3 import DCNv3
+        self.dcnv3 = DCNv3(c, kernel_size=k, stride=s, pad=k // 2, group=g, offset_scale=offset_scale,
+                           center_feature_scale=center_feature_scale)
+        self.bn = nn.BatchNorm2d(c)
+        self.act = nn.SiLU()
+
+    def forward(self, x):
+        return self.act(self.bn(self.dcnv3(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)))
 
 
 def fuse_conv_and_bn(conv, bn):

@@ -55,6 +55,10 @@ def parse_model(d, ch):
         elif name == 'nn.Upsample':
             m = nn.Upsample
             c2 = ch[f]
+        elif name == 'DCNv3_YOLO':                                    # the reference's generic branch (:1647-1648): channels pass through
+            m = B.DCNv3_YOLO
+            c2 = ch[f]
+            args = [c2, *args[1:]]
         elif name == 'Concat':                                        # :1589-1591
             m = B.Concat
             c2 = sum(ch[x] for x in f)

@@ -87,8 +87,13 @@ def synthetic_image_set(img_size, n=6, seed=0):
     return imgs, labels
 
 
-def somi_cfg(width=1.0, depth=1.0, nc=10, anchors=4):
-    """The layer table of models/modules/YOLO-SOMI.yaml as a dict (C2fEACBAM -> C2fCBAM)."""
+def somi_cfg(width=1.0, depth=1.0, nc=10, anchors=4, dcn=False, dcn_group=8):
+    """The layer table of models/modules/YOLO-SOMI.yaml as a dict (C2fEACBAM -> C2fCBAM).
+
+    dcn=True: "yolov5l-SOMI (DCNv3 blocks)" of BASELINE configs[1].  The reference vendors DCNv3 but wires it into no yaml (SURVEY
+    fact 3), so the sites are the build's choice: one DCNv3_YOLO block (DCNv3 -> BN -> SiLU, 3x3, `dcn_group` groups) behind each of
+    the two high-resolution lateral convs of the neck - P2 (160x160 at 640) and P3 (80x80), 256 channels: the representative
+    shapes of SURVEY section 8a row F10.  Later layers shift by one / two; their `from` indices are rewritten accordingly."""
     bb = [[-1, 1, 'Conv', [64, 3, 2]], [-1, 1, 'ODConv_3rd', [128, 3, 2, 4]], [-1, 3, 'C2fCBAM', [128, True]],
           [-1, 1, 'Conv', [256, 3, 2]], [-1, 6, 'C2fCBAM', [256, True]], [-1, 1, 'Conv', [512, 3, 2]],
           [-1, 6, 'C2fCBAM', [512, True]], [-1, 1, 'Conv', [1024, 3, 2]], [-1, 3, 'C2fCBAM', [1024, True]],
@@ -103,8 +108,19 @@ def somi_cfg(width=1.0, depth=1.0, nc=10, anchors=4):
           [-1, 1, 'ODConv_3rd', [256, 3, 2, 4]], [[-1, 13], 1, 'BiFPN', []], [-1, 3, 'C2fCBAM', [1024]],
           [[25, 28, 31, 34], 1, 'DecoupledDetect', ['nc', 'anchors']]]
     import copy
-    return dict(nc=nc, depth_multiple=depth, width_multiple=width, anchors=copy.deepcopy(anchors),
-                backbone=copy.deepcopy(bb), head=copy.deepcopy(hd))
+    bb, hd = copy.deepcopy(bb), copy.deepcopy(hd)
+    if dcn:
+        layers = bb + hd
+        for after in (11, 10):                                   # insert behind layer 11 first, so that index 10 stays valid
+            for l in layers:                                     # absolute references to later layers move up by one
+                l[0] = [j + 1 if j > after else j for j in l[0]] if isinstance(l[0], list) else (l[0] + 1 if l[0] > after else l[0])
+            layers.insert(after + 1, [after, 1, 'DCNv3_YOLO', [256, 3, 1, dcn_group]])
+        # the lateral convs' other consumers (the BiFPN inputs) now read the DCNv3 output: references to 10 / 11 move to 11 / 13
+        for l in layers:
+            if l[2] != 'DCNv3_YOLO':
+                l[0] = [{10: 11, 12: 13}.get(j, j) for j in l[0]] if isinstance(l[0], list) else {10: 11, 12: 13}.get(l[0], l[0])
+        bb, hd = layers[:len(bb)], layers[len(bb):]
+    return dict(nc=nc, depth_multiple=depth, width_multiple=width, anchors=copy.deepcopy(anchors), backbone=bb, head=hd)
 
 
 COCO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]

@@ -158,3 +158,130 @@ def test_dcnv3_module_backward_matches_oracle(cfs):
         got, want = p.grad.cpu().double(), q.grad.double()
         err, scale = (got - want).abs().max().item(), want.abs().max().item()
         assert err <= 1e-3 * scale + 1e-6, f'd{n}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+# ---------------------------------------------------------------------------------------------- DCNv3 wired into the graph (J2)
+T = torch.from_numpy
+
+
+@pytest.mark.parametrize('tag', ['plain', 'cfs', 'g8'])
+def test_dcnv3_module_matches_reference_module_vectors(golden, tag):
+    """The HIP DCNv3 layer against the reference's own `DCNv3_pytorch` module (models/ops_dcnv3/modules/dcnv3.py:95-219): output,
+    input gradient, every parameter gradient."""
+    from oracle.somi_ref.dcnv3 import DCNv3 as ODCN
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd.dcnv3 import DCNv3
+    g = golden('dcnv3_module_' + tag)
+    C, G, cfs = (int(v) for v in g['cfg'])
+    kw = dict(kernel_size=3, stride=1, pad=1, group=G, offset_scale=float(g['offset_scale']), center_feature_scale=bool(cfs))
+    mod = DCNv3(C, **kw)
+    mod.load_state_dict(fill_state(ODCN(C, **kw), 11).state_dict())
+    mod = mod.cuda().train()
+    x = T(g['x']).cuda().requires_grad_(True)
+    y = mod(x)
+    rel_close(y, T(g['y']), what='module output')
+    y.backward(T(g['dy']).cuda())
+    rel_close(x.grad, T(g['dx']), what='d input')
+    for n, p in mod.named_parameters():
+        want = T(g['grad.' + n]).double()
+        err = (p.grad.cpu().double() - want).abs().max().item()
+        assert err <= 1e-3 * want.abs().max().item() + 1e-6, f'd{n}: {err:.3e}'
+
+
+def test_dcnv3_yolo_block_forward_backward(golden):
+    """DCNv3 -> BN -> SiLU: eval (BN folded into the output projection) and train outputs against the block built around the
+    reference's module, then the hand-written backward against autograd of the oracle block."""
+    import torch.nn as nn
+    from oracle.somi_ref import blocks as OB
+    from oracle.somi_ref.testing import fill_state
+    from somi_amd import blocks as MB
+    g = golden('block_dcnv3_yolo')
+    ref = fill_state(OB.DCNv3_YOLO(32, 3, 1, 4), 2)
+    OB.initialize_weights(ref)
+    mine = MB.DCNv3_YOLO(32, 3, 1, 4)
+    mine.load_state_dict(ref.state_dict())
+    mine.bn.eps, mine.bn.momentum = 1e-3, 0.03
+    mine = mine.cuda()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()          # noqa: E731
+    x = MB.Act(nhwc(T(g['in0'])).cuda())
+    for mode in ('eval', 'train'):
+        mine.train(mode == 'train')
+        with torch.no_grad():
+            out = mine(x)
+        rel_close(out.t, nhwc(T(g[f'out_{mode}'])), what=f'DCNv3_YOLO {mode}')
+    ref = fill_state(OB.DCNv3_YOLO(32, 3, 1, 4), 2).train()      # fresh running statistics on both sides
+    OB.initialize_weights(ref)
+    mine.load_state_dict(ref.state_dict())
+    mine.train()
+    gen = torch.Generator().manual_seed(6)
+    xr = torch.randn(3, 32, 9, 13, generator=gen, requires_grad=True)
+    y = ref(xr)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    out = mine(MB.Act(nhwc(xr.detach()).cuda()))
+    rel_close(out.t, nhwc(y), what='train forward')
+    dx = mine.backward(MB.Act(nhwc(dy).cuda()))
+    rel_close(dx.t, nhwc(xr.grad), what='dx')
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        err, scale = (p.grad.cpu().double() - q.grad.double()).abs().max().item(), q.grad.abs().max().item()
+        # the output projection's bias sits in front of a batch-statistics BatchNorm: its gradient is zero in exact arithmetic,
+        # what both sides hold is rounding noise of the size of the cancelling terms
+        atol = 1e-4 if n.endswith('output_proj.bias') else 2e-6
+        assert err <= 1e-3 * scale + atol, f'd{n}: max err {err:.3e} vs scale {scale:.3e}'
+    for n in ('running_mean', 'running_var'):
+        rel_close(getattr(mine.bn, n), getattr(ref.bn, n), what=n)
+    assert isinstance(mine.bn, nn.BatchNorm2d)
+
+
+def test_somi_graph_with_dcnv3_sites_matches_reference_vectors(golden):
+    """The SOMI graph with its two DCNv3 sites (BASELINE configs[1] "yolov5l-SOMI (DCNv3 blocks)", here at width 0.25) against the
+    numbers of the reference's own Model built around the reference's DCNv3 module: eval predictions, train-mode outputs, the
+    reference ComputeLoss and the gradients of every DCNv3-site parameter."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg
+    from somi_amd.loss import ComputeLoss
+    from somi_amd.model import Model
+    g = golden('model_w025_dcn')
+    cfg = somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS, dcn=True)
+    mine = Model(cfg)
+    assert sum(p.numel() for p in mine.parameters()) == int(g['nparams'])
+    mine.load_state_dict(fill_state(OModel(cfg), 1).state_dict())
+    mine = mine.cuda().eval()
+    x = T(g['x']).cuda()
+    with torch.no_grad():
+        z, raw = mine(x)
+    rel_close(z, T(g['z']), what='z')
+    for i, r in enumerate(raw):
+        rel_close(r, T(g[f'raw{i}']), what=f'raw{i}')
+    mine.train()
+    mine.hyp = dict(HYP_VISDRONE)
+    tr = mine(x)
+    for i, r in enumerate(tr):
+        rel_close(r, T(g[f'train{i}']), what=f'train{i}')
+    loss, items = ComputeLoss(mine)(tr, T(g['targets']).cuda())
+    rel_close(loss, T(g['loss']).reshape(1), rel=1e-4, what='loss')
+    loss.backward()
+    pd = dict(mine.named_parameters())
+    for i, n in enumerate(g['grad_names']):
+        want = T(g[f'grad{i}']).double()
+        err = (pd[str(n)].grad.cpu().double() - want).abs().max().item()
+        assert err <= 2e-3 * want.abs().max().item() + 2e-6, f'd{n}: {err:.3e} vs scale {want.abs().max().item():.3e}'
+
+
+@pytest.mark.parametrize('S', [640, 1280])
+def test_full_width_dcn_graph_sites_at_80_and_160(S):
+    """Full-width graph with DCNv3 at its real shapes (256 channels, 8 groups of 32): sites at 160x160 and 80x80 for a 640 image,
+    320x320 and 160x160 at 1280 (BASELINE configs[3]); one image, eval predictions against the CPU oracle."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg
+    from somi_amd.model import Model
+    cfg = somi_cfg(1.0, 1.0, nc=3 if S == 1280 else 10, anchors=SOMI_ANCHORS, dcn=True)
+    ref = fill_state(OModel(cfg), 4).eval()
+    mine = Model(cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda().eval()
+    x = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(S))
+    with torch.no_grad():
+        zr, _ = ref(x)
+        z, _ = mine(x.cuda())
+    rel_close(z, zr, what=f'z @{S} with DCNv3 sites')

@@ -646,3 +646,66 @@ def test_training_step_is_bit_reproducible(graph):
     for key in ('params', 'm', 'v', 'ema'):
         for gi, st in enumerate(tr.optimizer._flat):
             assert torch.equal(a[key][gi], b[key][gi]), f'{key} of ' + first_difference(a[key][gi], b[key][gi], st)
+
+
+def test_uavdt_1280_nc3_training_step_gradients():
+    """BASELINE configs[3] per-GPU shape: full-width SOMI, nc=3 (UAVDT), 1280x1280 - grids 320/160/80/40 - one training step at batch 2
+    (the squeeze BN of ODConv needs more than one sample): loss against the fp64 CPU oracle at 1e-4, train-mode outputs within 4x of
+    the fp32 CPU oracle's own distance from fp64 (36 layers deep, both fp32 paths sit 1e-3 ... 3e-3 of the output range from fp64),
+    and every parameter gradient judged as in test_full_width_model_train_step_gradients: nothing O(1) anywhere, and the population of
+    relative errors (against fp64) within a small factor of what the fp32 CPU oracle itself is off."""
+    import copy
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.loss import ComputeLoss as OLoss
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    from somi_amd.model import Model
+    torch.set_num_threads(16)
+    cfg = somi_cfg(1.0, 1.0, nc=3, anchors=SOMI_ANCHORS)
+    ref = fill_state(OModel(cfg), 6)
+    mine = Model(cfg)
+    mine.load_state_dict(ref.state_dict())
+    ref.hyp = mine.hyp = dict(HYP_VISDRONE)
+    ref64 = copy.deepcopy(ref).double()
+    imgs, targets = synthetic_batch(2, 1280, nc=3, seed=14)
+    mine = mine.cuda().train()
+    pm = mine(imgs.cuda())
+    lm, im = ComputeLoss(mine)(pm, targets.cuda())
+    lm.backward()
+    torch.cuda.synchronize()
+    assert [tuple(p.shape) for p in pm] == [(2, 4, g, g, 8) for g in (320, 160, 80, 40)]
+    ref64.train()
+    p64 = ref64(imgs.double() / 255)
+    l64, _ = OLoss(ref64)(p64, targets.double())
+    l64.backward()
+    rel_close(lm, l64.detach().float(), rel=1e-4, what='loss @1280 nc=3')
+    ref.train()
+    p32 = ref(imgs.float() / 255)
+    l32, _ = OLoss(ref)(p32, targets)
+    l32.backward()
+    for a, b32, b64 in zip(pm, p32, p64):
+        b64 = b64.detach()
+        scale = b64.abs().max().item()
+        e_mine = (a.detach().cpu().double() - b64).abs().max().item() / scale
+        e_o32 = (b32.detach().double() - b64).abs().max().item() / scale
+        assert e_mine <= max(4 * e_o32, 1e-3), f'train outputs @1280: HIP {e_mine:.2e} vs fp32 CPU {e_o32:.2e} (relative to fp64)'
+    del p64, p32
+    rel_mine, rel_o32, bad = [], [], []
+    for (n, p), (_, q32), (_, q64) in zip(mine.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+        if q64.grad is None:
+            continue
+        assert p.grad is not None, n
+        g64 = q64.grad
+        scale = g64.abs().max().item() + 1e-12
+        if scale < 1e-4:
+            continue
+        rel_mine.append((p.grad.cpu().double() - g64).abs().max().item() / scale)
+        rel_o32.append((q32.grad.double() - g64).abs().max().item() / scale)
+        if rel_mine[-1] > 0.5:
+            bad.append((n, rel_mine[-1], rel_o32[-1]))
+    assert not bad, bad[:8]
+    rm, ro = torch.tensor(rel_mine), torch.tensor(rel_o32)
+    print(f'1280 nc=3: HIP median {float(rm.median()):.2e} q90 {float(rm.quantile(0.9)):.2e} max {float(rm.max()):.2e}; '
+          f'fp32 CPU median {float(ro.median()):.2e} q90 {float(ro.quantile(0.9)):.2e} max {float(ro.max()):.2e}')
+    assert rm.median() <= max(4 * float(ro.median()), 1e-2), (float(rm.median()), float(ro.median()))
+    assert rm.quantile(0.9) <= max(4 * float(ro.quantile(0.9)), 3e-2), (float(rm.quantile(0.9)), float(ro.quantile(0.9)))

@@ -216,12 +216,15 @@ __global__ __launch_bounds__(256) void global_pool_stage2(const float *__restric
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * C) return;
     const int b = i / C, c = i % C;
-    float s = 0.f, m = -__builtin_huge_valf();
+    // the chunk partials are folded in double: at 1280x1280 a channel's mean is the sum of 1600 partials, and ODConv's squeeze
+    // BatchNorm over a batch of two turns the DIFFERENCE of two such means into an O(1) signal (tools/layer_drift.py)
+    double s = 0.0;
+    float m = -__builtin_huge_valf();
     for (int k = 0; k < nchunk; ++k) {
-        s += part_sum[((long)b * nchunk + k) * C + c];
+        s += (double)part_sum[((long)b * nchunk + k) * C + c];
         m = fmaxf(m, part_max[((long)b * nchunk + k) * C + c]);
     }
-    out_avg[i] = s * inv_hw;
+    out_avg[i] = (float)(s * (double)inv_hw);
     if (out_max) out_max[i] = m;
 }
 

@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256) void img_partial_sum_kernel(const float *__res
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * C) return;
     const int b = i / C, c = i % C;
-    float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += part[((long)b * nchunk + k) * C + c];
-    out[i] = s;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += (double)part[((long)b * nchunk + k) * C + c];
+    out[i] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------ D

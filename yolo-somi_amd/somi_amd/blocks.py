@@ -1119,3 +1119,61 @@ class Detect(nn.Module):
         widths = self.__dict__.pop('_ctx')
         return [run.backward(ops.detect_plain_raw_backward(draws[i].contiguous(), widths[i], self.na, self.nc))
                 for i, run in enumerate(self._runners)]
+
+
+# ================================================================================================ DCNv3 wired into a graph
+class DCNv3_YOLO(_Packed):
+    """NHWC DCNv3 layer (models/ops_dcnv3/modules/dcnv3.py:222-379) -> BatchNorm2d -> SiLU, channel-preserving: the build's wiring
+    of the reference's deformable-conv layer into the YOLO graph (the reference wires it into no model).  The
+    activations are already NHWC on this path, so the NCHW<->NHWC permutes of an NCHW graph do not exist.  Eval: BN is folded into
+    the layer's output projection (+SiLU in that conv's epilogue): no pass of its own.  Train: the DCNv3 module's hand-written
+    backward (somi_amd.dcnv3.DCNv3._backward_impl) is chained with the BN / SiLU backward kernel."""
+
+    def __init__(self, c, k=3, s=1, g=4, offset_scale=1.0, center_feature_scale=False):
+        super().__init__()
+        from .dcnv3 import DCNv3
+        if s != 1:
+            raise NotImplementedError('DCNv3_YOLO is wired with stride 1')
+        self.dcnv3 = DCNv3(c, kernel_size=k, stride=s, pad=k // 2, group=g, offset_scale=offset_scale,
+                           center_feature_scale=center_feature_scale)
+        self.bn = nn.BatchNorm2d(c)
+        self.act = nn.SiLU()
+
+    def _pack(self, dev):
+        """eval: output projection with the BatchNorm folded in (W' = diag(s) W, b' = s b + t)."""
+        s_, t_ = bn_fold(self.bn)
+        w = (self.dcnv3.output_proj.weight.detach().float() * s_[:, None]).contiguous().to(dev)
+        b = (self.dcnv3.output_proj.bias.detach().float() * s_ + t_).contiguous().to(dev)
+        return w, b
+
+    def forward(self, x):
+        c = self.bn.num_features
+        if x.coff != 0 or x.t.shape[3] != c or x.c != c or c % 4:
+            raise NotImplementedError('DCNv3_YOLO input must be a whole tensor with channels a multiple of 4')
+        if not self.training:
+            w, b = self._packed(x.t.device)
+            return Act(self.dcnv3._forward_impl(x.t, out_proj=(w, b, _act_name(self.act))), 0, c)
+        self.invalidate()
+        u, saved = self.dcnv3._forward_impl(x.t, keep=True)
+        bn, dev = self.bn, x.t.device
+        rm, rv = bn.running_mean.detach().clone(), bn.running_var.detach().clone()
+        st = ops.bn_stats(u, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv)
+        with torch.no_grad():
+            bn.running_mean.copy_(rm)
+            bn.running_var.copy_(rv)
+            _bump_batches_tracked(bn)
+        out = ops.chan_affine_act(u, c, 0, st[2], st[3], _act_name(self.act), 0, torch.empty_like(u))
+        self.__dict__['_ctx'] = (u, st, saved)
+        return Act(out, 0, c)
+
+    def backward(self, dz, need_dx=True):
+        u, st, saved = self.__dict__.pop('_ctx')
+        c, dev = self.bn.num_features, u.device
+        dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+        du = ops.bn_act_backward(dz.t, dz.coff, u, 0, c, *st, _act_name(self.act), 0, True, torch.empty_like(u), 0, dg, db)
+        _acc_grad(self.bn.weight, dg)
+        _acc_grad(self.bn.bias, db)
+        dinput, grads = self.dcnv3._backward_impl(saved, du)
+        for p_, g_ in zip(self.dcnv3._params(), grads):
+            _acc_grad(p_, g_.view_as(p_) if g_.numel() == p_.numel() else g_[:p_.shape[0]])
+        return Act(dinput, 0, c) if need_dx else None

@@ -131,9 +131,11 @@ class DCNv3(nn.Module):
             ps += [self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias]
         return ps
 
-    def _forward_impl(self, input, keep=False):
+    def _forward_impl(self, input, keep=False, out_proj=None):
         """Every arithmetic step runs in libsomi_hip.so: 4 Linear layers = 1x1 MFMA convs, depthwise conv, LayerNorm+GELU,
-        mask softmax, the deformable gather and the centre-feature-scale blend.  keep: also return what backward needs."""
+        mask softmax, the deformable gather and the centre-feature-scale blend.  keep: also return what backward needs.
+        out_proj = (weight, bias, act): replaces the output projection's parameters (a caller folding a following BatchNorm into it)
+        and puts `act` into that conv's epilogue."""
         N, H, W, C = input.shape
         if self.dw_kernel_size != 3:
             raise NotImplementedError('depthwise kernel size 3 only on the MI355X path')
@@ -160,7 +162,10 @@ class DCNv3(nn.Module):
         if self.center_feature_scale:
             logit = self._linear(x1, self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias)
             yb = ops.cfs_blend(y, x_proj, logit, self.group, self.group_channels)
-        out = self._linear(yb, self.output_proj.weight, self.output_proj.bias)
+        if out_proj is not None:
+            out = ops.conv2d_nhwc(yb, out_proj[0], out_proj[1], kh=1, kw=1, act=out_proj[2])
+        else:
+            out = self._linear(yb, self.output_proj.weight, self.output_proj.bias)
         if keep:
             return out, (input, x_proj, wdw, u, x1, offset, mask, y, logit, yb)
         return out

@@ -59,6 +59,10 @@ def parse_model(d, ch):
         elif name == 'nn.Upsample':
             m = B.Upsample
             c2 = ch[f]
+        elif name == 'DCNv3_YOLO':                                # the reference's generic branch (models/yolo.py:1647-1648): channels pass through
+            m = B.DCNv3_YOLO
+            c2 = ch[f]
+            args = [c2, *args[1:]]
         elif name == 'Concat':                                    # models/yolo.py:1589-1591
             m = B.Concat
             c2 = sum(ch[x] for x in f)
@@ -229,6 +233,8 @@ class Model(nn.Module):
                     give(src, d)
             elif srcs[0] < 0:
                 m.backward(g, need_dx=False)
+            elif isinstance(m, B.DCNv3_YOLO):
+                give(srcs[0], m.backward(g))
             else:
                 have = grads.get(srcs[0])
                 if (have is not None and isinstance(m, (B.Conv, B.C2fCBAM, B.C3, B.SPPF, B.SPP)) and have.coff == 0 and
