@@ -1,13 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py - YOLO-SOMI hot path on MI355X: images/s of the 640x640 inference step (forward + NMS), synthetic data.
+"""bench.py - YOLO-SOMI hot path on MI355X: images/s of the 640x640 TRAINING step (default) or inference step, synthetic data.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
-torch.distributed.run with one rank per GPU.  A step = one pass of the hot path over one batch of VisDrone-shaped
-synthetic uint8 images already resident in HBM: ingest(/255) -> SOMI forward (yolov5l-SOMI, 77.5 M parameters, eval,
-Conv+BN folded) -> decode -> NMS(conf 0.001, iou 0.6, multi_label).  Inference shards by image with no data-path
-collective ("replicas only"): value = images all ranks processed / max-over-ranks time, weak scaling.
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel: the fp32-MFMA implicit-GEMM conv, timed live with HIP
-events on the launch stream) and, at N=1, `cpu_baseline` (the CPU oracle on the host cores, bounded sample).
+torch.distributed.run with one rank per GPU (the process refuses to run when WORLD_SIZE != --gpus).  A step = one pass of the hot
+path over one batch of VisDrone-shaped synthetic uint8 images already resident in HBM:
+
+  --mode train (default; BASELINE configs[1] at --batch 32): ingest (/255) -> train-mode forward (batch-statistic BN) -> ComputeLoss
+      -> hand-written backward -> (N>1: bucketed gradient all-reduce over RCCL, overlapped) -> fused Adam + EMA
+  --mode infer (configs[4] at --batch 128): ingest -> eval forward (Conv+BN folded) -> decode -> NMS(conf 0.001, iou 0.6, multi_label)
+
+  --model somi-dcn (default): yolov5l-SOMI with its two DCNv3 sites ("yolov5l-SOMI (DCNv3 blocks)", BASELINE configs[1])
+  --model somi:      the layer table of models/modules/YOLO-SOMI.yaml exactly (the reference wires DCNv3 into no yaml)
+  --model yolov5s:   stock YOLOv5s, 80 classes (BASELINE configs[0]; use --batch 2)
+
+Training shards data-parallel (weak scaling, per-rank batch fixed); inference shards by image with no collective ("replicas only").
+value = images all ranks processed / max-over-ranks time.  Rank 0 prints ONE JSON line with
+  roofline         the dominant kernel = the fp32-MFMA implicit-GEMM conv variant with the largest total time: algorithmic FLOPs of
+                   its launches / HIP-event time of those launches inside the timed region (events on the launch stream);
+  roofline_dcnv3   (DCN graph) the DCNv3 operator kernels inside the step against the HBM roofline: algorithmic bytes / event time;
+  cpu_baseline     (N=1) the CPU oracle on the host cores, bounded sample, protocol of BASELINE.md section 3;
+  allreduce        (N>1) the gradient exchange on its own, after the timed region.
 """
 import argparse
 import json
@@ -23,13 +35,17 @@ for p in (ROOT, os.path.join(ROOT, 'yolo-somi_amd')):
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 XGMI_LINKS, XGMI_LINK_GBPS = 7, 153  # per GPU: 7 point-to-point xGMI links of ~153 GB/s each (MI355X_MICROARCH.md)
+MODELS = {'somi-dcn': 'yolov5l-SOMI (DCNv3 blocks)', 'somi': 'yolov5l-SOMI', 'yolov5s': 'yolov5s'}
 
 
-def somi_cfg_full():
-    """Layer table of models/modules/YOLO-SOMI.yaml (C2fEACBAM -> C2fCBAM) with the yaml's 16 anchor pairs."""
-    from somi_amd.configs import somi_cfg, SOMI_ANCHORS
-    return somi_cfg(1.0, 1.0, nc=10, anchors=SOMI_ANCHORS)
+def model_cfg(name):
+    """-> (layer table, number of classes).  somi: models/modules/YOLO-SOMI.yaml (C2fEACBAM -> C2fCBAM) with the yaml's 16 anchor pairs."""
+    from somi_amd.configs import somi_cfg, yolov5_cfg, SOMI_ANCHORS
+    if name == 'yolov5s':
+        return yolov5_cfg(), 80
+    return somi_cfg(1.0, 1.0, nc=10, anchors=SOMI_ANCHORS, dcn=(name == 'somi-dcn')), 10
 
 
 def synthetic_images(batch, size, seed, device):
@@ -37,56 +53,90 @@ def synthetic_images(batch, size, seed, device):
     return torch.randint(0, 256, (batch, 3, size, size), generator=g, dtype=torch.uint8).to(device)
 
 
-def cpu_baseline_train(size):
-    """The oracle's training step (forward in train mode + ComputeLoss + backward + torch Adam) on the host cores, batch 2."""
+def host_cpu():
+    """(threads to use, CPU model): the physical cores of one socket, capped by what this process may actually run on - its affinity
+    mask and its cgroup CPU quota (a 1-GPU box hands out a 16-CPU share of its 64-core socket; more threads than that only thrash)."""
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id':
+                core = v
+            elif not k and phys is not None:
+                if phys == '0':
+                    cores.add(core)
+                phys = core = None
+    except OSError:
+        pass
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:                                                        # cgroup v2, then v1
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        quota = None if q == 'max' else int(q) // int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            quota = None if q <= 0 else q // int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        except (OSError, ValueError):
+            pass
+    n = min(len(cores) or allowed, allowed, quota or allowed, int(os.environ.get('SOMI_CPU_THREADS', '16')))
+    return max(n, 1), model
+
+
+def cpu_baseline(model_name, mode, size):
+    """The CPU oracle (restatement of the reference path, kind 'port') timed on this box's host cores.  Protocol of BASELINE.md section 3
+    (utils/get_FPS.py:81-101 scaled down): warm-up, then a timed loop, wall clock around the loop; batch 8 for the SOMI graphs, 2 for
+    yolov5s; threads = physical cores of one socket.  The loop is cut to a ~25 s budget (the protocol's 3 + 10 iterations of an
+    11 s SOMI training step would be minutes): the sample string says what ran."""
     from oracle.somi_ref import Model as OracleModel
     from oracle.somi_ref.loss import ComputeLoss as OracleLoss
-    from oracle.somi_ref.testing import fill_state, synthetic_batch, HYP_VISDRONE
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    m = fill_state(OracleModel(somi_cfg_full()), 1).train()
-    m.hyp = dict(HYP_VISDRONE)
-    crit = OracleLoss(m)
-    opt = torch.optim.Adam(m.parameters(), lr=3e-4, betas=(0.843, 0.999))
-    B = 2
-    imgs, targets = synthetic_batch(B, size, seed=0)
-    x = imgs.float() / 255
-    n, t0 = 0, time.time()
-    while True:
-        loss, _ = crit(m(x), targets)
-        loss.backward()
-        opt.step()
-        opt.zero_grad()
-        n += 1
-        if n >= 2 or time.time() - t0 > 30:
-            break
-    dt = time.time() - t0
-    return {'value': round(B * n / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} x (forward + loss + backward + Adam) of yolov5l-SOMI at batch {B}, {size}x{size}, torch CPU fp32, {cores} threads'}
-
-
-def cpu_baseline(size, seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference path, kind 'port') timed on this box's host cores: forward + NMS."""
-    from oracle.somi_ref import Model as OracleModel
     from oracle.somi_ref.nms import non_max_suppression as oracle_nms
-    from oracle.somi_ref.testing import fill_state
-    cores = min(16, os.cpu_count() or 1)
+    from oracle.somi_ref.testing import fill_state, synthetic_batch, HYP_VISDRONE
+    cores, cpu_model = host_cpu()
     torch.set_num_threads(cores)
-    m = fill_state(OracleModel(somi_cfg_full()), 1).eval().fuse()
-    B = 2
-    x = synthetic_images(B, size, 0, 'cpu').float() / 255
-    with torch.no_grad():
-        m(x)                                                    # warm-up (also builds the decode grids)
-        n, t0 = 0, time.time()
-        while True:
-            z, _ = m(x)
-            oracle_nms(z, 0.001, 0.6, multi_label=True)
-            n += 1
-            if time.time() - t0 > seconds_budget or n >= 10:
-                break
-        dt = time.time() - t0
-    return {'value': round(B * n / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} x (forward + NMS) of yolov5l-SOMI at batch {B}, {size}x{size}, torch CPU fp32, {cores} threads'}
+    cfg, nc = model_cfg(model_name)
+    B = 2 if model_name == 'yolov5s' else 8
+    m = fill_state(OracleModel(cfg), 1)
+    imgs, targets = synthetic_batch(B, size, nc=nc, seed=0)
+    x = imgs.float() / 255
+    if mode == 'train':
+        m.train()
+        m.hyp = dict(HYP_VISDRONE)
+        crit = OracleLoss(m)
+        opt = torch.optim.Adam(m.parameters(), lr=3e-4, betas=(0.843, 0.999))
+
+        def step():
+            loss, _ = crit(m(x), targets)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+        what = 'forward + ComputeLoss + backward + Adam'
+    else:
+        m = m.eval().fuse()
+
+        def step():
+            with torch.no_grad():
+                z, _ = m(x)
+                oracle_nms(z, 0.001, 0.6, multi_label=True)
+        what = 'forward + NMS'
+    warm = 3 if model_name == 'yolov5s' else 1
+    for _ in range(warm):
+        step()
+    n, t0 = 0, time.time()
+    while n < 10 and (n == 0 or time.time() - t0 < 25.0):
+        step()
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(B * n / dt, 3), 'unit': 'images/s', 'cores': cores, 'cpu_model': cpu_model, 'kind': 'port',
+            'sample': f'{warm} warm-up + {n} timed x ({what}) of {MODELS[model_name]} at batch {B}, {size}x{size}, torch CPU fp32, {cores} threads '
+                      f"(this box's CPU share: min of one socket's physical cores, the cgroup quota and 16); BASELINE.md section 3 protocol (3 + 10 "
+                      f'iterations) cut to a 25 s budget'}
 
 
 def pmc_traffic(kernel_name):
@@ -108,18 +158,27 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE configs[1]: bs=32)')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 32: BASELINE configs[1]; 2 for yolov5s)')
     ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--model', choices=list(MODELS), default='somi-dcn')
+    ap.add_argument('--no-dcn', action='store_true', help='same as --model somi')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-infer', action='store_true', help='skip the side measurement of the inference rate (profiling runs)')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
-                    help='train: forward(train)+loss+backward+Adam+EMA step (BASELINE configs[1]); infer: forward+NMS')
+                    help='train: forward(train)+loss+backward+Adam+EMA step (BASELINE configs[1]); infer: forward+NMS (configs[4])')
     args = ap.parse_args()
+    if args.no_dcn and args.model == 'somi-dcn':
+        args.model = 'somi'
+    if args.batch is None:
+        args.batch = 2 if args.model == 'yolov5s' else 32
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:                                      # a mis-launch must not print an N=1 number under --gpus 8
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with python -m torch.distributed.run '
+                         f'--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the product path has no CPU fallback)')
     backend = os.environ.get('SOMI_DIST_BACKEND', 'nccl')     # 'gloo' + several ranks on one GPU = rehearsal on a 1-GPU box only
@@ -138,13 +197,16 @@ def main():
             dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI, one GPU per rank
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
 
     from somi_amd import ops
     from somi_amd.model import Model
     from somi_amd.nms import non_max_suppression
 
     torch.manual_seed(0)
-    model = Model(somi_cfg_full())
+    cfg, nc = model_cfg(args.model)
+    model = Model(cfg)
+    nparams = sum(p.numel() for p in model.parameters())
     from somi_amd.configs import fill_state
     fill_state(model, 1)                                        # deterministic synthetic weights, BN stats randomised
     model = model.to(dev).eval()
@@ -172,7 +234,7 @@ def main():
     if args.mode == 'train':
         from somi_amd.configs import HYP_VISDRONE, synthetic_batch
         from somi_amd.train import TrainStep
-        _, targets = synthetic_batch(args.batch, args.size, seed=1000 + rank)
+        _, targets = synthetic_batch(args.batch, args.size, nc=nc, seed=1000 + rank)
         targets = targets.to(dev)
         trainer = TrainStep(model, dict(HYP_VISDRONE), args.batch, dist=dist)
 
@@ -185,7 +247,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    ops.PROFILE = prof = []                                     # per-launch HIP events around every conv launch
+    ops.PROFILE = prof = []                                     # per-launch HIP events around every conv / DCNv3 launch
     dt = timed_steps(step, args.steps, dist=dist, sync=torch.cuda.synchronize, device=dev)   # barrier+sync both sides, MAX over ranks
     ops.PROFILE = None
 
@@ -197,32 +259,35 @@ def main():
         alg = nbytes / secs / 1e9
         exchange = {'bytes': nbytes, 'buckets': sum(len(c) for c in trainer.buckets.buckets), 'ms': round(secs * 1e3, 3),
                     'algbw_GBps': round(alg, 1), 'busbw_GBps': round(alg * 2 * (world - 1) / world, 1),
-                    'xgmi_peak_GBps_per_gpu': XGMI_LINKS * XGMI_LINK_GBPS, 'backend': backend,
+                    'xgmi_peak_GBps_per_gpu': XGMI_LINKS * XGMI_LINK_GBPS, 'backend': backend, 'ranks': dist.get_world_size(),
                     'note': 'bucketed SUM all-reduce of the flat fp32 gradient buffers, not overlapped with anything'}
 
     if rank == 0:
-        # dominant kernel = the conv tile variant with the largest total time
-        by = {}
-        for name, flops, e0, e1, _ in prof:
-            d = by.setdefault(name, [0, 0.0, 0.0])
+        # dominant kernel = the conv tile variant with the largest total time; DCNv3 launches carry bytes instead of FLOPs
+        by, dcn = {}, {}
+        for name, work, e0, e1, _ in prof:
+            d = (dcn if name.startswith('dcnv3') else by).setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
-            d[1] += flops
+            d[1] += work
             d[2] += e0.elapsed_time(e1) * 1e-3
         name, (cnt, flops, secs) = max(by.items(), key=lambda kv: kv[1][2])
         all_flops, all_secs = sum(v[1] for v in by.values()), sum(v[2] for v in by.values())
         achieved = flops / secs / 1e12
+        label = MODELS[args.model]
+        step_txt = (f'{label} training step: uint8 ingest + forward (batch-stat BN) + ComputeLoss + backward + '
+                    f'{"gradient all-reduce + " if world > 1 else ""}Adam + EMA' if args.mode == 'train' else
+                    f'{label} inference step: uint8 ingest + forward + decode{"" if args.no_nms else " + NMS(conf 0.001, iou 0.6, multi_label)"}')
+        which = {('somi-dcn', 'train'): 'BASELINE configs[1] shape', ('somi', 'train'): "configs[1] shape on the reference's shipped yaml (no DCNv3 site)",
+                 ('yolov5s', 'train'): 'BASELINE configs[0] graph', ('somi-dcn', 'infer'): 'BASELINE configs[4] shape at --batch 128',
+                 ('somi', 'infer'): 'configs[4] shape at --batch 128, shipped yaml', ('yolov5s', 'infer'): 'configs[0] graph'}[(args.model, args.mode)]
         out = {
-            'metric': (f'images/sec train (forward+loss+backward+Adam+EMA) @{args.size}, VisDrone-shaped synthetic, yolov5l-SOMI' if args.mode == 'train'
-                       else f'images/sec infer (forward+NMS) @{args.size}, VisDrone-shaped synthetic, yolov5l-SOMI'),
+            'metric': (f'images/sec train (forward+loss+backward+Adam+EMA) @{args.size}, VisDrone-shaped synthetic, {label}' if args.mode == 'train'
+                       else f'images/sec infer (forward+NMS) @{args.size}, VisDrone-shaped synthetic, {label}'),
             'value': round(whole_job_rate(args.batch, args.steps, world, dt), 2), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': (f'yolov5l-SOMI training step: uint8 ingest + forward (batch-stat BN) + ComputeLoss + backward + '
-                                    f'{"gradient all-reduce + " if world > 1 else ""}Adam + EMA, ' if args.mode == 'train' else
-                                    f'yolov5l-SOMI inference step: uint8 ingest + forward + decode'
-                                    f'{"" if args.no_nms else " + NMS(conf 0.001, iou 0.6, multi_label)"}, ') +
-                                   f'{args.size}x{args.size}, batch {args.batch}/GPU (BASELINE configs[1] shape)',
-                       'batch_per_gpu': args.batch, 'imgsz': args.size, 'params': 77537610,
+            'config': {'workload': f'{step_txt}, {args.size}x{args.size}, batch {args.batch}/GPU ({which})',
+                       'batch_per_gpu': args.batch, 'imgsz': args.size, 'params': nparams, 'classes': nc,
                        'parallelism': (f'dp{world}' if args.mode == 'train' else f'replicas x{world}')},
             'infer_images_per_s_per_gpu': None if infer_ips is None else round(infer_ips, 2),
             'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
@@ -233,10 +298,20 @@ def main():
                          'conv_share_of_step': round(all_secs / dt, 3)},
         }
         out['roofline']['traffic'] = pmc_traffic(name)
+        if dcn:                                                  # the DCNv3 operator kernels of the step against the HBM roofline
+            kernels = {}
+            for k, (c_, b_, s_) in sorted(dcn.items()):
+                kernels[k] = {'launches': c_, 'avg_launch_us': round(s_ / c_ * 1e6, 2), 'avg_launch_MB': round(b_ / c_ / 1e6, 1),
+                              'achieved_GBps': round(b_ / s_ / 1e9, 1), 'frac': round(b_ / s_ / 1e9 / HBM_PEAK_GBPS, 4),
+                              'traffic': pmc_traffic(k)}
+            tb, ts = sum(v[1] for v in dcn.values()), sum(v[2] for v in dcn.values())
+            out['roofline_dcnv3'] = {'bound': 'hbm', 'achieved': round(tb / ts / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                                     'frac': round(tb / ts / 1e9 / HBM_PEAK_GBPS, 4), 'share_of_step': round(ts / dt, 4), 'kernels': kernels,
+                                     'note': 'algorithmic bytes 4(2C+3GK) forward / 4(4C+6GK) backward per output pixel (SURVEY 8d)'}
         if exchange:
             out['allreduce'] = exchange
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline_train(args.size) if args.mode == 'train' else cpu_baseline(args.size)
+            out['cpu_baseline'] = cpu_baseline(args.model, args.mode, args.size)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -228,3 +228,16 @@ def test_ctypes_mirrors_match_the_c_layout():
         got = [int(v) for v in line.split()[1:]]
         want = [ctypes.sizeof(ct)] + [getattr(ct, f).offset for f in fields]
         assert got == want, (cname, got, want)
+
+
+def test_bench_refuses_a_mislaunch():
+    """bench.py --gpus N must not print an N=1 number when it was not launched with N ranks: WORLD_SIZE != --gpus exits
+    non-zero before anything touches the GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout) and '{' not in r.stdout

@@ -100,9 +100,17 @@ def dcnv3_forward_raw(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group
     N, H, W, _ = input.shape
     Ho, Wo = conv_out_size(H, kh, sh, ph, dh), conv_out_size(W, kw, sw, pw, dw)
     out = torch.empty(N, Ho, Wo, group * group_channels, device=input.device, dtype=torch.float32)
+    prof = PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().somi_dcnv3_forward_f32(_ptr(input), _ptr(offset), _ptr(mask), _ptr(out), N, H, W, group,
                                             group_channels, kh, kw, sh, sw, ph, pw, dh, dw, float(offset_scale),
                                             int(im2col_step), _stream()), 'dcnv3_forward')
+    if prof:                                                      # algorithmic bytes: 4 (2C + 3GK) per output pixel
+        e1.record()
+        C_ = group * group_channels
+        PROFILE.append(('dcnv3_fwd_kernel', 4.0 * N * Ho * Wo * (2 * C_ + 3 * group * kh * kw), e0, e1, (N, H, W, C_, group, kh, sh, 10)))
     return out
 
 
@@ -112,9 +120,18 @@ def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw,
     gi = torch.zeros_like(input)
     go = torch.empty_like(offset)
     gm = torch.empty_like(mask)
+    prof = PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().somi_dcnv3_backward_f32(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go),
                                              _ptr(gm), N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw,
                                              float(offset_scale), int(im2col_step), _stream()), 'dcnv3_backward')
+    if prof:                                                      # 4 (4C + 6GK) per output pixel
+        e1.record()
+        C_ = group * group_channels
+        Ho, Wo = grad_output.shape[1], grad_output.shape[2]
+        PROFILE.append(('dcnv3_bwd_kernel', 4.0 * N * Ho * Wo * (4 * C_ + 6 * group * kh * kw), e0, e1, (N, H, W, C_, group, kh, sh, 11)))
     return gi, go, gm
 
 
