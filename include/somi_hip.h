@@ -143,6 +143,26 @@ int somi_dcnv3_backward_f32(const float *input, const float *offset, const float
                             int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
                             float offset_scale, int im2col_step, somi_stream_t stream);
 
+/* The other two dtypes the reference extension dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69,136), same argument
+ * meaning as the _f32 pair.  _f16: tensors are IEEE half (the AMP path of train.py:263), arithmetic fp32 (the reference's opmath_t),
+ * and the three gradient outputs are FP32 buffers exactly like the reference's (dcnv3_cuda.cu:126-133: the caller casts them back,
+ * :168-170).  _f64: everything double (the exact-parity mode of models/ops_dcnv3/test.py:55).  grad_input must be zeroed by the
+ * caller (at::zeros in the reference); grad_offset / grad_mask are fully overwritten. */
+int somi_dcnv3_forward_f16(const void *input, const void *offset, const void *mask, void *output, int N, int H, int W, int G, int Gc,
+                           int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
+                           float offset_scale, int im2col_step, somi_stream_t stream);
+int somi_dcnv3_backward_f16(const void *input, const void *offset, const void *mask, const void *grad_output, float *grad_input,
+                            float *grad_offset, float *grad_mask, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w,
+                            int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
+                            int im2col_step, somi_stream_t stream);
+int somi_dcnv3_forward_f64(const double *input, const double *offset, const double *mask, double *output, int N, int H, int W, int G,
+                           int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
+                           int dilation_w, float offset_scale, int im2col_step, somi_stream_t stream);
+int somi_dcnv3_backward_f64(const double *input, const double *offset, const double *mask, const double *grad_output, double *grad_input,
+                            double *grad_offset, double *grad_mask, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w,
+                            int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
+                            int im2col_step, somi_stream_t stream);
+
 /* Pieces of the DCNv3 nn.Module around the operator (models/ops_dcnv3/modules/dcnv3.py:283-291,334,370-376):
  *  LayerNorm over C (biased variance, eps inside the sqrt) + activation on contiguous NHWC;
  *  softmax over the K points of each (pixel, group): x, y are (n_groups, K) contiguous;

@@ -285,3 +285,108 @@ def test_full_width_dcn_graph_sites_at_80_and_160(S):
         zr, _ = ref(x)
         z, _ = mine(x.cuda())
     rel_close(z, zr, what=f'z @{S} with DCNv3 sites')
+
+
+# ---------------------------------------------------------------------------------------------- boundary: dtypes, module name, custom ops
+def _golden_case(g, dtype):
+    N, H, W, G, Gc, k, s, p, d = (int(v) for v in g['params'])
+    t = lambda key: T(g[key]).to(dtype).cuda()                   # noqa: E731
+    return (t('input'), t('offset'), t('mask')), (k, k, s, s, p, p, d, d, G, Gc, float(g['offset_scale'])), t('grad_output')
+
+
+def test_dcnv3_double_matches_the_reference_test_bar(golden):
+    """models/ops_dcnv3/test.py:55: the extension in double against dcnv3_core_pytorch with torch.allclose defaults (rtol 1e-5,
+    atol 1e-8) - forward, and the same bar for the three gradients (the reference only asks rtol 1e-2 / atol 1e-3 there, :134-148)."""
+    from somi_amd.dcnv3 import dcnv3_backward, dcnv3_forward
+    g = golden('dcnv3_testpy_f64')
+    (x, off, m), cfg, go = _golden_case(g, torch.float64)
+    out = dcnv3_forward(x, off, m, *cfg, 256)
+    assert out.dtype == torch.float64 and torch.allclose(out.cpu(), T(g['output'])), float((out.cpu() - T(g['output'])).abs().max())
+    gi, goff, gm = dcnv3_backward(x, off, m, *cfg, go, 256)
+    for got, key in ((gi, 'grad_input'), (goff, 'grad_offset'), (gm, 'grad_mask')):
+        assert got.dtype == torch.float64
+        assert torch.allclose(got.cpu(), T(g[key]), rtol=1e-5, atol=1e-8), (key, float((got.cpu() - T(g[key])).abs().max()))
+    for tag in ('bwd_D30', 's2_p1', 'd2_p2', 'k5_p2'):          # ragged group width, stride, dilation, 5x5 in double as well
+        g = golden('dcnv3_' + tag)
+        (x, off, m), cfg, go = _golden_case(g, torch.float64)
+        assert torch.allclose(dcnv3_forward(x, off, m, *cfg, 256).cpu(), T(g['output']), rtol=1e-5, atol=1e-8), tag
+        for got, key in zip(dcnv3_backward(x, off, m, *cfg, go, 256), ('grad_input', 'grad_offset', 'grad_mask')):
+            assert torch.allclose(got.cpu(), T(g[key]), rtol=1e-5, atol=1e-8), (tag, key)
+
+
+def test_dcnv3_half_fp32_accumulation():
+    """The AMP path (train.py:263; AT_DISPATCH_FLOATING_TYPES_AND_HALF): half storage, fp32 arithmetic, fp32 gradient buffers cast
+    back to half (dcnv3_cuda.cu:126-133,168-170).  Yardstick: the CPU oracle in fp32 on the same half-rounded inputs; the only
+    difference allowed is the final rounding to half (2^-11 relative) plus fp32 summation order."""
+    from oracle.somi_ref import dcnv3 as O
+    from somi_amd.dcnv3 import DCNv3Function
+    gen = torch.Generator().manual_seed(21)
+    N, H, W, G, Gc, k = 2, 14, 11, 4, 16, 3
+    x = torch.randn(N, H, W, G * Gc, generator=gen).half()
+    off = (torch.randn(N, H, W, G * 9 * 2, generator=gen) * 2).half()
+    m = torch.softmax(torch.randn(N, H, W, G, 9, generator=gen), -1).reshape(N, H, W, G * 9).half()
+    go = torch.randn(N, H, W, G * Gc, generator=gen).half()
+    xr, orr, mr = (t.float().requires_grad_(True) for t in (x, off, m))
+    want = O.dcnv3_core(xr, orr, mr, k, k, 1, 1, 1, 1, 1, 1, G, Gc, 1.5)
+    want.backward(go.float())
+    xd, od, md = (t.cuda().requires_grad_(True) for t in (x, off, m))
+    out = DCNv3Function.apply(xd, od, md, k, k, 1, 1, 1, 1, 1, 1, G, Gc, 1.5, 256)
+    assert out.dtype == torch.float16
+    rel_close(out.float(), want.detach(), rel=1e-3, what='half forward')
+    out.backward(go.cuda())
+    for got, ref, what in ((xd.grad, xr.grad, 'grad_input'), (od.grad, orr.grad, 'grad_offset'), (md.grad, mr.grad, 'grad_mask')):
+        assert got.dtype == torch.float16
+        rel_close(got.float(), ref, rel=1e-3, what=f'half {what}')
+
+
+def test_integration_md_section_1_runs_as_written(golden):
+    """INTEGRATION.md section 1 - the reference-side ctypes glue a maintainer would paste over `import DCNv3` - is executed verbatim
+    (only the library path is filled in) and then driven exactly like functions/dcnv3_func.py:39-43,54-58 drives the extension."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, 'INTEGRATION.md')).read()
+    sec = md[md.index('## 1. DCNv3 extension'):md.index('## 2. Model forward')]
+    code = re.search(r'```python\n(.*?)```', sec, re.S).group(1)
+    code = code.replace("'.../yolo-somi_amd/lib/libsomi_hip.so'", repr(os.path.join(root, 'yolo-somi_amd', 'lib', 'libsomi_hip.so')))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md#1', 'exec'), ns)
+    ext = ns['DCNv3']
+    for tag, dt in (('testpy_f32', torch.float32), ('testpy_f64', torch.float64), ('s2_p1', torch.float32)):
+        g = golden('dcnv3_' + tag)
+        (x, off, m), cfg, go = _golden_case(g, dt)
+        out = ext.dcnv3_forward(x, off, m, *cfg, 256)
+        rel_close(out, T(g['output']), what=f'{tag} forward through the INTEGRATION glue')
+        gi, goff, gm = ext.dcnv3_backward(x, off, m, *cfg, go, 256)
+        rel_close(gi, T(g['grad_input']), what='grad_input')
+        rel_close(goff, T(g['grad_offset']), what='grad_offset')
+        rel_close(gm, T(g['grad_mask']), what='grad_mask')
+    with pytest.raises(RuntimeError, match='must divide im2col_step'):
+        ext.dcnv3_forward(torch.zeros(3, 8, 8, 16, device='cuda'), torch.zeros(3, 8, 8, 72, device='cuda'), torch.zeros(3, 8, 8, 36, device='cuda'),
+                          3, 3, 1, 1, 1, 1, 1, 1, 4, 4, 1.0, 2)
+
+
+def test_import_DCNv3_resolves_to_the_drop_in_module_and_custom_ops(golden):
+    """`import DCNv3` (functions/dcnv3_func.py:16) with yolo-somi_amd/ on sys.path, and the torch.library registration: the op pair
+    under torch.ops.somi with the autograd formula attached, plus somi.nms against the host wrapper."""
+    import DCNv3
+    import somi_amd.torch_ops  # noqa: F401
+    from somi_amd.nms import non_max_suppression
+    g = golden('dcnv3_testpy_f32')
+    (x, off, m), cfg, go = _golden_case(g, torch.float32)
+    rel_close(DCNv3.dcnv3_forward(x, off, m, *cfg, 256), T(g['output']), what='DCNv3.dcnv3_forward')
+    for got, key in zip(DCNv3.dcnv3_backward(x, off, m, *cfg, go, 256), ('grad_input', 'grad_offset', 'grad_mask')):
+        rel_close(got, T(g[key]), what=f'DCNv3.dcnv3_backward {key}')
+    xs = [t.clone().requires_grad_(True) for t in (x, off, m)]
+    out = torch.ops.somi.dcnv3_forward(*xs, *cfg, 256)
+    rel_close(out, T(g['output']), what='torch.ops.somi.dcnv3_forward')
+    out.backward(go)
+    for t, key in zip(xs, ('grad_input', 'grad_offset', 'grad_mask')):
+        rel_close(t.grad, T(g[key]), what=f'autograd of the custom op: {key}')
+    pred = T(golden('nms')['pred']).cuda()
+    det, count = torch.ops.somi.nms(pred, 0.25, 0.45, False, False, 300)
+    want = non_max_suppression(pred, 0.25, 0.45)
+    for b, w in enumerate(want):
+        assert int(count[b]) == w.shape[0] and torch.equal(det[b, :w.shape[0]], w)
+    with pytest.raises(NotImplementedError, match="'CPU' backend"):
+        torch.ops.somi.dcnv3_forward(x.cpu(), off.cpu(), m.cpu(), *cfg, 256)

@@ -241,3 +241,23 @@ def test_bench_refuses_a_mislaunch():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], capture_output=True, text=True,
                        timeout=300, env=env, cwd=root)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout) and '{' not in r.stdout
+
+
+def test_custom_ops_are_registered_device_only():
+    """north_star: 'surfaced to Python through PyTorch-ROCm custom ops'.  torch.ops.somi.* exist with the reference extension's
+    signatures, have shape (fake) kernels, and have NO CPU kernel - a CPU tensor fails loudly instead of falling back."""
+    import DCNv3                                                  # yolo-somi_amd/DCNv3.py: what `import DCNv3` (dcnv3_func.py:16) finds
+    import somi_amd.torch_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert callable(DCNv3.dcnv3_forward) and callable(DCNv3.dcnv3_backward)
+    for name in ('dcnv3_forward', 'dcnv3_backward', 'conv2d_nhwc', 'nms', 'yolo_loss'):
+        assert hasattr(torch.ops.somi, name), name
+    schema = str(torch.ops.somi.dcnv3_forward.default._schema)
+    assert 'int kernel_h' in schema and 'float offset_scale' in schema and 'int im2col_step' in schema
+    with FakeTensorMode():
+        x, o, m = torch.empty(2, 9, 7, 64), torch.empty(2, 5, 4, 72), torch.empty(2, 5, 4, 36)
+        assert torch.ops.somi.dcnv3_forward(x, o, m, 3, 3, 2, 2, 1, 1, 1, 1, 4, 16, 1.0, 256).shape == (2, 5, 4, 64)
+    with pytest.raises(NotImplementedError, match="'CPU' backend"):
+        torch.ops.somi.nms(torch.zeros(1, 10, 15), 0.25, 0.45, False, False, 300)
+    with pytest.raises(RuntimeError, match='CUDA tensor'):
+        DCNv3.dcnv3_forward(torch.zeros(1, 4, 4, 16), torch.zeros(1, 4, 4, 72), torch.zeros(1, 4, 4, 36), 3, 3, 1, 1, 1, 1, 1, 1, 4, 4, 1.0, 256)

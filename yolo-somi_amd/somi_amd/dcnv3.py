@@ -13,13 +13,15 @@ from torch.autograd.function import once_differentiable
 from . import ops
 
 
-def _checked(t, name):
+def _checked(t, name, like=None):
     if not t.is_contiguous():
         raise RuntimeError(f'{name} tensor has to be contiguous')          # dcnv3_cuda.cu:29-31
     if not t.is_cuda:
         raise RuntimeError(f'{name} must be a CUDA tensor')               # dcnv3_cuda.cu:32-34 (HIP device here)
-    if t.dtype != torch.float32:
-        raise RuntimeError(f'{name}: only float32 is implemented on the MI355X path')
+    if t.dtype not in (torch.float32, torch.float16, torch.float64):      # AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69
+        raise RuntimeError(f'"dcnv3" not implemented for \'{t.dtype}\'')
+    if like is not None and t.dtype != like.dtype:
+        raise RuntimeError(f'{name}: expected scalar type {like.dtype} but found {t.dtype}')
     return t
 
 
@@ -27,7 +29,7 @@ def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, p
                   group, group_channels, offset_scale, im2col_step):
     """-> output (N,Ho,Wo,group*group_channels); src/dcnv3.h:20-26."""
     for n, t in (('input', input), ('offset', offset), ('mask', mask)):
-        _checked(t, n)
+        _checked(t, n, input)
     if input.shape[3] != group * group_channels:
         raise RuntimeError(f'Input channels and group times group channels wont match: '
                            f'({input.shape[3]} vs {group * group_channels}).')
@@ -39,7 +41,7 @@ def dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, 
                    group, group_channels, offset_scale, grad_output, im2col_step):
     """-> [grad_input, grad_offset, grad_mask]; src/dcnv3.h:40-47."""
     for n, t in (('input', input), ('offset', offset), ('mask', mask), ('grad_output', grad_output)):
-        _checked(t, n)
+        _checked(t, n, input)
     if input.shape[3] != group * group_channels:
         raise RuntimeError(f'Input channels and group times group channels wont match: '
                            f'({input.shape[3]} vs {group * group_channels}).')

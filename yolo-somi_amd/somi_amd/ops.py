@@ -95,10 +95,19 @@ def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', 
     return out
 
 
+_DCN_SUFFIX = {torch.float32: 'f32', torch.float16: 'f16', torch.float64: 'f64'}
+
+
 def dcnv3_forward_raw(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels, offset_scale,
                       im2col_step):
     N, H, W, _ = input.shape
     Ho, Wo = conv_out_size(H, kh, sh, ph, dh), conv_out_size(W, kw, sw, pw, dw)
+    if input.dtype != torch.float32:                              # half / double: the reference's other two dispatch types
+        out = torch.empty(N, Ho, Wo, group * group_channels, device=input.device, dtype=input.dtype)
+        fn = getattr(_lib.lib(), 'somi_dcnv3_forward_' + _DCN_SUFFIX[input.dtype])
+        check(fn(_ptr(input), _ptr(offset), _ptr(mask), _ptr(out), N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw,
+                 float(offset_scale), int(im2col_step), _stream()), 'dcnv3_forward')
+        return out
     out = torch.empty(N, Ho, Wo, group * group_channels, device=input.device, dtype=torch.float32)
     prof = PROFILE is not None
     if prof:
@@ -117,6 +126,16 @@ def dcnv3_forward_raw(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group
 def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels,
                        offset_scale, im2col_step):
     N, H, W, _ = input.shape
+    if input.dtype != torch.float32:
+        # half: fp32 gradient buffers cast back to half afterwards, exactly as dcnv3_cuda.cu:126-133,168-170; double: double
+        gdt = torch.float64 if input.dtype == torch.float64 else torch.float32
+        gi = torch.zeros(input.shape, device=input.device, dtype=gdt)
+        go = torch.empty(offset.shape, device=input.device, dtype=gdt)
+        gm = torch.empty(mask.shape, device=input.device, dtype=gdt)
+        fn = getattr(_lib.lib(), 'somi_dcnv3_backward_' + _DCN_SUFFIX[input.dtype])
+        check(fn(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go), _ptr(gm), N, H, W, group, group_channels, kh, kw,
+                 sh, sw, ph, pw, dh, dw, float(offset_scale), int(im2col_step), _stream()), 'dcnv3_backward')
+        return gi.to(input.dtype), go.to(input.dtype), gm.to(input.dtype)
     gi = torch.zeros_like(input)
     go = torch.empty_like(offset)
     gm = torch.empty_like(mask)
