@@ -253,7 +253,7 @@ def test_custom_ops_are_registered_device_only():
     for name in ('dcnv3_forward', 'dcnv3_backward', 'conv2d_nhwc', 'nms', 'yolo_loss'):
         assert hasattr(torch.ops.somi, name), name
     schema = str(torch.ops.somi.dcnv3_forward.default._schema)
-    assert 'int kernel_h' in schema and 'float offset_scale' in schema and 'int im2col_step' in schema
+    assert 'Int kernel_h' in schema and 'float offset_scale' in schema and 'Int im2col_step' in schema      # int / SymInt
     with FakeTensorMode():
         x, o, m = torch.empty(2, 9, 7, 64), torch.empty(2, 5, 4, 72), torch.empty(2, 5, 4, 36)
         assert torch.ops.somi.dcnv3_forward(x, o, m, 3, 3, 2, 2, 1, 1, 1, 1, 4, 16, 1.0, 256).shape == (2, 5, 4, 64)
