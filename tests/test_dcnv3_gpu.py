@@ -306,12 +306,15 @@ def test_dcnv3_double_matches_the_reference_test_bar(golden):
     for got, key in ((gi, 'grad_input'), (goff, 'grad_offset'), (gm, 'grad_mask')):
         assert got.dtype == torch.float64
         assert torch.allclose(got.cpu(), T(g[key]), rtol=1e-5, atol=1e-8), (key, float((got.cpu() - T(g[key])).abs().max()))
-    for tag in ('bwd_D30', 's2_p1', 'd2_p2', 'k5_p2'):          # ragged group width, stride, dilation, 5x5 in double as well
+    # ragged group width, stride, dilation, 5x5 in double as well.  dcnv3_core_pytorch builds its reference points in float32
+    # (functions/dcnv3_func.py:99-112), so its own double output carries ~1e-7 relative noise that these geometries amplify: 1e-4,
+    # a hundred times inside the reference's backward bar (rtol 1e-2 / atol 1e-3, test.py:134-148)
+    for tag in ('bwd_D30', 's2_p1', 'd2_p2', 'k5_p2'):
         g = golden('dcnv3_' + tag)
         (x, off, m), cfg, go = _golden_case(g, torch.float64)
-        assert torch.allclose(dcnv3_forward(x, off, m, *cfg, 256).cpu(), T(g['output']), rtol=1e-5, atol=1e-8), tag
+        assert torch.allclose(dcnv3_forward(x, off, m, *cfg, 256).cpu(), T(g['output']), rtol=1e-4, atol=1e-7), tag
         for got, key in zip(dcnv3_backward(x, off, m, *cfg, go, 256), ('grad_input', 'grad_offset', 'grad_mask')):
-            assert torch.allclose(got.cpu(), T(g[key]), rtol=1e-5, atol=1e-8), (tag, key)
+            assert torch.allclose(got.cpu(), T(g[key]), rtol=1e-4, atol=1e-7), (tag, key, float((got.cpu() - T(g[key])).abs().max()))
 
 
 def test_dcnv3_half_fp32_accumulation():
