@@ -443,6 +443,9 @@ typedef struct somi_loss_desc {
     const float *anchors;
     float balance[4];
     float box_gain, obj_gain, cls_gain, cls_pw, obj_pw, anchor_t, cp, cn, gr;
+    float fl_gamma;     /* hyp['fl_gamma']: > 0 wraps both BCE terms in FocalLoss(gamma, alpha 0.25) (utils/loss.py:125-127,35-60) */
+    int32_t slide;      /* hyp['slide_ratio'] > 0: SlideLoss around them (:129-131,378-402), weighted by the level's mean IoU */
+    float nwd_ratio;    /* 0, or iou_ratio = 0.5 when hyp['nwdloss'] > 0: box term (1-r)(1-CIoU) + r(1-NWD) (:148,162-169) */
 } somi_loss_desc;
 
 size_t somi_loss_workspace_bytes(const somi_loss_desc *d);

@@ -374,6 +374,27 @@ def gen_loss():
             rec[f'tcls{i}'], rec[f'tbox{i}'], rec[f'anch{i}'] = tcls[i], tbox[i], anch[i]
             rec[f'idx{i}'] = torch.stack(indices[i], 0) if indices[i][0].numel() else torch.zeros(4, 0, dtype=torch.long)
         save(f'loss_{tag}', **rec)
+    # the branches hyp.VisDrone.yaml leaves off, through the reference's own ComputeLoss under modified hyper-parameters: FocalLoss
+    # (utils/loss.py:35-60), SlideLoss (:378-402), both stacked (:125-131), the NWD box term (:162-169, utils/metrics.py:341-354),
+    # label smoothing (:123); same predictions / targets as fixture `a`
+    g = torch.Generator().manual_seed(300)
+    B, S = 2, 64
+    p0 = [torch.randn(B, det.na, S // int(s), S // int(s), det.no, generator=g) for s in m.stride]
+    _, targets = synthetic_batch(B, S, seed=0)
+    for tag, over in (('focal', dict(fl_gamma=1.5)), ('slide', dict(slide_ratio=1.0)), ('focal_slide', dict(fl_gamma=2.0, slide_ratio=1.0)),
+                      ('nwd', dict(nwdloss=1.0)), ('all', dict(fl_gamma=1.5, slide_ratio=1.0, nwdloss=1.0, label_smoothing=0.1))):
+        m.hyp = dict(HYP_VISDRONE, **over)
+        crit_b = RefComputeLoss(m)
+        p = [t.clone().requires_grad_(True) for t in p0]
+        loss, items = crit_b(p, targets)
+        grads = torch.autograd.grad(loss, p, allow_unused=True)
+        rec = dict(targets=targets, loss=loss, items=items, anchors=det.anchors, stride=m.stride,
+                   hyp_keys=np.array(sorted(over)), hyp_vals=np.array([over[k] for k in sorted(over)], dtype=np.float64))
+        for i in range(len(p)):
+            rec[f'p{i}'] = p[i]
+            rec[f'g{i}'] = grads[i] if grads[i] is not None else torch.zeros_like(p[i])
+        save(f'loss_branch_{tag}', **rec)
+    m.hyp = dict(HYP_VISDRONE)
     # bbox_iou CIoU (utils/metrics.py:476-518)
     g = torch.Generator().manual_seed(350)
     b1 = torch.rand(64, 4, generator=g) * torch.tensor([20, 20, 8, 8.]) + torch.tensor([0, 0, 0.05, 0.05])

@@ -3,7 +3,9 @@
 Follows utils/loss.py:112-262 (ComputeLoss), utils/metrics.py:476-518 (bbox_iou, CIoU branch),
 utils/loss.py:14-15 (smooth_BCE) and utils/RepulsionLoss.py:5-95 (repulsion_loss, optional term that
 the reference imports but never calls - kept separate and off by default).
-Branches the VisDrone hyper-parameters switch off (focal gamma>0, slide_ratio>0, nwdloss>0) raise.
+The branches hyp.VisDrone.yaml leaves off are restated too: FocalLoss (utils/loss.py:35-60, fl_gamma > 0), SlideLoss
+(:378-402, slide_ratio > 0, stacked on top of the focal wrapper exactly as :125-131 stacks them) and the NWD box term
+(:162-169 with utils/metrics.py:341-354, nwdloss > 0, shapeloss == 0).  autobalance and the shapeloss variant raise.
 """
 import math
 
@@ -51,16 +53,44 @@ class ComputeLoss:
         h = model.hyp
         det = model.model[-1]
         self.hyp = h
-        if h['fl_gamma'] > 0 or h['slide_ratio'] > 0 or h['nwdloss'] > 0 or autobalance:
-            raise NotImplementedError('focal / slide / NWD / autobalance branches are off in hyp.VisDrone.yaml')
+        if autobalance or (h['nwdloss'] > 0 and h.get('shapeloss', 0) > 0):
+            raise NotImplementedError('autobalance / the shapeloss NWD variant are not restated')
+        self.fl_gamma, self.slide, self.nwd = float(h['fl_gamma']), h['slide_ratio'] > 0, h['nwdloss'] > 0
         self.cls_pw, self.obj_pw = float(h['cls_pw']), float(h['obj_pw'])
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
         self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, 0.02])     # :135
         self.gr = 1.0
         self.na, self.nc, self.nl, self.anchors = det.na, det.nc, det.nl, det.anchors
 
-    def _bce(self, logits, target, pw):
-        return F.binary_cross_entropy_with_logits(logits, target, pos_weight=torch.tensor([pw], device=logits.device))
+    def _bce(self, logits, target, pw, auto_iou=None):
+        """BCEWithLogits(pos_weight) -> [FocalLoss(gamma, alpha=0.25), utils/loss.py:35-60] -> [SlideLoss, :378-402] -> mean.
+        auto_iou: the level's mean IoU when the reference passes it (:186-187,191-192), else SlideLoss's default 0.5."""
+        if self.fl_gamma <= 0 and not self.slide:
+            return F.binary_cross_entropy_with_logits(logits, target, pos_weight=torch.tensor([pw], device=logits.device))
+        loss = F.binary_cross_entropy_with_logits(logits, target, pos_weight=torch.tensor([pw], device=logits.device), reduction='none')
+        if self.fl_gamma > 0:
+            prob = torch.sigmoid(logits)
+            p_t = target * prob + (1 - target) * (1 - prob)
+            loss = loss * ((target * 0.25 + (1 - target) * 0.75) * (1.0 - p_t) ** self.fl_gamma)
+        if self.slide:
+            auto_iou = 0.5 if auto_iou is None else float(auto_iou)
+            if auto_iou < 0.2:
+                auto_iou = 0.2
+            b1 = target <= auto_iou - 0.1
+            b2 = (target > (auto_iou - 0.1)) & (target < auto_iou)
+            b3 = target >= auto_iou
+            loss = loss * (1.0 * b1 + math.exp(1.0 - auto_iou) * b2 + torch.exp(-(target - 1.0)) * b3)
+        return loss.mean()
+
+    @staticmethod
+    def _wasserstein(pred, target, eps=1e-7, constant=12.8):
+        """utils/metrics.py:341-354, fed xywh boxes although it reads its columns as x1y1x2y2 - kept as the reference has it."""
+        b1_x1, b1_y1, b1_x2, b1_y2 = pred.split(1, dim=-1)
+        b2_x1, b2_y1, b2_x2, b2_y2 = target.split(1, dim=-1)
+        w1, h1 = b1_x2 - b1_x1, b1_y2 - b1_y1 + eps
+        w2, h2 = b2_x2 - b2_x1, b2_y2 - b2_y1 + eps
+        cd = ((b1_x1 + b1_x2) / 2 - (b2_x1 + b2_x2) / 2).pow(2) + ((b1_y1 + b1_y2) / 2 - (b2_y1 + b2_y2) / 2).pow(2) + eps
+        return torch.exp(-torch.sqrt(cd + ((w1 - w2).pow(2) + (h1 - h2).pow(2)) / 4) / constant)
 
     def __call__(self, p, targets):
         dev = targets.device
@@ -74,17 +104,24 @@ class ComputeLoss:
                 ps = pi[b, a, gj, gi]
                 pxy = ps[:, :2].sigmoid() * 2 - 0.5
                 pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * anchors[i]
-                iou = bbox_ciou_xywh(torch.cat((pxy, pwh), 1).T, tbox[i])
-                lbox = lbox + (1.0 - iou).mean()
-                iou = iou.detach().clamp(0, 1).type(tobj.dtype)
+                pbox = torch.cat((pxy, pwh), 1)
+                iou = bbox_ciou_xywh(pbox.T, tbox[i])
+                if self.nwd:                                                               # :162-169, iou_ratio = 0.5 (:148)
+                    nwd = self._wasserstein(pbox, tbox[i]).squeeze()
+                    lbox = lbox + 0.5 * (1.0 - iou).mean() + 0.5 * (1.0 - nwd).mean()
+                    iou = (iou.detach() * 0.5 + nwd.detach() * 0.5).clamp(0, 1).type(tobj.dtype)
+                else:
+                    lbox = lbox + (1.0 - iou).mean()
+                    iou = iou.detach().clamp(0, 1).type(tobj.dtype)
                 order = torch.argsort(iou)                                                 # :174-176
                 b, a, gj, gi, iou = b[order], a[order], gj[order], gi[order], iou[order]
                 tobj[b, a, gj, gi] = (1.0 - self.gr) + self.gr * iou                       # last write wins
+                auto_iou = iou.mean()                                                      # :180
                 if self.nc > 1:
                     t = torch.full_like(ps[:, 5:], self.cn)
                     t[range(n), tcls[i]] = self.cp
-                    lcls = lcls + self._bce(ps[:, 5:], t, self.cls_pw)
-            lobj = lobj + self._bce(pi[..., 4], tobj, self.obj_pw) * self.balance[i]
+                    lcls = lcls + self._bce(ps[:, 5:], t, self.cls_pw, auto_iou)
+            lobj = lobj + self._bce(pi[..., 4], tobj, self.obj_pw, auto_iou if n else None) * self.balance[i]
         lbox = lbox * self.hyp['box']
         lobj = lobj * self.hyp['obj']
         lcls = lcls * self.hyp['cls']

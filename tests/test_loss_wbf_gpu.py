@@ -42,12 +42,35 @@ def test_compute_loss_matches_reference_vectors(golden, tag):
     rel_close(l2, g['loss'], rel=1e-4, what='loss (no grad)')
 
 
-def test_compute_loss_rejects_disabled_branches():
+@pytest.mark.parametrize('tag', ['focal', 'slide', 'focal_slide', 'nwd', 'all'])
+def test_compute_loss_branches_match_reference_vectors(golden, tag):
+    """FocalLoss / SlideLoss / both stacked / the NWD box term / everything with label smoothing (utils/loss.py:35-60,125-131,162-169,
+    378-402; hyp.VisDrone.yaml leaves them off): loss, items and gradients against the reference's own ComputeLoss under those
+    hyper-parameters, plus the value-only path."""
     from somi_amd.configs import HYP_VISDRONE
     from somi_amd.loss import ComputeLoss
-    h = dict(HYP_VISDRONE, fl_gamma=1.5)
+    g = golden('loss_branch_' + tag)
+    hyp = dict(HYP_VISDRONE, **{str(k): float(v) for k, v in zip(g['hyp_keys'], g['hyp_vals'])})
+    crit = ComputeLoss(_M(T(g['anchors']), hyp))
+    p = [T(g[f'p{i}']).cuda().requires_grad_(True) for i in range(4)]
+    loss, items = crit(p, T(g['targets']).cuda())
+    rel_close(loss, g['loss'], rel=1e-4, what=f'{tag}: loss')
+    rel_close(items, g['items'], rel=1e-4, what=f'{tag}: loss_items')
+    loss.backward()
+    for i in range(4):
+        rel_close(p[i].grad, g[f'g{i}'], rel=1e-3, what=f'{tag}: d loss / d p[{i}]')
+    with torch.no_grad():
+        l2, _ = crit([t.detach() for t in p], T(g['targets']).cuda())
+    rel_close(l2, g['loss'], rel=1e-4, what=f'{tag}: loss (no grad)')
+
+
+def test_compute_loss_rejects_what_is_not_restated():
+    from somi_amd.configs import HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
     with pytest.raises(NotImplementedError):
-        ComputeLoss(_M(torch.ones(4, 4, 2), h))
+        ComputeLoss(_M(torch.ones(4, 4, 2), dict(HYP_VISDRONE, nwdloss=1.0, shapeloss=1.0)))
+    with pytest.raises(NotImplementedError):
+        ComputeLoss(_M(torch.ones(4, 4, 2), dict(HYP_VISDRONE)), autobalance=True)
 
 
 def _wbf_inputs(seed, nm=2, n=120):

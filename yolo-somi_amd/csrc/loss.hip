@@ -18,13 +18,18 @@
 //               sums per workgroup) and, when gradients are wanted, the objectness gradient plus the 1/n scaling of
 //               the box / class gradients written in step 1.
 //   4. finish   fixed-order reduction of slots and partials -> out[0..3] = (lbox+lobj+lcls)*bs, lbox, lobj, lcls.
-// Branches hyp.VisDrone.yaml switches off (focal, slide, NWD, autobalance) are rejected by the host layer.
+// The branches hyp.VisDrone.yaml leaves off are here too: FocalLoss (utils/loss.py:35-60) and SlideLoss (:378-402) as per-element
+// weights of both BCE terms (stacked like :125-131), the NWD box term (:162-169, utils/metrics.py:341-354) blended into the box loss,
+// its gradient and the objectness target.  SlideLoss needs the level's mean IoU before any BCE can be weighted, so the class BCE of
+// the matched entries is evaluated in pass 1b (after a one-workgroup-per-level mean, 1a).  autobalance is rejected by the host layer.
 #include "common.h"
 
 namespace somi {
 
 constexpr float CIOU_EPS = 1e-7f;
 constexpr int NOFF = 5;
+constexpr int SLOT = 3;
+constexpr float NWD_EPS = 1e-7f, NWD_CONSTANT = 12.8f, FOCAL_ALPHA = 0.25f;
 
 struct LossArgs {
     somi_loss_desc d;
@@ -34,7 +39,8 @@ struct LossArgs {
     int nblk[4];            // dense workgroups per level
     int blk_off[4];
     unsigned *tobj;         // [sum cells] float bits (>= 0), zeroed
-    float *slots;           // [nl][na*nt*NOFF][2] = {1-ciou or -1 (invalid), cls bce sum}
+    float *slots;           // [nl][na*nt*NOFF][SLOT] = {box loss or -1 (invalid), cls bce sum, clamp(iou,0,1)}
+    float *auto_iou;        // [4] per level: mean of the entries' clamped IoU (SlideLoss), 0.5 when the level has none
     int *nent;              // [4] entries per level, zeroed
     int *head;              // [sum cells] last entry pushed onto the cell's list, -1 = none (only with gradients)
     int *next;              // [nl][na*nt*NOFF] list links
@@ -62,6 +68,21 @@ __device__ __forceinline__ Dual dmax(Dual a, Dual b) { return a.v >= b.v ? a : b
 __device__ __forceinline__ Dual dclamp0(Dual a) { return a.v > 0.f ? a : dconst(0.f); }   // clamp(0): zero grad at/below 0
 __device__ __forceinline__ Dual datan(Dual a) { Dual r; r.v = atanf(a.v); const float s = 1.f / (1.f + a.v * a.v); for (int i = 0; i < 4; ++i) r.g[i] = a.g[i] * s; return r; }
 
+__device__ __forceinline__ Dual dsqrt(Dual a) { Dual r; r.v = sqrtf(a.v); const float s = 0.5f / r.v; for (int i = 0; i < 4; ++i) r.g[i] = a.g[i] * s; return r; }
+__device__ __forceinline__ Dual dexp(Dual a) { Dual r; r.v = expf(a.v); for (int i = 0; i < 4; ++i) r.g[i] = a.g[i] * r.v; return r; }
+
+// wasserstein_loss (utils/metrics.py:341-354): written for x1y1x2y2 boxes but fed (x, y, w, h) by ComputeLoss (utils/loss.py:166) - the
+// columns are used exactly as the reference uses them
+__device__ __forceinline__ Dual nwd_xywh(Dual px, Dual py, Dual pw, Dual ph, float tx, float ty, float tw, float th) {
+    const Dual w1 = pw - px, h1 = (ph - py) + NWD_EPS;
+    const float w2 = tw - tx, h2 = (th - ty) + NWD_EPS;
+    const Dual dcx = (px + pw) * 0.5f + (-(tx + tw) / 2), dcy = (py + ph) * 0.5f + (-(ty + th) / 2);
+    const Dual cd = (dcx * dcx + dcy * dcy) + NWD_EPS;
+    const Dual dw = w1 + (-w2), dh = h1 + (-h2);
+    const Dual whd = (dw * dw + dh * dh) * 0.25f;
+    return dexp(dsqrt(cd + whd) * (-1.f / NWD_CONSTANT));
+}
+
 // CIoU of predicted (px,py,pw,ph) vs target (tx,ty,tw,th), xywh (utils/metrics.py:476-518 with alpha=1)
 __device__ __forceinline__ Dual ciou_xywh(Dual px, Dual py, Dual pw, Dual ph, float tx, float ty, float tw, float th) {
     const Dual b1x1 = px - pw * 0.5f, b1x2 = px + pw * 0.5f, b1y1 = py - ph * 0.5f, b1y2 = py + ph * 0.5f;
@@ -87,6 +108,35 @@ __device__ __forceinline__ float bce_logits(float x, float y, float pw) { return
 __device__ __forceinline__ float bce_logits_grad(float x, float y, float pw) {
     const float s = 1.f / (1.f + expf(-x));
     return (1.f - y) - (1.f + (pw - 1.f) * y) * (1.f - s);
+}
+
+// SlideLoss weight of a target value (utils/loss.py:386-395); auto_iou is floored at 0.2 (:387-388)
+__device__ __forceinline__ float slide_weight(float y, float auto_iou) {
+    const float ai = auto_iou < 0.2f ? 0.2f : auto_iou;
+    if (y <= ai - 0.1f) return 1.f;
+    if (y < ai) return expf(1.f - ai);
+    return expf(-(y - 1.f));
+}
+// One element of [SlideLoss(][FocalLoss(]BCEWithLogits(pos_weight)[)][)] with reduction 'none' (utils/loss.py:47-53,385-396):
+// value and d value / d logit.  gamma <= 0: no focal factor; slide == 0: no slide factor.
+__device__ __forceinline__ void weighted_bce(float x, float y, float pw, float gamma, int slide, float auto_iou, float &val, float &grad) {
+    float l = bce_logits(x, y, pw), dl = bce_logits_grad(x, y, pw);
+    if (gamma > 0.f) {
+        const float s = 1.f / (1.f + expf(-x));
+        const float q = 1.f - (y * s + (1.f - y) * (1.f - s));                              // 1 - p_t
+        const float af = y * FOCAL_ALPHA + (1.f - y) * (1.f - FOCAL_ALPHA);
+        const float m = q > 0.f ? powf(q, gamma) : 0.f;
+        const float dm = q > 0.f ? gamma * powf(q, gamma - 1.f) * (-(2.f * y - 1.f) * s * (1.f - s)) : 0.f;
+        dl = af * (dl * m + l * dm);
+        l = l * af * m;
+    }
+    if (slide) {
+        const float w = slide_weight(y, auto_iou);
+        l *= w;
+        dl *= w;
+    }
+    val = l;
+    grad = dl;
 }
 
 // ------------------------------------------------------------------------------------------------ 1. match
@@ -121,7 +171,8 @@ __device__ __forceinline__ Triple load_triple(const somi_loss_desc &d, int l, in
 // One entry (triple, offset k): its cell, the decoded box, CIoU with the derivatives w.r.t. the four box logits
 struct Entry {
     size_t cell;
-    Dual c;
+    Dual c;                 // the box term's similarity: CIoU, or (1-r) CIoU + r NWD with the NWD branch on; box loss = 1 - c.v
+    float iou01;            // what goes to the objectness target / SlideLoss mean: clamp(c.v, 0, 1)
     float s0, s1, s2, s3;
 };
 __device__ __forceinline__ Entry eval_entry(const somi_loss_desc &d, int no, const float *pl, const Triple &r, int an, int k) {
@@ -138,6 +189,11 @@ __device__ __forceinline__ Entry eval_entry(const somi_loss_desc &d, int no, con
     const float pxv = e.s0 * 2.f - 0.5f, pyv = e.s1 * 2.f - 0.5f;
     const float pwv = (e.s2 * 2.f) * (e.s2 * 2.f) * r.aw, phv = (e.s3 * 2.f) * (e.s3 * 2.f) * r.ah;
     e.c = ciou_xywh(dvar(pxv, 0), dvar(pyv, 1), dvar(pwv, 2), dvar(phv, 3), tbx, tby, r.gw, r.gh);
+    if (d.nwd_ratio > 0.f) {                                                              // utils/loss.py:162-169
+        const Dual w = nwd_xywh(dvar(pxv, 0), dvar(pyv, 1), dvar(pwv, 2), dvar(phv, 3), tbx, tby, r.gw, r.gh);
+        e.c = e.c * (1.f - d.nwd_ratio) + w * d.nwd_ratio;
+    }
+    e.iou01 = fminf(fmaxf(e.c.v, 0.f), 1.f);
     return e;
 }
 
@@ -148,8 +204,8 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= per_level) return;
     const int an = idx / d.nt, t = idx % d.nt;                 // anchor-major like targets.repeat(na,1,1)
-    float *slot = a.slots + ((size_t)l * per_level + idx) * NOFF * 2;
-    for (int k = 0; k < NOFF; ++k) slot[k * 2] = -1.f;         // invalid
+    float *slot = a.slots + ((size_t)l * per_level + idx) * NOFF * SLOT;
+    for (int k = 0; k < NOFF; ++k) slot[k * SLOT] = -1.f;      // invalid
     const Triple r = load_triple(d, l, an, t);
     if (!r.ok) return;
     const float *pl = d.p[l];
@@ -157,15 +213,10 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossArgs a) {
     for (int k = 0; k < NOFF; ++k) {
         if (!r.use[k]) continue;
         const Entry e = eval_entry(d, a.no, pl, r, an, k);
-        slot[k * 2] = 1.f - e.c.v;
-        const float iou01 = fminf(fmaxf(e.c.v, 0.f), 1.f);
-        atomicMax(a.tobj + a.cell_off[l] + e.cell, __float_as_uint((1.f - d.gr) + d.gr * iou01));
-        float csum = 0.f;
-        if (d.nc > 1) {
-            const float *ps = pl + e.cell * a.no;
-            for (int j = 0; j < d.nc; ++j) csum += bce_logits(ps[5 + j], j == r.cls ? d.cp : d.cn, d.cls_pw);
-        }
-        slot[k * 2 + 1] = csum;
+        slot[k * SLOT] = 1.f - e.c.v;
+        slot[k * SLOT + 1] = 0.f;
+        slot[k * SLOT + 2] = e.iou01;
+        atomicMax(a.tobj + a.cell_off[l] + e.cell, __float_as_uint((1.f - d.gr) + d.gr * e.iou01));
         if (d.grad[l]) {                                        // push onto the cell's list; 1b sums the list in a fixed order
             const int ent = ((int)l * per_level + idx) * NOFF + k;
             a.next[ent] = atomicExch(a.head + a.cell_off[l] + e.cell, ent);
@@ -175,6 +226,26 @@ __global__ __launch_bounds__(256) void loss_match_kernel(const LossArgs a) {
     if (emitted) atomicAdd(a.nent + l, emitted);
 }
 
+// ------------------------------------------------------------------------------------------------ 1a. per-level mean IoU (SlideLoss)
+// auto_iou = iou.mean() over the level's entries (utils/loss.py:180); 0.5 - SlideLoss's default - for a level without entries (:191-194)
+__global__ __launch_bounds__(256) void loss_level_mean_kernel(const LossArgs a) {
+    __shared__ double red[256];
+    const somi_loss_desc &d = a.d;
+    const int l = blockIdx.x;
+    const int per_level = d.na * d.nt * NOFF;
+    const float *sl = a.slots + (size_t)l * per_level * SLOT;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < per_level; i += 256)
+        if (sl[i * SLOT] >= 0.f) s += sl[i * SLOT + 2];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.auto_iou[l] = a.nent[l] ? (float)(red[0] / a.nent[l]) : 0.5f;
+}
+
 // ------------------------------------------------------------------------------------------------ 1b. gradient of the matched entries
 __global__ __launch_bounds__(256) void loss_scatter_kernel(const LossArgs a) {
     const somi_loss_desc &d = a.d;
@@ -182,15 +253,28 @@ __global__ __launch_bounds__(256) void loss_scatter_kernel(const LossArgs a) {
     const int per_level = d.na * d.nt;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float *gl = d.grad[l];
-    if (idx >= per_level || !gl) return;
+    if (idx >= per_level) return;
     const int an = idx / d.nt, t = idx % d.nt;
     const Triple r = load_triple(d, l, an, t);
     if (!r.ok) return;
     const float *pl = d.p[l];
     const int base = (int)l * per_level * NOFF;
+    const float ai = d.slide ? a.auto_iou[l] : 0.5f;
+    float *slot = a.slots + ((size_t)l * per_level + idx) * NOFF * SLOT;
     for (int k = 0; k < NOFF; ++k) {
         if (!r.use[k]) continue;
         const Entry own = eval_entry(d, a.no, pl, r, an, k);
+        const float *ps = pl + own.cell * a.no;
+        if (d.nc > 1) {                                          // this entry's class BCE (utils/loss.py:182-189)
+            float csum = 0.f;
+            for (int j = 0; j < d.nc; ++j) {
+                float v, g_;
+                weighted_bce(ps[5 + j], j == r.cls ? d.cp : d.cn, d.cls_pw, d.fl_gamma, d.slide, ai, v, g_);
+                csum += v;
+            }
+            slot[k * SLOT + 1] = csum;
+        }
+        if (!gl) continue;
         const int ent = base + idx * NOFF + k;
         const int *head = a.head + a.cell_off[l] + own.cell;
         if (*head != ent) continue;                              // exactly one entry per hit cell heads its list
@@ -208,13 +292,16 @@ __global__ __launch_bounds__(256) void loss_scatter_kernel(const LossArgs a) {
             const int an2 = idx2 / d.nt, t2 = idx2 % d.nt;       // same level, same anchor (the cell index contains it)
             const Triple r2 = load_triple(d, l, an2, t2);
             const Entry e = eval_entry(d, a.no, pl, r2, an2, k2);
-            gb[0] += -e.c.g[0] * 2.f * e.s0 * (1.f - e.s0);     // d(1-ciou)/d logits, unscaled
+            gb[0] += -e.c.g[0] * 2.f * e.s0 * (1.f - e.s0);     // d(1 - similarity)/d logits, unscaled
             gb[1] += -e.c.g[1] * 2.f * e.s1 * (1.f - e.s1);
             gb[2] += -e.c.g[2] * 8.f * e.s2 * e.s2 * (1.f - e.s2) * r2.aw;
             gb[3] += -e.c.g[3] * 8.f * e.s3 * e.s3 * (1.f - e.s3) * r2.ah;
             if (d.nc > 1) {
-                const float *ps = pl + own.cell * a.no;
-                for (int j = 0; j < d.nc; ++j) g[5 + j] += bce_logits_grad(ps[5 + j], j == r2.cls ? d.cp : d.cn, d.cls_pw);
+                for (int j = 0; j < d.nc; ++j) {
+                    float v, g_;
+                    weighted_bce(ps[5 + j], j == r2.cls ? d.cp : d.cn, d.cls_pw, d.fl_gamma, d.slide, ai, v, g_);
+                    g[5 + j] += g_;
+                }
             }
         }
         g[0] = gb[0]; g[1] = gb[1]; g[2] = gb[2]; g[3] = gb[3];
@@ -233,6 +320,7 @@ __global__ __launch_bounds__(256) void loss_dense_kernel(const LossArgs a, int l
     const float obj_scale = d.balance[l] * d.obj_gain * bs / (float)cells;
     const float box_scale = n ? d.box_gain * bs / (float)n : 0.f;
     const float cls_scale = n ? d.cls_gain * bs / ((float)n * (float)d.nc) : 0.f;
+    const float ai = d.slide ? a.auto_iou[l] : 0.5f;               // 0.5 (SlideLoss's default) for a level without entries
     float part = 0.f;
     if (gl) {
         const long items = cells * a.no;
@@ -240,16 +328,21 @@ __global__ __launch_bounds__(256) void loss_dense_kernel(const LossArgs a, int l
             const int ch = (int)(it % a.no);
             if (ch == 4) {
                 const float x = pl[it], y = __uint_as_float(a.tobj[a.cell_off[l] + it / a.no]);
-                part += bce_logits(x, y, d.obj_pw);
-                gl[it] = bce_logits_grad(x, y, d.obj_pw) * obj_scale;
+                float v, g_;
+                weighted_bce(x, y, d.obj_pw, d.fl_gamma, d.slide, ai, v, g_);
+                part += v;
+                gl[it] = g_ * obj_scale;
             } else {
                 const float gv = gl[it];
                 if (gv != 0.f) gl[it] = gv * (ch < 4 ? box_scale : cls_scale);
             }
         }
     } else {
-        for (long cidx = blockIdx.x * 256L + threadIdx.x; cidx < cells; cidx += (long)gridDim.x * 256)
-            part += bce_logits(pl[cidx * a.no + 4], __uint_as_float(a.tobj[a.cell_off[l] + cidx]), d.obj_pw);
+        for (long cidx = blockIdx.x * 256L + threadIdx.x; cidx < cells; cidx += (long)gridDim.x * 256) {
+            float v, g_;
+            weighted_bce(pl[cidx * a.no + 4], __uint_as_float(a.tobj[a.cell_off[l] + cidx]), d.obj_pw, d.fl_gamma, d.slide, ai, v, g_);
+            part += v;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -266,9 +359,9 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const LossArgs a, floa
     for (int l = 0; l < d.nl; ++l) {
         // fixed-order reductions: thread-strided partial sums, then a tree over the 256 lanes
         double sb = 0.0, sc = 0.0, so = 0.0;
-        const float *sl = a.slots + (size_t)l * per_level * 2;
+        const float *sl = a.slots + (size_t)l * per_level * SLOT;
         for (int i = threadIdx.x; i < per_level; i += 256)
-            if (sl[i * 2] >= 0.f) { sb += sl[i * 2]; sc += sl[i * 2 + 1]; }
+            if (sl[i * SLOT] >= 0.f) { sb += sl[i * SLOT]; sc += sl[i * SLOT + 1]; }
         for (int i = threadIdx.x; i < a.nblk[l]; i += 256) so += a.partial[a.blk_off[l] + i];
         double vals[3] = {sb, sc, so};
         for (int q = 0; q < 3; ++q) {
@@ -330,7 +423,7 @@ extern "C" size_t somi_loss_workspace_bytes(const somi_loss_desc *d) {
     LossArgs a;
     if (!d || plan(*d, a)) return 0;
     const size_t tobj = align_up((size_t)(a.cell_off[d->nl - 1] + a.cells[d->nl - 1]) * 4, 256);
-    const size_t slots = align_up((size_t)d->nl * d->na * (d->nt > 0 ? d->nt : 1) * NOFF * 2 * 4, 256);
+    const size_t slots = align_up((size_t)d->nl * d->na * (d->nt > 0 ? d->nt : 1) * NOFF * SLOT * 4, 256);
     const size_t part = align_up((size_t)(a.blk_off[d->nl - 1] + a.nblk[d->nl - 1]) * 4, 256);
     const size_t next = align_up((size_t)d->nl * d->na * (d->nt > 0 ? d->nt : 1) * NOFF * 4, 256);
     return tobj + 256 + slots + part + tobj + next;      // + the per-cell list heads and the entry links of the gradient pass
@@ -349,8 +442,9 @@ extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *w
     char *w = static_cast<char *>(workspace);
     const size_t tobj_b = align_up((size_t)(a.cell_off[d.nl - 1] + a.cells[d.nl - 1]) * 4, 256);
     a.tobj = reinterpret_cast<unsigned *>(w); w += tobj_b;
-    a.nent = reinterpret_cast<int *>(w); w += 256;
-    a.slots = reinterpret_cast<float *>(w); w += align_up((size_t)d.nl * d.na * (d.nt > 0 ? d.nt : 1) * NOFF * 2 * 4, 256);
+    a.nent = reinterpret_cast<int *>(w);
+    a.auto_iou = reinterpret_cast<float *>(w + 64); w += 256;          // same zeroed 256-byte block: counters, then the level means
+    a.slots = reinterpret_cast<float *>(w); w += align_up((size_t)d.nl * d.na * (d.nt > 0 ? d.nt : 1) * NOFF * SLOT * 4, 256);
     a.partial = reinterpret_cast<float *>(w); w += align_up((size_t)(a.blk_off[d.nl - 1] + a.nblk[d.nl - 1]) * 4, 256);
     a.head = reinterpret_cast<int *>(w); w += tobj_b;
     a.next = reinterpret_cast<int *>(w);
@@ -360,9 +454,13 @@ extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *w
     if (any_grad && d.nt > 0) (void)hipMemsetAsync(a.head, 0xFF, tobj_b, s);   // -1: empty lists
     for (int l = 0; l < d.nl; ++l)
         if (d.grad[l]) (void)hipMemsetAsync(d.grad[l], 0, (size_t)a.cells[l] * a.no * 4, s);
+    SOMI_REQUIRE(d.fl_gamma >= 0.f && d.nwd_ratio >= 0.f && d.nwd_ratio <= 1.f, SOMI_EINVAL, "loss: bad focal gamma / NWD ratio");
     if (d.nt > 0) {
         hipLaunchKernelGGL(loss_match_kernel, dim3(cdiv((long)d.na * d.nt, 256), d.nl), dim3(256), 0, s, a);
-        if (any_grad) hipLaunchKernelGGL(loss_scatter_kernel, dim3(cdiv((long)d.na * d.nt, 256), d.nl), dim3(256), 0, s, a);
+        if (d.slide) hipLaunchKernelGGL(loss_level_mean_kernel, dim3(d.nl), dim3(256), 0, s, a);
+        if (any_grad || d.nc > 1) hipLaunchKernelGGL(loss_scatter_kernel, dim3(cdiv((long)d.na * d.nt, 256), d.nl), dim3(256), 0, s, a);
+    } else if (d.slide) {
+        hipLaunchKernelGGL(loss_level_mean_kernel, dim3(d.nl), dim3(256), 0, s, a);     // no entries anywhere: every level gets the default
     }
     for (int l = 0; l < d.nl; ++l) hipLaunchKernelGGL(loss_dense_kernel, dim3(a.nblk[l]), dim3(256), 0, s, a, l);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, a, out4);

@@ -32,7 +32,8 @@ class LossDesc(C.Structure):
                 ('nl', C.c_int32), ('na', C.c_int32), ('nc', C.c_int32), ('B', C.c_int32), ('nt', C.c_int32),
                 ('targets', C.c_void_p), ('anchors', C.c_void_p), ('balance', C.c_float * 4),
                 ('box_gain', C.c_float), ('obj_gain', C.c_float), ('cls_gain', C.c_float), ('cls_pw', C.c_float),
-                ('obj_pw', C.c_float), ('anchor_t', C.c_float), ('cp', C.c_float), ('cn', C.c_float), ('gr', C.c_float)]
+                ('obj_pw', C.c_float), ('anchor_t', C.c_float), ('cp', C.c_float), ('cn', C.c_float), ('gr', C.c_float),
+                ('fl_gamma', C.c_float), ('slide', C.c_int32), ('nwd_ratio', C.c_float)]
 
 
 class AugSource(C.Structure):

@@ -2,9 +2,9 @@
 
 `ComputeLoss(model)(p, targets) -> (loss[1], loss_items[3] detached)`; p is the list of (B,na,ny,nx,no) training
 outputs, targets (nt,6) = [image, class, x, y, w, h] normalised.  The loss value and d loss / d p come out of the same
-fused launches; autograd sees one node.  hyp keys read: cls_pw, obj_pw, fl_gamma, slide_ratio, nwdloss, box, obj, cls,
-anchor_t (+label_smoothing) - the ones the reference's __init__ reads; the branches hyp.VisDrone.yaml leaves off
-(focal, slide, NWD, autobalance) raise NotImplementedError.
+fused launches; autograd sees one node.  hyp keys read: cls_pw, obj_pw, fl_gamma, slide_ratio, nwdloss, shapeloss, box, obj, cls,
+anchor_t (+label_smoothing) - the ones the reference's __init__ / __call__ read.  FocalLoss (fl_gamma > 0), SlideLoss (slide_ratio > 0)
+and the NWD box term (nwdloss > 0) run inside the same kernels; autobalance and the shapeloss NWD variant raise NotImplementedError.
 """
 import ctypes as C
 
@@ -37,8 +37,8 @@ class ComputeLoss:
     def __init__(self, model, autobalance=False):
         self.sort_obj_iou = False
         h = model.hyp
-        if autobalance or h['fl_gamma'] > 0 or h['slide_ratio'] > 0 or h['nwdloss'] > 0:
-            raise NotImplementedError('focal / slide / NWD / autobalance are off in hyp.VisDrone.yaml and not on the HIP path')
+        if autobalance or (h['nwdloss'] > 0 and h.get('shapeloss', 0) > 0):
+            raise NotImplementedError('autobalance and the shapeloss NWD variant (utils/metrics.py:373) are not on the HIP path')
         det = model.model[-1]
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
         self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, 0.02])       # utils/loss.py:135
@@ -74,6 +74,8 @@ class ComputeLoss:
         d.box_gain, d.obj_gain, d.cls_gain = float(h['box']), float(h['obj']), float(h['cls'])
         d.cls_pw, d.obj_pw, d.anchor_t = float(h['cls_pw']), float(h['obj_pw']), float(h['anchor_t'])
         d.cp, d.cn, d.gr = float(self.cp), float(self.cn), float(self.gr)
+        d.fl_gamma, d.slide = float(h['fl_gamma']), int(h['slide_ratio'] > 0)
+        d.nwd_ratio = 0.5 if h['nwdloss'] > 0 else 0.0           # iou_ratio, utils/loss.py:148
         L = _lib.lib()
         nbytes = L.somi_loss_workspace_bytes(C.byref(d))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)

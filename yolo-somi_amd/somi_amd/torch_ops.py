@@ -120,7 +120,7 @@ def yolo_loss(p: List[torch.Tensor], targets: torch.Tensor, anchors: torch.Tenso
     m = _M()
     m.model = [det]
     m.hyp = dict(box=gains[0], obj=gains[1], cls=gains[2], cls_pw=gains[3], obj_pw=gains[4], anchor_t=gains[5], fl_gamma=0.0, slide_ratio=0,
-                 nwdloss=0, label_smoothing=0.0)
+                 nwdloss=0, shapeloss=0, label_smoothing=0.0)
     crit = ComputeLoss(m)
     crit.cp, crit.cn, crit.gr = gains[6], gains[7], gains[8]
     crit.balance = list(balance)
