@@ -62,7 +62,7 @@ sys.path.insert(0, f'{REF}/models/ops_dcnv3')
 from functions.dcnv3_func import dcnv3_core_pytorch  # noqa: E402
 
 sys.path.insert(0, ROOT)
-from oracle.somi_ref.testing import fill_state, synthetic_batch, somi_cfg, yolov5_cfg, SOMI_ANCHORS, HYP_VISDRONE  # noqa: E402
+from oracle.somi_ref.testing import fill_state, synthetic_batch, somi_cfg, tiny_somi_cfg, yolov5_cfg, SOMI_ANCHORS, HYP_VISDRONE  # noqa: E402
 from oracle.somi_ref.nms import greedy_nms  # noqa: E402
 
 # the NMS core is third-party (torchvision): install the restated greedy NMS so the reference's
@@ -346,6 +346,33 @@ def gen_dcn():
     save('model_w025_dcn', **rec)
 
 
+# ------------------------------------------------------------------------------------------------ checkpoint (N4)
+def gen_ckpt():
+    """A checkpoint exactly as train.py:310-317 writes it - `torch.save` of a dict whose 'model' / 'ema' entries are whole pickled
+    module objects of the reference's own classes (models.yolo.Model, models.common.*, and `Conv` under the module path the reference
+    really gets it from, ultralytics.nn.modules.conv), in half precision.  The fixture is the file's bytes; the expected
+    weights are regenerated from names by fill_state.  ema: a cut-down SOMI graph using every SOMI module class (seed 4); model: yolov5 v6.0 at
+    width 0.125 (seed 5)."""
+    import io
+    from copy import deepcopy
+    conv_cls = sys.modules['ultralytics.nn.modules.conv'].Conv
+    conv_cls.__module__, conv_cls.__qualname__ = 'ultralytics.nn.modules.conv', 'Conv'
+    ema = fill_state(RY.Model(tiny_somi_cfg()), 4)
+    mdl = fill_state(RY.Model(yolov5_cfg(0.125, 0.33, nc=80)), 5)
+    ema.names = [f'class{i}' for i in range(10)]
+    ema.hyp = dict(HYP_VISDRONE)
+    ckpt = {'epoch': 12, 'best_fitness': np.array([0.4321]), 'model': deepcopy(mdl).half(), 'ema': deepcopy(ema).half(), 'updates': 345,
+            'optimizer': None, 'wandb_id': None, 'date': '2026-01-01T00:00:00'}
+    buf = io.BytesIO()
+    torch.save(ckpt, buf)
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(900))
+    ema.eval()
+    with torch.no_grad():
+        z, _ = deepcopy(ema).half().float()(x)                   # what attempt_load(...).float() evaluates (models/experimental.py:96-100)
+    save('checkpoint_ref', bytes=np.frombuffer(buf.getvalue(), dtype=np.uint8), x=x, z=z,
+         nparams_ema=np.int64(sum(p.numel() for p in ema.parameters())), nparams_model=np.int64(sum(p.numel() for p in mdl.parameters())))
+
+
 # ------------------------------------------------------------------------------------------------ loss
 def gen_loss():
     m = build_ref_model(0.25, 0.33, SOMI_ANCHORS)
@@ -584,6 +611,6 @@ def gen_augment():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'stock', 'dcn', 'loss', 'nms', 'val', 'augment']
+    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'stock', 'dcn', 'ckpt', 'loss', 'nms', 'val', 'augment']
     for w in which:
         globals()[f'gen_{w}']()

@@ -148,3 +148,15 @@ def yolov5_cfg(width=0.50, depth=0.33, nc=80, anchors=None, version='6.0'):
           [[17, 20, 23], 1, 'Detect', ['nc', 'anchors']]]
     return dict(nc=nc, depth_multiple=depth, width_multiple=width, anchors=copy.deepcopy(anchors or COCO_ANCHORS),
                 backbone=copy.deepcopy(bb), head=copy.deepcopy(hd))
+
+
+def tiny_somi_cfg(nc=10):
+    """A cut-down graph that uses every module class of the SOMI yaml once (Conv, ODConv_3rd, C2fCBAM, SPPF, nn.Upsample, BiFPN, SEAM,
+    DecoupledDetect) at 32 / 64 channels, two detection levels: ~0.2 M parameters - for fixtures that carry whole pickled models."""
+    import copy
+    bb = [[-1, 1, 'Conv', [32, 3, 2]], [-1, 1, 'ODConv_3rd', [32, 3, 2, 4]], [-1, 1, 'C2fCBAM', [32, True]], [-1, 1, 'Conv', [64, 3, 2]],
+          [-1, 1, 'SPPF', [64, 5]]]
+    hd = [[2, 1, 'Conv', [32]], [4, 1, 'Conv', [32]], [-1, 1, 'nn.Upsample', [None, 2, 'nearest']], [[-1, 5], 1, 'BiFPN', []],
+          [-1, 1, 'SEAM', [32, 1, 16]], [-1, 1, 'C2fCBAM', [32]], [[10, 6], 1, 'DecoupledDetect', ['nc', 'anchors']]]
+    return dict(nc=nc, depth_multiple=1.0, width_multiple=1.0, anchors=[[4, 6, 12, 8, 7, 14, 20, 12], [13, 22, 31, 18, 21, 33, 46, 23]],
+                backbone=copy.deepcopy(bb), head=copy.deepcopy(hd))

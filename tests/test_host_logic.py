@@ -96,6 +96,7 @@ def test_product_config_data_matches_oracle_copy():
     from somi_amd import configs as P
     assert O.somi_cfg(0.5, 0.67) == P.somi_cfg(0.5, 0.67)
     assert O.SOMI_ANCHORS == P.SOMI_ANCHORS and O.HYP_VISDRONE == P.HYP_VISDRONE
+    assert O.tiny_somi_cfg() == P.tiny_somi_cfg() and O.somi_cfg(dcn=True) == P.somi_cfg(dcn=True)
     assert O.COCO_ANCHORS == P.COCO_ANCHORS and all(O.yolov5_cfg(version=v) == P.yolov5_cfg(version=v) for v in ('6.0', '5.0'))
     a, b = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8)), nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8))
     O.fill_state(a, 3), P.fill_state(b, 3)
@@ -261,3 +262,28 @@ def test_custom_ops_are_registered_device_only():
         torch.ops.somi.nms(torch.zeros(1, 10, 15), 0.25, 0.45, False, False, 300)
     with pytest.raises(RuntimeError, match='CUDA tensor'):
         DCNv3.dcnv3_forward(torch.zeros(1, 4, 4, 16), torch.zeros(1, 4, 4, 72), torch.zeros(1, 4, 4, 36), 3, 3, 1, 1, 1, 1, 1, 1, 4, 4, 1.0, 256)
+
+
+def test_read_checkpoint_pickled_by_the_reference_itself(golden):
+    """tests/golden/checkpoint_ref.npz holds the bytes of a checkpoint written the way train.py:310-317 writes it, from the reference's
+    OWN classes (models.yolo.Model, models.common.*, Conv under ultralytics.nn.modules.conv - SURVEY fact 5).  Read back with the
+    default foreign_prefixes and none of that code importable: every class becomes a stand-in, the weights are the half-rounded
+    fill_state values, the architecture dict and the side attributes survive."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import fill_state, tiny_somi_cfg, yolov5_cfg
+    from somi_amd.checkpoint import ForeignModule, read_checkpoint
+    g = golden('checkpoint_ref')
+    ck = read_checkpoint(g['bytes'].tobytes())
+    assert ck['epoch'] == 12 and ck['updates'] == 345 and ck['optimizer'] is None and abs(float(ck['best_fitness'][0]) - 0.4321) < 1e-12
+    for key, cfg, seed in (('ema', tiny_somi_cfg(), 4), ('model', yolov5_cfg(0.125, 0.33, nc=80), 5)):
+        m = ck[key]
+        assert isinstance(m, ForeignModule) and type(m).__module__ == 'models.yolo' and type(m).__name__ == 'Model'
+        mods = {type(x).__module__ for x in m.modules()}
+        assert 'ultralytics.nn.modules.conv' in mods and all(isinstance(x, (ForeignModule, torch.nn.Module)) for x in m.modules())
+        want = fill_state(OModel(cfg), seed).half().state_dict()
+        got = m.state_dict()
+        assert list(got) == list(want)
+        for k in want:
+            assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
+        assert isinstance(m.yaml, dict) and m.yaml['nc'] == cfg['nc']
+    assert ck['ema'].names[3] == 'class3' and ck['ema'].hyp['anchor_t'] == 3

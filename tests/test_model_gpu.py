@@ -210,3 +210,20 @@ def test_other_class_counts(nc):
         err = (p.grad.cpu().double() - q.grad.double()).abs().max().item()
         scale = q.grad.double().abs().max().item()
         assert err <= 2e-3 * scale + 5e-6, (n, err, scale)      # atol: ODConv's squeeze path under a batch-of-2 BN is rounding noise
+
+
+def test_attempt_load_checkpoint_written_by_the_reference(golden, tmp_path):
+    """attempt_load (models/experimental.py:90-122) on the bytes of a checkpoint pickled from the reference's own module classes
+    (tests/golden/checkpoint_ref.npz, default foreign_prefixes): EMA weights first, fp16 -> float, eval; its predictions equal what
+    the reference's own EMA module computes for the same image."""
+    from somi_amd.checkpoint import attempt_load
+    g = golden('checkpoint_ref')
+    f = tmp_path / 'best.pt'
+    f.write_bytes(g['bytes'].tobytes())
+    model, info = attempt_load(str(f))
+    assert info['used'] == 'ema' and info['epoch'] == 12 and info['updates'] == 345
+    assert sum(p.numel() for p in model.parameters()) == int(g['nparams_ema']) and not model.training
+    assert model.names[0] == 'class0' and model.hyp['box'] == 0.07
+    with torch.no_grad():
+        z, _ = model(T(g['x']).cuda())
+    rel_close(z, T(g['z']), what='predictions of the loaded EMA weights')
