@@ -129,6 +129,12 @@ const char *somi_conv2d_kernel_name(const somi_conv_desc *d);
  * kernel_h-inner; mask (N,Ho,Wo,G*K); output (N,Ho,Wo,G*Gc).  All contiguous.
  * Backward: grad_input must be ZEROED by the caller (the reference allocates it with at::zeros,
  * dcnv3_cuda.cu:126-133); grad_offset / grad_mask are fully overwritten.
+ * workspace (optional, may be NULL / 0): somi_dcnv3_backward_workspace_bytes(...) bytes, 16-byte aligned, enable the windowed
+ * form of the fp32 backward (grad_input summed per tile in LDS in exact arithmetic, combined in a fixed order: no float atomics,
+ * run-to-run bit-identical, while every sampling tap stays within SOMI_DCN_SLACK = 2 pixels of the kernel footprint; taps
+ * beyond go through fp32 atomics and are counted in the uint32 at workspace + size - 256).  Without it - or for group widths other than 8/16/32/64 (then the size is 0) - one kernel
+ * scatters with fp32 atomics like the reference.  The _f16 / _f64 entries take the two arguments for a uniform signature and
+ * ignore them.
  * im2col_step is validated like the reference (batch % min(batch, im2col_step) == 0) and otherwise
  * unused: the whole batch is one launch.
  */
@@ -141,7 +147,9 @@ int somi_dcnv3_backward_f32(const float *input, const float *offset, const float
                             float *grad_input, float *grad_offset, float *grad_mask,
                             int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h,
                             int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
-                            float offset_scale, int im2col_step, somi_stream_t stream);
+                            float offset_scale, int im2col_step, void *workspace, size_t workspace_bytes, somi_stream_t stream);
+size_t somi_dcnv3_backward_workspace_bytes(int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w,
+                                           int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale);
 
 /* The other two dtypes the reference extension dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69,136), same argument
  * meaning as the _f32 pair.  _f16: tensors are IEEE half (the AMP path of train.py:263), arithmetic fp32 (the reference's opmath_t),
@@ -154,14 +162,14 @@ int somi_dcnv3_forward_f16(const void *input, const void *offset, const void *ma
 int somi_dcnv3_backward_f16(const void *input, const void *offset, const void *mask, const void *grad_output, float *grad_input,
                             float *grad_offset, float *grad_mask, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w,
                             int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
-                            int im2col_step, somi_stream_t stream);
+                            int im2col_step, void *workspace, size_t workspace_bytes, somi_stream_t stream);
 int somi_dcnv3_forward_f64(const double *input, const double *offset, const double *mask, double *output, int N, int H, int W, int G,
                            int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
                            int dilation_w, float offset_scale, int im2col_step, somi_stream_t stream);
 int somi_dcnv3_backward_f64(const double *input, const double *offset, const double *mask, const double *grad_output, double *grad_input,
                             double *grad_offset, double *grad_mask, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w,
                             int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
-                            int im2col_step, somi_stream_t stream);
+                            int im2col_step, void *workspace, size_t workspace_bytes, somi_stream_t stream);
 
 /* Pieces of the DCNv3 nn.Module around the operator (models/ops_dcnv3/modules/dcnv3.py:283-291,334,370-376):
  *  LayerNorm over C (biased variance, eps inside the sqrt) + activation on contiguous NHWC;

@@ -393,3 +393,51 @@ def test_import_DCNv3_resolves_to_the_drop_in_module_and_custom_ops(golden):
         assert int(count[b]) == w.shape[0] and torch.equal(det[b, :w.shape[0]], w)
     with pytest.raises(NotImplementedError, match="'CPU' backend"):
         torch.ops.somi.dcnv3_forward(x.cpu(), off.cpu(), m.cpu(), *cfg, 256)
+
+
+@pytest.mark.parametrize('N,H,W,G,Gc,k,s,p,d,osc,spread', [(2, 40, 40, 8, 32, 3, 1, 1, 1, 1.0, 0.6),     # the bench graph's site shape
+                                                           (2, 37, 29, 4, 16, 3, 1, 1, 1, 2.0, 0.5),     # ragged tiles, offset_scale 2
+                                                           (3, 21, 17, 4, 8, 3, 2, 1, 1, 1.0, 0.8),      # stride 2
+                                                           (1, 24, 24, 2, 64, 3, 1, 2, 2, 1.0, 0.7),     # dilation 2, 64-wide groups
+                                                           (2, 19, 23, 2, 16, 5, 1, 2, 1, 1.0, 0.6),     # 5x5
+                                                           (2, 33, 33, 8, 32, 3, 1, 1, 1, 1.0, 6.0)])    # most taps beyond the window
+def test_dcnv3_backward_windowed_form(N, H, W, G, Gc, k, s, p, d, osc, spread):
+    """The windowed backward (grad_input summed per tile in LDS in exact arithmetic, staged, combined in a fixed order) against the
+    CPU oracle's autograd, against the direct fp32-atomic form, and against itself: two launches are bit-identical when no tap left
+    its window."""
+    from oracle.somi_ref import dcnv3 as O
+    from somi_amd import ops
+    from somi_amd.dcnv3 import dcnv3_backward
+    g = torch.Generator().manual_seed(H * 131 + W + k)
+    Ho, Wo = O.dcnv3_out_size(H, k, s, p, d), O.dcnv3_out_size(W, k, s, p, d)
+    K = k * k
+    x = torch.randn(N, H, W, G * Gc, generator=g)
+    off = torch.randn(N, Ho, Wo, G * K * 2, generator=g) * spread
+    if spread < 1.0:
+        off.clamp_(-1.9 / osc, 1.9 / osc)                        # stay inside the window's 2 pixels of slack
+    m = torch.softmax(torch.randn(N, Ho, Wo, G, K, generator=g), -1).reshape(N, Ho, Wo, G * K)
+    go = torch.randn(N, Ho, Wo, G * Gc, generator=g)
+    go[0, :3] = 0                                               # an all-zero tile
+    want = O.dcnv3_backward(x, off, m, k, k, s, s, p, p, d, d, G, Gc, osc, go, 256)
+    dev = torch.device('cuda:0')
+    args = (x.to(dev), off.to(dev), m.to(dev), k, k, s, s, p, p, d, d, G, Gc, osc, go.to(dev), 256)
+    a = dcnv3_backward(*args)
+    over = ops.dcn_overflow_taps()
+    assert over is not None or k == 5, 'the windowed form did not run'      # 5x5: the tap lists exceed the LDS budget -> direct form
+    for got, ref, what in zip(a, want, ('grad_input', 'grad_offset', 'grad_mask')):
+        rel_close(got, ref, rel=1e-4, what=f'windowed {what}')
+    b = dcnv3_backward(*args)
+    if over is None:
+        pass
+    elif spread < 1.0:
+        assert over == 0, f'{over} taps left their window at offsets ~N(0,{spread})'
+        assert all(torch.equal(u, v) for u, v in zip(a, b)), 'two launches of the windowed backward differ'
+    else:
+        assert over > 0
+    ops.DCN_DIRECT = True
+    try:
+        c = dcnv3_backward(*args)
+    finally:
+        ops.DCN_DIRECT = False
+    for got, ref, what in zip(c, want, ('grad_input', 'grad_offset', 'grad_mask')):
+        rel_close(got, ref, rel=1e-4, what=f'direct {what}')

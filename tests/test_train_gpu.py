@@ -614,7 +614,7 @@ def _optimizer_restore(opt, snap, model):
     model.invalidate()
 
 
-@pytest.mark.parametrize('graph', ['somi_w025', 'somi_full', 'yolov5s'])
+@pytest.mark.parametrize('graph', ['somi_w025', 'somi_full', 'yolov5s', 'somi_dcn_w025'])
 def test_training_step_is_bit_reproducible(graph):
     """The same TrainStep from the same state, twice: gradients (captured right before the optimizer), BatchNorm statistics, weights,
     Adam moments and the EMA shadow must be bit-identical - every reduction on the path has a fixed order (stream-K fix-up, wgrad
@@ -625,8 +625,17 @@ def test_training_step_is_bit_reproducible(graph):
     from somi_amd.train import TrainStep
     cfg, B, S, nc = {'somi_w025': (somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS), 4, 128, 10),
                      'somi_full': (somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS), 4, 160, 10),
-                     'yolov5s': (yolov5_cfg(), 4, 256, 80)}[graph]
-    model = fill_state(Model(cfg), 5).cuda()
+                     'yolov5s': (yolov5_cfg(), 4, 256, 80),
+                     'somi_dcn_w025': (somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS, dcn=True), 4, 128, 10)}[graph]
+    model = fill_state(Model(cfg), 5)
+    if graph == 'somi_dcn_w025':
+        # the DCNv3 backward is bit-reproducible while every sampling tap stays inside its tile's window (2 pixels of slack around the
+        # kernel footprint; taps beyond go through fp32 atomics like the reference's kernel): keep the learned offsets small
+        with torch.no_grad():
+            for m_ in model.modules():
+                if type(m_).__name__ == 'DCNv3':
+                    m_.offset.weight.mul_(0.2), m_.offset.bias.mul_(0.2)
+    model = model.cuda()
     tr = TrainStep(model, dict(HYP_VISDRONE), B)
     imgs, targets = synthetic_batch(B, S, nc=nc, seed=8)
     targets = torch.cat([targets, targets[:7]])                  # duplicate targets: several entries per loss cell
@@ -655,6 +664,9 @@ def test_training_step_is_bit_reproducible(graph):
                          bufs=tr.optimizer.flat_buffers.clone(), m=[st['m'].clone() for st in tr.optimizer._flat],
                          v=[st['v'].clone() for st in tr.optimizer._flat], ema=[st['ema'].clone() for st in tr.optimizer._flat]))
     a, b = runs
+    if graph == 'somi_dcn_w025':
+        from somi_amd import ops
+        assert ops.dcn_overflow_taps() == 0, 'sampling taps left their window: this run exercises the atomic fallback, not the claim'
 
     def first_difference(x, y, st):
         idx = int((x != y).nonzero()[0])

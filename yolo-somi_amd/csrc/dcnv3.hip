@@ -14,9 +14,23 @@
 //            the Gc/4 lanes of a group), gathers the 4 taps as 16 B loads (a group's channels are contiguous in
 //            NHWC, so a tap is one 4*Gc-byte run) and accumulates; outputs leave as coalesced 16 B stores.
 // HBM-bound: algorithmic bytes per output pixel = 4*(2*C + 3*G*K) forward (input once + output + offset + mask).
-// Backward adds the grad_output read, fp32 atomics into grad_input (as the reference does) and the in-wave
-// reduction over a group's channels for grad_offset / grad_mask (DPP/shuffle butterflies instead of the
-// reference's shared-memory tree).
+// Backward, two forms.
+//   windowed (the fast path; needs a caller workspace, group widths 8/16/32/64):
+//     A  dcnv3_bwd_om_kernel: grad_offset / grad_mask - the forward's gather plus the grad_output read and an in-wave
+//        reduction over a group's channels (shuffle butterflies instead of the reference's shared-memory tree); no atomics.
+//     B  dcnv3_bwd_gin_kernel: grad_input.  The reference scatters 4 taps x K points x C channels of fp32 atomics per output pixel
+//        (36.9 KB/px at C=256: the kernel sat on the chip's 1.3 TB/s float-atomic rate, 2.6 % of the HBM roofline).  Here a
+//        workgroup owns an 8x8 tile of output pixels of ONE group and a window of the input around it (tile + kernel reach + R
+//        pixels of offset slack).  The tile's 64*K*4 taps are bucketed by window cell in LDS (integer counting sort: histogram,
+//        scan, fill), then every (cell, channel) lane sums its cell's list in a register.  The addends are first rounded onto a
+//        power-of-two grid 2^-38 of the tile's largest |grad_output|, so every partial sum is exactly representable: the double sum
+//        is EXACT, hence independent of the (arbitrary) order inside a list.  No float atomics (LDS double atomics measured 35
+//        cycles per wave instruction: 1.7 ms at N32 80x80; this form ... see DESIGN.md).  The window leaves as plain stores into a
+//        staging slab [tile][cell][Gc].
+//     C  dcnv3_bwd_combine_kernel: every input pixel adds the (at most 2x2) windows that cover it in ascending tile order.
+//     grad_input is therefore run-to-run bit-identical whenever every tap stays within R pixels of the kernel footprint; taps
+//     beyond the window (the reference test's offsets of +-20 pixels) go to grad_input as fp32 atomics like the reference's own.
+//   direct (no workspace, other group widths): one kernel, fp32 atomics into grad_input exactly as the reference does.
 #include "common.h"
 
 namespace somi {
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const DcnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward
 // LDS: records, then 3 float accumulators per record (grad_mask, grad_w, grad_h partial sums over channels).
-template <int VEC>
+template <int VEC, bool SCATTER>
 __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const DcnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int GK = a.G * a.K;
@@ -195,14 +209,28 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const DcnArgs a) {
             float gm = 0.f, gw = 0.f, gh = 0.f;
             if (bits) {                                        // wave-divergent only where groups differ
                 const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                f32x4 u1 = {0.f, 0.f, 0.f, 0.f}, u2 = u1, u3 = u1, u4 = u1;      // one 16-byte gather per tap, like the forward
+                if constexpr (VEC == 4) {
+                    if (bits & 1) u1 = *reinterpret_cast<const f32x4 *>(src + r.off[0]);
+                    if (bits & 2) u2 = *reinterpret_cast<const f32x4 *>(src + r.off[1]);
+                    if (bits & 4) u3 = *reinterpret_cast<const f32x4 *>(src + r.off[2]);
+                    if (bits & 8) u4 = *reinterpret_cast<const f32x4 *>(src + r.off[3]);
+                } else {
+                    if (bits & 1) u1[0] = src[r.off[0]];
+                    if (bits & 2) u2[0] = src[r.off[1]];
+                    if (bits & 4) u3[0] = src[r.off[2]];
+                    if (bits & 8) u4[0] = src[r.off[3]];
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float t = tg[e], tm = t * m;
-                    float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-                    if (bits & 1) { v1 = src[r.off[0] + e]; if (live) atomicAdd(gin + r.off[0] + e, w1 * tm); }
-                    if (bits & 2) { v2 = src[r.off[1] + e]; if (live) atomicAdd(gin + r.off[1] + e, w2 * tm); }
-                    if (bits & 4) { v3 = src[r.off[2] + e]; if (live) atomicAdd(gin + r.off[2] + e, w3 * tm); }
-                    if (bits & 8) { v4 = src[r.off[3] + e]; if (live) atomicAdd(gin + r.off[3] + e, w4 * tm); }
+                    const float v1 = u1[e], v2 = u2[e], v3 = u3[e], v4 = u4[e];
+                    if (SCATTER && live) {
+                        if (bits & 1) atomicAdd(gin + r.off[0] + e, w1 * tm);
+                        if (bits & 2) atomicAdd(gin + r.off[1] + e, w2 * tm);
+                        if (bits & 4) atomicAdd(gin + r.off[2] + e, w3 * tm);
+                        if (bits & 8) atomicAdd(gin + r.off[3] + e, w4 * tm);
+                    }
                     // dcnv3_col2im_bilinear: grad_h_weight / grad_w_weight (dcnv3_im2col_cuda.cuh:112-141)
                     const float ghw = -hw * v1 - lw * v2 + hw * v3 + lw * v4;
                     const float gww = -hh * v1 + hh * v2 - lh * v3 + lh * v4;
@@ -238,6 +266,299 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const DcnArgs a) {
         *reinterpret_cast<float2 *>(a.grad_offset + s * 2) =
             make_float2(a.offset_scale * accs[i * 3 + 1], a.offset_scale * accs[i * 3 + 2]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ backward A: grad_offset / grad_mask
+// The forward's structure (records in LDS, 3 sampling points = 12 sixteen-byte gathers in flight per lane) plus the grad_output read and a
+// butterfly over the LG = Gc/4 lanes of a group; no atomics.  Needs Gc/4 a power of two <= 64.
+__global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const DcnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Rec *recs = reinterpret_cast<Rec *>(smem);
+    const int tile = xcd_remap(blockIdx.x, a.ntile);
+    const long pix0 = (long)tile * a.TP;
+    const int np = (int)min((long)a.TP, a.npix - pix0);
+    const int GK = a.G * a.K;
+    for (int i = threadIdx.x; i < np * GK; i += 256) {
+        const int pl = i / GK, gk = i % GK;
+        recs[i] = make_record<true>(a, pix0 + pl, gk / a.K, gk % a.K);
+    }
+    __syncthreads();
+    const int CV = a.C / 4, LG = a.Gc / 4, lane = threadIdx.x & 63;
+    const long img = (long)a.H * a.W * a.C;
+    const int nit = np * CV, nit_pad = (nit + 255) / 256 * 256;       // whole waves stay in the loop for the shuffles
+    for (int it = threadIdx.x; it < nit_pad; it += 256) {
+        const bool live = it < nit;
+        const int itc = live ? it : nit - 1;
+        const int pl = itc / CV, c = (itc % CV) * 4;
+        const long pix = pix0 + pl;
+        const int n = (int)(pix / ((long)a.Ho * a.Wo));
+        const int g = c / a.Gc;
+        const float *src = a.input + n * img + c;
+        const Rec *rr = recs + (pl * a.G + g) * a.K;
+        const f32x4 tg = live ? *reinterpret_cast<const f32x4 *>(a.grad_output + pix * a.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const long sbase = (pix * a.G + g) * a.K;
+        for (int k0 = 0; k0 < a.K; k0 += 3) {
+            const int nk = min(3, a.K - k0);
+            f32x4 u[12];
+            int bits[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const Rec &r = rr[k0 + (j < nk ? j : 0)];
+                bits[j] = j < nk ? __float_as_int(r.f[3]) : 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    u[j * 4 + t] = (bits[j] >> t) & 1 ? *reinterpret_cast<const f32x4 *>(src + r.off[t]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j >= nk) break;                                  // wave-uniform
+                const Rec &r = rr[k0 + j];
+                const float lh = r.f[0], lw = r.f[1], m = r.f[2], hh = 1.f - lh, hw = 1.f - lw;
+                const f32x4 v1 = u[j * 4], v2 = u[j * 4 + 1], v3 = u[j * 4 + 2], v4 = u[j * 4 + 3];
+                // dcnv3_col2im_bilinear: value, grad_h_weight, grad_w_weight (dcnv3_im2col_cuda.cuh:112-141)
+                const f32x4 val = (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
+                const f32x4 ghw = hw * (v3 - v1) + lw * (v4 - v2);
+                const f32x4 gww = hh * (v2 - v1) + lh * (v4 - v3);
+                float gm = (tg[0] * val[0] + tg[1] * val[1]) + (tg[2] * val[2] + tg[3] * val[3]);
+                float gw = ((tg[0] * gww[0] + tg[1] * gww[1]) + (tg[2] * gww[2] + tg[3] * gww[3])) * m;
+                float gh = ((tg[0] * ghw[0] + tg[1] * ghw[1]) + (tg[2] * ghw[2] + tg[3] * ghw[3])) * m;
+                for (int o = LG >> 1; o > 0; o >>= 1) {
+                    gm += __shfl_xor(gm, o);
+                    gw += __shfl_xor(gw, o);
+                    gh += __shfl_xor(gh, o);
+                }
+                if (live && (lane & (LG - 1)) == 0) {                // one lane per group owns the point: plain stores
+                    const long sp = sbase + k0 + j;
+                    a.grad_mask[sp] = gm;
+                    *reinterpret_cast<float2 *>(a.grad_offset + sp * 2) = make_float2(a.offset_scale * gw, a.offset_scale * gh);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward B / C: grad_input
+constexpr int GIN_TH = 8, GIN_TW = 8, GIN_TP = GIN_TH * GIN_TW;      // output pixels per workgroup (one group)
+struct GinGeo {
+    int R;                       // offset slack in input pixels around the kernel footprint
+    int tiles_h, tiles_w;
+    int WH, WW;                  // window extent (input pixels)
+    int lo_h, lo_w;              // window origin = tile origin * stride + lo
+    float *staging;              // [N][G][tiles][WH*WW][Gc]
+    unsigned *overflow;          // taps that fell outside their tile's window (added with fp32 atomics): 0 <=> bit-reproducible
+};
+struct RecG {                    // one sampling point of one output pixel: floor position and the four tap coefficients x mask
+    int h0, w0;
+    float cf[4];                 // 0 for a tap outside the image / an unused point
+};
+
+constexpr int GIN_OVF_CAP = 768;  // LDS list of taps beyond the window; further ones are added by the filing lane itself
+struct OvfG {                    // a tap beyond the window: its image pixel instead of a cell
+    int hw, px;
+    float cf;
+};
+
+// LDS (dynamic): tgt [GIN_TP][GC] floats | recs [GIN_TP*K] | ent_cf [GIN_TP*K*4] floats | ovf [GIN_OVF_CAP] | cnt, start, cur [ncell+1] ints |
+// ent_px [GIN_TP*K*4] bytes - 48 KB at K = 9, Gc = 32: three workgroups per CU
+template <int GC>
+__global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, const GinGeo q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ncell = q.WH * q.WW, nrec = GIN_TP * a.K, ntap = nrec * 4;
+    float *tgt = reinterpret_cast<float *>(smem);
+    RecG *recs = reinterpret_cast<RecG *>(tgt + GIN_TP * GC);
+    float *ent_cf = reinterpret_cast<float *>(recs + nrec);
+    OvfG *ovf = reinterpret_cast<OvfG *>(ent_cf + ntap);
+    int *cnt = reinterpret_cast<int *>(ovf + GIN_OVF_CAP), *start = cnt + ncell + 1, *cur = start + ncell + 1;
+    uint8_t *ent_px = reinterpret_cast<uint8_t *>(cur + ncell + 1);
+    __shared__ float red[4];
+    __shared__ int wsum[4];
+    __shared__ int novf;
+    const int tile = blockIdx.x, n = blockIdx.y, g = blockIdx.z;
+    const int th0 = (tile / q.tiles_w) * GIN_TH, tw0 = (tile % q.tiles_w) * GIN_TW;
+    const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
+    for (int i = threadIdx.x; i <= ncell; i += 256) { cnt[i] = 0; cur[i] = 0; }
+    if (threadIdx.x == 0) novf = 0;
+    // the tile's grad_output for this group, and its largest magnitude
+    constexpr int SLOTS = 256 / GC, NPX = GIN_TP / SLOTS;
+    const int c = threadIdx.x % GC, slot = threadIdx.x / GC;
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int pl = slot + i * SLOTS;
+        const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+        const float t = (ho < a.Ho && wo < a.Wo) ? a.grad_output[(((long)n * a.Ho + ho) * a.Wo + wo) * a.C + g * GC + c] : 0.f;
+        tgt[pl * GC + c] = t;
+        mx = fmaxf(mx, fabsf(t));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // 1. records (floor position + the four tap coefficients x mask) and the histogram of the taps over the window cells
+    for (int i = threadIdx.x; i < nrec; i += 256) {
+        const int pl = i / a.K, k = i % a.K;
+        const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+        RecG r;
+        r.h0 = r.w0 = 0;
+        r.cf[0] = r.cf[1] = r.cf[2] = r.cf[3] = 0.f;
+        if (ho < a.Ho && wo < a.Wo) {
+            const long pix = ((long)n * a.Ho + ho) * a.Wo + wo;
+            const long s = (pix * a.G + g) * a.K + k;
+            const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + s * 2);
+            const float m = a.mask[s];
+            const int ii = k / a.kh, jj = k % a.kh;
+            const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
+            const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
+            const float p0h = (float)(half_h - a.ph + ho * a.sh) - (float)half_h * a.offset_scale;
+            const float loc_w = p0w + ((float)(ii * a.dw) + ofs.x) * a.offset_scale;
+            const float loc_h = p0h + ((float)(jj * a.dh) + ofs.y) * a.offset_scale;
+            if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)a.H && loc_w < (float)a.W) {
+                const float fh = floorf(loc_h), fw = floorf(loc_w);
+                const int h0 = (int)fh, w0 = (int)fw;
+                const float lh = loc_h - fh, lw = loc_w - fw, hh = 1.f - lh, hw = 1.f - lw;
+                const bool h0ok = h0 >= 0, h1ok = h0 + 1 <= a.H - 1, w0ok = w0 >= 0, w1ok = w0 + 1 <= a.W - 1;
+                r.h0 = h0;
+                r.w0 = w0;
+                r.cf[0] = (h0ok && w0ok) ? hh * hw * m : 0.f;
+                r.cf[1] = (h0ok && w1ok) ? hh * lw * m : 0.f;
+                r.cf[2] = (h1ok && w0ok) ? lh * hw * m : 0.f;
+                r.cf[3] = (h1ok && w1ok) ? lh * lw * m : 0.f;
+            }
+        }
+        recs[i] = r;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            if (r.cf[tp] == 0.f) continue;
+            const int wh = r.h0 + (tp >> 1) - win_h0, ww = r.w0 + (tp & 1) - win_w0;
+            if ((unsigned)wh < (unsigned)q.WH && (unsigned)ww < (unsigned)q.WW) atomicAdd(&cnt[wh * q.WW + ww], 1);
+        }
+    }
+    __syncthreads();
+    // 2. exclusive scan of the histogram: every thread owns a run of bins, the run sums are scanned over the block
+    const int bpt = (ncell + 255) / 256;
+    int run = 0;
+    for (int b = 0; b < bpt; ++b) { const int i = threadIdx.x * bpt + b; if (i < ncell) run += cnt[i]; }
+    int inc = run;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if ((threadIdx.x & 63) >= o) inc += t; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = inc - run;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+    for (int b = 0; b < bpt; ++b) { const int i = threadIdx.x * bpt + b; if (i < ncell) { start[i] = base; base += cnt[i]; } }
+    __syncthreads();
+    // 3. file every tap under its cell (the order inside a cell's list is arbitrary: the sum below does not depend on it)
+    for (int i = threadIdx.x; i < nrec; i += 256) {
+        const RecG r = recs[i];
+        const int pl = i / a.K;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            if (r.cf[tp] == 0.f) continue;
+            const int h = r.h0 + (tp >> 1), w = r.w0 + (tp & 1);
+            const int wh = h - win_h0, ww = w - win_w0;
+            if ((unsigned)wh < (unsigned)q.WH && (unsigned)ww < (unsigned)q.WW) {
+                const int cell = wh * q.WW + ww;
+                const int at = start[cell] + atomicAdd(&cur[cell], 1);
+                ent_cf[at] = r.cf[tp];
+                ent_px[at] = (uint8_t)pl;
+            } else {
+                const int at = atomicAdd(&novf, 1);
+                if (at < GIN_OVF_CAP) {
+                    ovf[at] = OvfG{h * a.W + w, pl, r.cf[tp]};
+                } else {                                           // list full (offsets far beyond the slack everywhere): add it here
+                    float *gp = a.grad_input + (((long)n * a.H + h) * a.W + w) * a.C + g * GC;
+                    for (int cc = 0; cc < GC; ++cc) atomicAdd(gp + cc, tgt[pl * GC + cc] * r.cf[tp]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 4. one channel lane per (cell, channel): the cell's list summed in registers.  Addends are rounded onto the grid 2^(e-38) with
+    //    2^e > mx: |addend| < 2^38 steps, at most 4*K*64 addends per cell -> every partial sum below 2^53 steps, i.e. exact in double
+    int e2;
+    (void)frexpf(mx, &e2);
+    const double magic = ldexp(1.5, 52 + e2 - 38);               // (x + magic) - magic rounds x to a multiple of 2^(e2-38)
+    const bool finite = mx > 0.f && mx < __builtin_huge_valf();
+    float *dst = q.staging + (((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile) * (long)ncell * GC;
+    for (int cell = slot; cell < ncell; cell += SLOTS) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;             // exact sums: splitting the chain changes nothing but the latency
+        if (finite) {
+            int e = start[cell];
+            const int e1 = e + cnt[cell];
+            for (; e + 4 <= e1; e += 4) {
+                const float c0 = ent_cf[e], c1 = ent_cf[e + 1], c2 = ent_cf[e + 2], c3 = ent_cf[e + 3];
+                const float t0 = tgt[ent_px[e] * GC + c], t1 = tgt[ent_px[e + 1] * GC + c], t2 = tgt[ent_px[e + 2] * GC + c],
+                            t3 = tgt[ent_px[e + 3] * GC + c];
+                a0 += ((double)(t0 * c0) + magic) - magic;
+                a1 += ((double)(t1 * c1) + magic) - magic;
+                a2 += ((double)(t2 * c2) + magic) - magic;
+                a3 += ((double)(t3 * c3) + magic) - magic;
+            }
+            for (; e < e1; ++e) a0 += ((double)(tgt[ent_px[e] * GC + c] * ent_cf[e]) + magic) - magic;
+        }
+        dst[cell * GC + c] = (float)((a0 + a1) + (a2 + a3));
+    }
+    // 5. taps beyond the window: fp32 atomics into grad_input like the reference's own kernel (128 contiguous bytes per tap)
+    if (novf) {
+        float *gin = a.grad_input + (long)n * a.H * a.W * a.C + g * GC + c;
+        const int nlist = novf < GIN_OVF_CAP ? novf : GIN_OVF_CAP;
+        for (int i = slot; i < nlist; i += SLOTS) {
+            const OvfG o = ovf[i];
+            atomicAdd(gin + (long)o.hw * a.C, tgt[o.px * GC + c] * o.cf);
+        }
+        if (threadIdx.x == 0) atomicAdd(q.overflow, (unsigned)novf);
+    }
+}
+
+// grad_input[n,h,w,c] += sum over the windows covering (h,w), ascending tile order (4 channels per lane)
+__global__ __launch_bounds__(256) void dcnv3_bwd_combine_kernel(const DcnArgs a, const GinGeo q) {
+    const int C4 = a.C >> 2;
+    const long items = (long)a.N * a.H * a.W * C4;
+    const int step_h = GIN_TH * a.sh, step_w = GIN_TW * a.sw, ntile = q.tiles_h * q.tiles_w;
+    const long ncell = (long)q.WH * q.WW;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        long p = it / C4;
+        const int w = (int)(p % a.W);
+        p /= a.W;
+        const int h = (int)(p % a.H);
+        const long n = p / a.H;
+        const int g = c / a.Gc, cg = c % a.Gc;
+        // tiles t with t*step + lo <= x <= t*step + lo + extent - 1
+        const int xh = h - q.lo_h, xw = w - q.lo_w;
+        int th_lo = xh - (q.WH - 1) <= 0 ? 0 : (xh - (q.WH - 1) + step_h - 1) / step_h, th_hi = xh < 0 ? -1 : xh / step_h;
+        int tw_lo = xw - (q.WW - 1) <= 0 ? 0 : (xw - (q.WW - 1) + step_w - 1) / step_w, tw_hi = xw < 0 ? -1 : xw / step_w;
+        if (th_hi > q.tiles_h - 1) th_hi = q.tiles_h - 1;
+        if (tw_hi > q.tiles_w - 1) tw_hi = q.tiles_w - 1;
+        float *o = a.grad_input + it * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(o);
+        for (int th = th_lo; th <= th_hi; ++th)
+            for (int tw = tw_lo; tw <= tw_hi; ++tw) {
+                const long cell = (long)(xh - th * step_h) * q.WW + (xw - tw * step_w);
+                acc += *reinterpret_cast<const f32x4 *>(q.staging + ((n * a.G + g) * ntile + th * q.tiles_w + tw) * ncell * a.Gc + cell * a.Gc + cg);
+            }
+        *reinterpret_cast<f32x4 *>(o) = acc;
+    }
+}
+
+// geometry of the windowed form; false when it does not apply (group width, LDS budget)
+static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &staging_bytes) {
+    if (!(a.Gc == 8 || a.Gc == 16 || a.Gc == 32 || a.Gc == 64)) return false;
+    static const int slack = [] { const char *e = getenv("SOMI_DCN_SLACK"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
+    q.R = slack;
+    const int half_h = (a.dh * (a.kh - 1)) >> 1, half_w = (a.dw * (a.kw - 1)) >> 1;
+    const int lo_rh = (int)ceilf((float)half_h * a.offset_scale), hi_rh = (int)ceilf((float)((a.kh - 1) * a.dh - half_h) * a.offset_scale);
+    const int lo_rw = (int)ceilf((float)half_w * a.offset_scale), hi_rw = (int)ceilf((float)((a.kw - 1) * a.dw - half_w) * a.offset_scale);
+    q.lo_h = half_h - a.ph - lo_rh - q.R;
+    q.lo_w = half_w - a.pw - lo_rw - q.R;
+    q.WH = (GIN_TH - 1) * a.sh + lo_rh + hi_rh + 2 * q.R + 2;
+    q.WW = (GIN_TW - 1) * a.sw + lo_rw + hi_rw + 2 * q.R + 2;
+    q.tiles_h = (a.Ho + GIN_TH - 1) / GIN_TH;
+    q.tiles_w = (a.Wo + GIN_TW - 1) / GIN_TW;
+    lds = (size_t)GIN_TP * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(RecG) + 4 * sizeof(float) + 4) + GIN_OVF_CAP * sizeof(OvfG) +
+          3 * ((size_t)q.WH * q.WW + 1) * sizeof(int);
+    if (lds > 150 * 1024 || (long)q.tiles_h * q.tiles_w > 65535L * 32) return false;
+    staging_bytes = ((size_t)a.N * a.G * q.tiles_h * q.tiles_w * q.WH * q.WW * a.Gc * sizeof(float) + 255) / 256 * 256 + 256;   // + the overflow counter
+    return true;
 }
 
 static int fill_args(DcnArgs &a, int N, int H, int W, int G, int Gc, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
@@ -286,11 +607,22 @@ extern "C" int somi_dcnv3_forward_f32(const float *input, const float *offset, c
     return launch_status("somi_dcnv3_forward_f32");
 }
 
+extern "C" size_t somi_dcnv3_backward_workspace_bytes(int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w,
+                                                      int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale) {
+    DcnArgs a{};
+    if (fill_args(a, N, H, W, G, Gc, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, offset_scale, N > 0 ? N : 1,
+                  sizeof(Rec) + 3 * sizeof(float)))
+        return 0;
+    GinGeo q{};
+    size_t lds = 0, bytes = 0;
+    return gin_plan(a, q, lds, bytes) ? bytes : 0;
+}
+
 extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, const float *mask, const float *grad_output,
                                        float *grad_input, float *grad_offset, float *grad_mask, int N, int H, int W, int G,
                                        int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
-                                       int dilation_h, int dilation_w, float offset_scale, int im2col_step,
-                                       somi_stream_t stream) {
+                                       int dilation_h, int dilation_w, float offset_scale, int im2col_step, void *workspace,
+                                       size_t workspace_bytes, somi_stream_t stream) {
     SOMI_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, SOMI_EINVAL,
                  "dcnv3 backward: null tensor");
     DcnArgs a{};
@@ -301,12 +633,41 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
     a.grad_input = grad_input; a.grad_offset = grad_offset; a.grad_mask = grad_mask;
     SOMI_REQUIRE((reinterpret_cast<uintptr_t>(offset) & 7u) == 0 && (reinterpret_cast<uintptr_t>(grad_offset) & 7u) == 0,
                  SOMI_EINVAL, "dcnv3: offset / grad_offset must be 8 B aligned");
+    hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)a.TP * G * a.K * (sizeof(Rec) + 3 * sizeof(float));
-    // one channel per lane: a wave's fp32 atomic covers 256 contiguous bytes of grad_input (the shape that runs at the
+    GinGeo q{};
+    size_t glds = 0, gbytes = 0;
+    const bool windowed = workspace && gin_plan(a, q, glds, gbytes) && workspace_bytes >= gbytes && aligned16(workspace) && aligned16(grad_input) &&
+                          aligned16(grad_output);
+    if (windowed) {
+        // A: grad_offset / grad_mask (float4 gathers, no atomics)
+        hipLaunchKernelGGL(dcnv3_bwd_om_kernel, dim3(a.ntile), dim3(256), (size_t)a.TP * G * a.K * sizeof(Rec), s, a);
+        // B: grad_input windows, C: combine
+        q.staging = static_cast<float *>(workspace);
+        q.overflow = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + gbytes - 256);
+        (void)hipMemsetAsync(q.overflow, 0, 256, s);
+        const dim3 grid(q.tiles_h * q.tiles_w, N, G);
+#define SOMI_GIN_LAUNCH(GC)                                                                                                      \
+    do {                                                                                                                         \
+        if (glds > 64 * 1024)                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)glds);                                                                               \
+        hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<GC>), grid, dim3(256), glds, s, a, q);                                         \
+    } while (0)
+        if (Gc == 8) SOMI_GIN_LAUNCH(8);
+        else if (Gc == 16) SOMI_GIN_LAUNCH(16);
+        else if (Gc == 32) SOMI_GIN_LAUNCH(32);
+        else SOMI_GIN_LAUNCH(64);
+#undef SOMI_GIN_LAUNCH
+        long blocks = ((long)N * H * W * (a.C / 4) + 255) / 256;
+        hipLaunchKernelGGL(dcnv3_bwd_combine_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, s, a, q);
+        return launch_status("somi_dcnv3_backward_f32 (windowed)");
+    }
+    // direct form.  One channel per lane: a wave's fp32 atomic covers 256 contiguous bytes of grad_input (the shape that runs at the
     // chip-wide atomic rate, MI355X_MICROARCH.md "Global float atomics"); 4 channels per lane (16 B stride between lanes'
     // dwords) measured 4x slower.  The float4 form is kept for group widths where it avoids the LDS-atomic fallback.
     const bool vec = (Gc % 4 == 0) && aligned16(grad_output) && !((Gc & (Gc - 1)) == 0 && Gc <= 64);
-    if (vec) hipLaunchKernelGGL(dcnv3_bwd_kernel<4>, dim3(a.ntile), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(dcnv3_bwd_kernel<1>, dim3(a.ntile), dim3(256), lds, (hipStream_t)stream, a);
+    if (vec) hipLaunchKernelGGL((dcnv3_bwd_kernel<4, true>), dim3(a.ntile), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((dcnv3_bwd_kernel<1, true>), dim3(a.ntile), dim3(256), lds, s, a);
     return launch_status("somi_dcnv3_backward_f32");
 }

@@ -184,7 +184,8 @@ extern "C" int somi_dcnv3_forward_f64(const double *input, const double *offset,
 extern "C" int somi_dcnv3_backward_f16(const void *input, const void *offset, const void *mask, const void *grad_output, float *grad_input,
                                        float *grad_offset, float *grad_mask, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w,
                                        int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
-                                       int im2col_step, somi_stream_t stream) {
+                                       int im2col_step, void *workspace, size_t workspace_bytes, somi_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;                      // uniform signature with the _f32 entry
     SOMI_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, SOMI_EINVAL, "dcnv3 backward: null tensor");
     DcnGeo g{};
     if (int rc = fill_geo(g, DCN_GEO_ARGS)) return rc;
@@ -194,7 +195,8 @@ extern "C" int somi_dcnv3_backward_f16(const void *input, const void *offset, co
 extern "C" int somi_dcnv3_backward_f64(const double *input, const double *offset, const double *mask, const double *grad_output, double *grad_input,
                                        double *grad_offset, double *grad_mask, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w,
                                        int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
-                                       int im2col_step, somi_stream_t stream) {
+                                       int im2col_step, void *workspace, size_t workspace_bytes, somi_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;                      // uniform signature with the _f32 entry
     SOMI_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, SOMI_EINVAL, "dcnv3 backward: null tensor");
     DcnGeo g{};
     if (int rc = fill_geo(g, DCN_GEO_ARGS)) return rc;

@@ -68,11 +68,12 @@ SIGNATURES = {
     'somi_conv2d_wgrad_nhwc_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, I, I, P, P, P, Z, S]),
     'somi_conv2d_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'somi_dcnv3_forward_f32': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
-    'somi_dcnv3_backward_f32': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, S]),
+    'somi_dcnv3_backward_workspace_bytes': (Z, [I] * 13 + [F]),
+    'somi_dcnv3_backward_f32': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
     'somi_dcnv3_forward_f16': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
-    'somi_dcnv3_backward_f16': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, S]),
+    'somi_dcnv3_backward_f16': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
     'somi_dcnv3_forward_f64': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
-    'somi_dcnv3_backward_f64': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, S]),
+    'somi_dcnv3_backward_f64': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
     'somi_layernorm_act_nhwc_f32': (I, [P, P, P, F, I, P, C.c_long, I, S]),
     'somi_group_softmax_f32': (I, [P, P, C.c_long, I, S]),
     'somi_layernorm_act_bwd_workspace_floats': (Z, [C.c_long, I]),

@@ -13,6 +13,7 @@ from ._lib import ConvDesc, check
 
 STREAMK = os.environ.get('SOMI_CONV_STREAMK', '1') != '0'
 FUSED_BN_STATS = os.environ.get('SOMI_FUSED_BN_STATS', '1') != '0'   # batch statistics from the conv epilogue (training forward)
+DCN_DIRECT = os.environ.get('SOMI_DCN_DIRECT', '0') == '1'          # 1: DCNv3 backward scatters with fp32 atomics (the reference's form)
 PROFILE = None   # bench.py sets this to a list: every conv launch appends (kernel name, algorithmic FLOPs, ev0, ev1)
 
 ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4, 'softmax': 5}
@@ -123,6 +124,15 @@ def dcnv3_forward_raw(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group
     return out
 
 
+DCN_LAST_WORKSPACE = None
+
+
+def dcn_overflow_taps():
+    """Sampling taps of the last windowed DCNv3 backward that fell outside their tile's LDS window (host sync; diagnostics / tests)."""
+    ws = DCN_LAST_WORKSPACE
+    return None if ws is None else int(ws[-256:-252].view(torch.int32).item())
+
+
 def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels,
                        offset_scale, im2col_step):
     N, H, W, _ = input.shape
@@ -134,7 +144,7 @@ def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw,
         gm = torch.empty(mask.shape, device=input.device, dtype=gdt)
         fn = getattr(_lib.lib(), 'somi_dcnv3_backward_' + _DCN_SUFFIX[input.dtype])
         check(fn(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go), _ptr(gm), N, H, W, group, group_channels, kh, kw,
-                 sh, sw, ph, pw, dh, dw, float(offset_scale), int(im2col_step), _stream()), 'dcnv3_backward')
+                 sh, sw, ph, pw, dh, dw, float(offset_scale), int(im2col_step), None, 0, _stream()), 'dcnv3_backward')
         return gi.to(input.dtype), go.to(input.dtype), gm.to(input.dtype)
     gi = torch.zeros_like(input)
     go = torch.empty_like(offset)
@@ -143,9 +153,14 @@ def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw,
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().somi_dcnv3_backward_f32(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go),
-                                             _ptr(gm), N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw,
-                                             float(offset_scale), int(im2col_step), _stream()), 'dcnv3_backward')
+    L = _lib.lib()
+    nbytes = 0 if DCN_DIRECT else L.somi_dcnv3_backward_workspace_bytes(N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw, float(offset_scale))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device) if nbytes else None      # staging slab of the windowed form
+    global DCN_LAST_WORKSPACE
+    DCN_LAST_WORKSPACE = ws                                      # tests read the overflow-tap counter at its end (dcn_overflow_taps)
+    check(L.somi_dcnv3_backward_f32(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go),
+                                    _ptr(gm), N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw,
+                                    float(offset_scale), int(im2col_step), _ptr(ws), nbytes, _stream()), 'dcnv3_backward')
     if prof:                                                      # 4 (4C + 6GK) per output pixel
         e1.record()
         C_ = group * group_channels
