@@ -742,8 +742,11 @@ def test_uavdt_1280_nc3_training_step_gradients():
     # ... with one discontinuous exception: the first layer of the channel-attention MLPs sits behind a ReLU fed by pooled values; a
     # hidden unit whose pre-activation is within rounding of zero has its gate open in one arithmetic and shut in the other, which
     # moves its whole weight row (the fp32 CPU path shows the same flips against fp64, at 8 ... 28 % of the scale here)
-    gated = [b for b in bad if '.channel_attention.shared_MLP.0.' in b[0]]
-    assert len(gated) == len(bad) and len(bad) <= max(3, len(rel_mine) // 100), [b for b in bad if b not in gated][:8] or bad[:8]
+    # ... and the bias of the 7x7 spatial-attention conv: the plain sum of its logit gradients over every pixel of the batch (2 x 320 x 320
+    # at layer 2), terms of both signs that cancel to a few ulps of their size (test_whole_model_train_step_gradients carries an absolute
+    # floor for the same parameter): the fp32 CPU path is 6 ... 17 % of the scale away from fp64 on it here
+    gated = [b for b in bad if '.channel_attention.shared_MLP.0.' in b[0] or b[0].endswith('.spatial_attention.cv1.bias')]
+    assert len(gated) == len(bad) and len(bad) <= max(6, len(rel_mine) // 100), [b for b in bad if b not in gated][:8] or bad[:8]
     rm, ro = torch.tensor(rel_mine), torch.tensor(rel_o32)
     print(f'1280 nc=3: HIP median {float(rm.median()):.2e} q90 {float(rm.quantile(0.9)):.2e} max {float(rm.max()):.2e}; '
           f'fp32 CPU median {float(ro.median()):.2e} q90 {float(ro.quantile(0.9)):.2e} max {float(ro.max()):.2e}')
