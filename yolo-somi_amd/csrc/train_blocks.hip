@@ -449,14 +449,18 @@ __global__ __launch_bounds__(256) void detect_raw_bwd_kernel(const float *__rest
 // a fixed order, the gradients of the window outputs that point at it.
 __global__ __launch_bounds__(256) void sppf_pool_argmax_kernel(const float *__restrict__ buf, uint8_t *__restrict__ arg, int B, int H, int W, int C,
                                                                int cs, int x_coff) {
-    const long items = (long)B * H * W * C;
+    const int C4 = C >> 2;                                             // 4 channels per lane: one 16-byte load per tap, one 4-byte code store
+    const long items = (long)B * H * W * C4;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C);
-        const long pix = it / C;
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
         const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
         const long b = pix / ((long)W * H);
-        float m[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
-        int mi[3] = {84, 84, 84};                                        // the centre; every window contains it
+        const float ninf = -__builtin_huge_valf();
+        f32x4 m[3] = {{ninf, ninf, ninf, ninf}, {ninf, ninf, ninf, ninf}, {ninf, ninf, ninf, ninf}};
+        int mi[3][4];
+        for (int l = 0; l < 3; ++l)
+            for (int e = 0; e < 4; ++e) mi[l][e] = 84;                   // the centre; every window contains it
         for (int dh = -6; dh <= 6; ++dh) {
             const int hi = hv + dh;
             if ((unsigned)hi >= (unsigned)H) continue;
@@ -466,26 +470,32 @@ __global__ __launch_bounds__(256) void sppf_pool_argmax_kernel(const float *__re
                 if ((unsigned)wi >= (unsigned)W) continue;
                 const int aw = dw < 0 ? -dw : dw;
                 const int rad = ah > aw ? ah : aw;
-                const float v = buf[((b * H + hi) * W + wi) * cs + x_coff + c];
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + ((b * H + hi) * W + wi) * cs + x_coff + c);
                 const int code = (dh + 6) * 13 + (dw + 6);
-                if (v > m[2]) { m[2] = v; mi[2] = code; }
-                if (rad <= 4 && v > m[1]) { m[1] = v; mi[1] = code; }
-                if (rad <= 2 && v > m[0]) { m[0] = v; mi[0] = code; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (v[e] > m[2][e]) { m[2][e] = v[e]; mi[2][e] = code; }
+                    if (rad <= 4 && v[e] > m[1][e]) { m[1][e] = v[e]; mi[1][e] = code; }
+                    if (rad <= 2 && v[e] > m[0][e]) { m[0][e] = v[e]; mi[0][e] = code; }
+                }
             }
         }
-        for (int l = 0; l < 3; ++l) arg[((long)l * B * H * W + pix) * C + c] = (uint8_t)mi[l];
+        for (int l = 0; l < 3; ++l)
+            *reinterpret_cast<uint32_t *>(arg + ((long)l * B * H * W + pix) * C + c) =
+                (uint32_t)mi[l][0] | ((uint32_t)mi[l][1] << 8) | ((uint32_t)mi[l][2] << 16) | ((uint32_t)mi[l][3] << 24);
     }
 }
 
 __global__ __launch_bounds__(256) void sppf_pool_bwd_gather_kernel(const uint8_t *__restrict__ arg, float *__restrict__ dbuf, int B, int H, int W, int C,
                                                                    int cs, int x_coff) {
-    const long items = (long)B * H * W * C, plane = (long)B * H * W;
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4, plane = (long)B * H * W;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C);
-        const long pix = it / C;
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
         const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
         const long b = pix / ((long)W * H);
-        float acc = dbuf[pix * cs + x_coff + c];
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(dbuf + pix * cs + x_coff + c);
         for (int l = 0; l < 3; ++l) {
             const int R = 2 + 2 * l;
             for (int dh = -R; dh <= R; ++dh) {                           // o = p + (dh, dw) points back at p when its code is (-dh, -dw)
@@ -495,11 +505,18 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_gather_kernel(const uint8_t
                     const int wo = wv + dw;
                     if ((unsigned)wo >= (unsigned)W) continue;
                     const long o = (b * H + ho) * W + wo;
-                    if (arg[((long)l * plane + o) * C + c] == (uint8_t)((6 - dh) * 13 + (6 - dw))) acc += dbuf[o * cs + x_coff + (l + 1) * C + c];
+                    const uint32_t want = (uint32_t)((6 - dh) * 13 + (6 - dw));
+                    const uint32_t codes = *reinterpret_cast<const uint32_t *>(arg + ((long)l * plane + o) * C + c);
+                    const uint32_t x = codes ^ (want * 0x01010101u);    // a zero byte = that channel's maximum sits at p
+                    if (((x - 0x01010101u) & ~x & 0x80808080u) == 0) continue;
+                    const f32x4 d = *reinterpret_cast<const f32x4 *>(dbuf + o * cs + x_coff + (l + 1) * C + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (((x >> (8 * e)) & 0xFFu) == 0) acc[e] += d[e];
                 }
             }
         }
-        dbuf[pix * cs + x_coff + c] = acc;
+        *reinterpret_cast<f32x4 *>(dbuf + pix * cs + x_coff + c) = acc;
     }
 }
 
@@ -710,10 +727,12 @@ extern "C" int somi_detect_raw_bwd_f32(const float *draw, float *dbox, int box_c
 extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, void *workspace, int B, int H, int W, int C, int cs, int x_coff,
                                            somi_stream_t stream) {
     SOMI_REQUIRE(buf && dbuf && workspace && B > 0 && H > 0 && W > 0 && C > 0 && x_coff + 4 * C <= cs, SOMI_EINVAL, "sppf bwd: bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && cs % 4 == 0 && x_coff % 4 == 0 && aligned16(buf) && aligned16(dbuf) && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0,
+                 SOMI_EINVAL, "sppf bwd: channels / strides must be multiples of 4, tensors 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     uint8_t *arg = static_cast<uint8_t *>(workspace);                    // 3*B*H*W*C bytes
-    hipLaunchKernelGGL(sppf_pool_argmax_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, s, buf, arg, B, H, W, C, cs, x_coff);
-    hipLaunchKernelGGL(sppf_pool_bwd_gather_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, s, arg, dbuf, B, H, W, C, cs, x_coff);
+    hipLaunchKernelGGL(sppf_pool_argmax_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, buf, arg, B, H, W, C, cs, x_coff);
+    hipLaunchKernelGGL(sppf_pool_bwd_gather_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, arg, dbuf, B, H, W, C, cs, x_coff);
     return launch_status("somi_sppf_pool_bwd_nhwc_f32");
 }
 
