@@ -73,86 +73,94 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][BM / WAVES_M / 32], float *lds, const ConvArgs &a,
                                               const RowMap &rm, int m0, int n0) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
-    constexpr int SLD = WN + 4;
+    // the whole D tile staged at once when it fits the operand buffers, else one 32-column slab of every wave tile per pass
+    constexpr bool SPLIT = WAVES_M * WAVES_N * WM * (WN + 4) > 2 * (BM + BN) * LDS_LD;
+    constexpr int SW = SPLIT ? 32 : WN, NPASS = WN / SW, SLD = SW + 4;
     static_assert(WAVES_M * WAVES_N * WM * SLD <= 2 * (BM + BN) * LDS_LD, "epilogue staging does not fit the operand buffers");
     const somi_conv_desc &d = a.d;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     float *stage = lds + wave * (WM * SLD);
     const int h4 = (lane >> 5) * 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {acc[jn][i][4 * g], acc[jn][i][4 * g + 1], acc[jn][i][4 * g + 2], acc[jn][i][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(&stage[(i * 32 + (lane & 31)) * SLD + jn * 32 + 8 * g + h4]) = v;
-            }
-    __syncthreads();
     const float *bias = d.bias ? d.bias + (size_t)rm.bz * d.Cout : nullptr;
     const size_t row_base = (size_t)rm.bz * a.M;
-    constexpr int NQ = WN / 4;                                    // float4 per staged row
-    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
-    // optional BatchNorm statistics: a lane always sweeps the same column quad (64 % NQ == 0), so it keeps that quad's sums
+    constexpr int NQ = SW / 4;                                    // float4 per staged row
+    const int mw = m0 + wm * WM;
     const bool stats = d.stat_sum != nullptr;
-    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, piv = st1;
-    if (stats && d.stat_pivot && nw + (lane % NQ) * 4 < d.Cout) piv = *reinterpret_cast<const f32x4 *>(d.stat_pivot + nw + (lane % NQ) * 4);
-    for (int idx = lane; idx < WM * NQ; idx += 64) {
-        const int ml = idx / NQ, n = nw + (idx % NQ) * 4, m = mw + ml;
-        if (m >= rm.Mrows || n >= d.Cout) continue;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(&stage[ml * SLD + (idx % NQ) * 4]);
-        size_t row = row_base + m;
-        if (rm.strided) {
-            const int rem = m % rm.HoWo;
-            row = ((size_t)(m / rm.HoWo + rm.bz) * d.Ho + rm.h0 + (rem / rm.Wc) * rm.cstep) * d.Wo + rm.w0 + (rem % rm.Wc) * rm.cstep;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass) __syncthreads();                                // the previous slab has been swept
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int js = 0; js < SW / 32; ++js)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int jn = pass * (SW / 32) + js;
+                    const f32x4 v = {acc[jn][i][4 * g], acc[jn][i][4 * g + 1], acc[jn][i][4 * g + 2], acc[jn][i][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(&stage[(i * 32 + (lane & 31)) * SLD + js * 32 + 8 * g + h4]) = v;
+                }
+        __syncthreads();
+        const int nw = n0 + wn * WN + pass * SW;
+        // optional BatchNorm statistics: a lane always sweeps the same column quad (64 % NQ == 0), so it keeps that quad's sums
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, piv = st1;
+        if (stats && d.stat_pivot && nw + (lane % NQ) * 4 < d.Cout) piv = *reinterpret_cast<const f32x4 *>(d.stat_pivot + nw + (lane % NQ) * 4);
+        for (int idx = lane; idx < WM * NQ; idx += 64) {
+            const int ml = idx / NQ, n = nw + (idx % NQ) * 4, m = mw + ml;
+            if (m >= rm.Mrows || n >= d.Cout) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(&stage[ml * SLD + (idx % NQ) * 4]);
+            size_t row = row_base + m;
+            if (rm.strided) {
+                const int rem = m % rm.HoWo;
+                row = ((size_t)(m / rm.HoWo + rm.bz) * d.Ho + rm.h0 + (rem / rm.Wc) * rm.cstep) * d.Wo + rm.w0 + (rem % rm.Wc) * rm.cstep;
+            }
+            float *yrow = d.y + row * d.y_cs + d.y_coff;
+            const float *rrow = d.residual ? d.residual + row * d.res_cs + d.res_coff : nullptr;
+            const float *rrow2 = d.residual2 ? d.residual2 + row * d.res2_cs + d.res2_coff : nullptr;
+            if (n + 3 < d.Cout) {
+                if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);
+                if (d.act == SOMI_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                } else if (d.act != SOMI_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act_rt(v[e], d.act);
+                }
+                if (d.post_scale)
+                    v = v * *reinterpret_cast<const f32x4 *>(d.post_scale + n) + *reinterpret_cast<const f32x4 *>(d.post_shift + n);
+                if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + n);
+                if (rrow2) v += *reinterpret_cast<const f32x4 *>(rrow2 + n);
+                *reinterpret_cast<f32x4 *>(yrow + n) = v;
+                if (stats) {
+                    const f32x4 t = v - piv;
+                    st1 += t;
+                    st2 += t * t;
+                }
+            } else {
+                for (int e = 0; e < 4 && n + e < d.Cout; ++e) {          // ragged Cout tail
+                    float t = v[e] + (bias ? bias[n + e] : 0.f);
+                    t = apply_act_rt(t, d.act);
+                    if (d.post_scale) t = t * d.post_scale[n + e] + d.post_shift[n + e];
+                    if (rrow) t += rrow[n + e];
+                    if (rrow2) t += rrow2[n + e];
+                    yrow[n + e] = t;
+                }
+            }
         }
-        float *yrow = d.y + row * d.y_cs + d.y_coff;
-        const float *rrow = d.residual ? d.residual + row * d.res_cs + d.res_coff : nullptr;
-        const float *rrow2 = d.residual2 ? d.residual2 + row * d.res2_cs + d.res2_coff : nullptr;
-        if (n + 3 < d.Cout) {
-            if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);
-            if (d.act == SOMI_ACT_SILU) {
+        if (stats) {                                              // fold the 64 / NQ lanes that share a column quad, then one row per (tile, wave row)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
-            } else if (d.act != SOMI_ACT_NONE) {
+            for (int off = NQ; off < 64; off <<= 1)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act_rt(v[e], d.act);
+                for (int e = 0; e < 4; ++e) {
+                    st1[e] += __shfl_xor(st1[e], off);
+                    st2[e] += __shfl_xor(st2[e], off);
+                }
+            const int n = nw + lane * 4;
+            if (lane < NQ && n < d.Cout) {
+                const size_t prow = (size_t)(m0 / BM) * WAVES_M + wm;
+                *reinterpret_cast<f32x4 *>(d.stat_sum + prow * d.Cout + n) = st1;
+                *reinterpret_cast<f32x4 *>(d.stat_sumsq + prow * d.Cout + n) = st2;
             }
-            if (d.post_scale)
-                v = v * *reinterpret_cast<const f32x4 *>(d.post_scale + n) + *reinterpret_cast<const f32x4 *>(d.post_shift + n);
-            if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + n);
-            if (rrow2) v += *reinterpret_cast<const f32x4 *>(rrow2 + n);
-            *reinterpret_cast<f32x4 *>(yrow + n) = v;
-            if (stats) {
-                const f32x4 t = v - piv;
-                st1 += t;
-                st2 += t * t;
-            }
-        } else {
-            for (int e = 0; e < 4 && n + e < d.Cout; ++e) {          // ragged Cout tail
-                float t = v[e] + (bias ? bias[n + e] : 0.f);
-                t = apply_act_rt(t, d.act);
-                if (d.post_scale) t = t * d.post_scale[n + e] + d.post_shift[n + e];
-                if (rrow) t += rrow[n + e];
-                if (rrow2) t += rrow2[n + e];
-                yrow[n + e] = t;
-            }
-        }
-    }
-    if (stats) {                                                  // fold the 64 / NQ lanes that share a column quad, then one row per (tile, wave row)
-#pragma unroll
-        for (int off = NQ; off < 64; off <<= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                st1[e] += __shfl_xor(st1[e], off);
-                st2[e] += __shfl_xor(st2[e], off);
-            }
-        const int n = nw + lane * 4;
-        if (lane < NQ && n < d.Cout) {
-            const size_t prow = (size_t)(m0 / BM) * WAVES_M + wm;
-            *reinterpret_cast<f32x4 *>(d.stat_sum + prow * d.Cout + n) = st1;
-            *reinterpret_cast<f32x4 *>(d.stat_sumsq + prow * d.Cout + n) = st2;
         }
     }
 }
@@ -169,7 +177,7 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned of
 // FAST: Cin % 32 == 0 (every K-tile lies inside one filter tap), kh*kw <= 32: the tap walk is wave-uniform (SALU), each
 // row's padding test is one bit of a mask built once, and a fetch costs 4 VALU per 16 B.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N / 2) void conv_igemm_f32_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_M * WAVES_N / 2)) void conv_igemm_f32_kernel(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
     constexpr int NT = WAVES_M * WAVES_N * 64, RPP = NT / 8;   // threads; rows fetched per pass (8 threads x 16 B cover a row's K-tile)
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N / 2) void
 // Stream-K fix-up: workgroup j looks at the boundary between the runs of workgroups j and j+1; if it cuts a tile and is the
 // first cut inside that tile, it adds the tile's pieces in ascending workgroup order and runs the epilogue.
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N / 2) void conv_streamk_fixup_kernel(const ConvArgs a, int G) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_M * WAVES_N / 2)) void conv_streamk_fixup_kernel(const ConvArgs a, int G) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32, NT = WAVES_M * WAVES_N * 64;
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
     const int nkt = a.K / BK, ntile = a.tiles_m * a.tiles_n;
@@ -488,7 +496,8 @@ struct TilePlan {
     int variant;   // 0: 128x128, 1: 64x128, 2: 128x64, 3: 128x32, 4: 128x128 with 8 waves (2 per SIMD and workgroup)
     bool sk;       // stream-K schedule
 };
-static const int kTileBM[6] = {128, 64, 128, 128, 128, 128}, kTileBN[6] = {128, 128, 64, 32, 128, 64};
+static const int kTileBM[7] = {128, 64, 128, 128, 128, 128, 256}, kTileBN[7] = {128, 128, 64, 32, 128, 64, 128};
+static inline int sk_slots(int variant) { return variant == 6 ? SK_GRID / 2 : SK_GRID; }   // resident workgroups chip-wide
 
 static bool fast_path(const somi_conv_desc &d) {
     return d.Cin % BK == 0 && d.kh * d.kw <= 32 && (size_t)d.kh * d.kw * d.Cin * 4 < (1u << 27);
@@ -511,13 +520,18 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
     static const int eight = getenv("SOMI_CONV_8WAVE") ? atoi(getenv("SOMI_CONV_8WAVE")) : 2;
     if (eight && p.variant == 0) p.variant = 4;
     if (eight > 1 && p.variant == 2) p.variant = 5;
+    // 256 x 128 tile, 8 waves of 64 x 64: a third fewer LDS operand bytes per MFMA than the 64 x 32 wave tile (the 128 x 128 form keeps
+    // the LDS port ~98 % busy at full MFMA rate); one workgroup per CU, so only for problems with many row tiles
+    static const int big = getenv("SOMI_CONV_BIG") ? atoi(getenv("SOMI_CONV_BIG")) : 1;
+    if (big && p.variant == 4 && fast_path(d) && !d.per_sample_w && !d.a_chan_scale && !d.a_pix_scale && M >= 256 * 256) p.variant = 6;
     if (sk_ok) {
         const int bm = kTileBM[p.variant], bn = kTileBN[p.variant];
         const long ntile = (long)cdiv(M, bm) * cdiv(d.Cout, bn), nkt = (long)d.kh * d.kw * d.Cin / BK;
-        const long rounds = (ntile + SK_GRID - 1) / SK_GRID;
+        const int slots = sk_slots(p.variant);
+        const long rounds = (ntile + slots - 1) / slots;
         static const int sk_pct = getenv("SOMI_SK_PCT") ? atoi(getenv("SOMI_SK_PCT")) : 90;   // stream-K below this slot efficiency (%)
-        p.sk = ntile * 100 < rounds * SK_GRID * sk_pct && ntile * nkt >= 32 &&     // (the grid shrinks to >= 8 K-tiles per workgroup)
-               d.workspace_bytes >= (size_t)SK_GRID * 2 * bm * bn * sizeof(float);
+        p.sk = ntile * 100 < rounds * slots * sk_pct && ntile * nkt >= 32 &&       // (the grid shrinks to >= 8 K-tiles per workgroup)
+               d.workspace_bytes >= (size_t)slots * 2 * bm * bn * sizeof(float);
     }
     return p;
 }
@@ -537,7 +551,7 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
     // stream-K grid: all 512 slots, unless that would leave a workgroup fewer than min_kt K-tiles (prologue, partial store and
     // fix-up then cost more than the MFMA work of the piece)
     static const int min_kt = getenv("SOMI_SK_MIN_KT") ? atoi(getenv("SOMI_SK_MIN_KT")) : 8;
-    int sk_grid = SK_GRID;
+    int sk_grid = BM + BN > 320 ? SK_GRID / 2 : SK_GRID;
     if (sk) {
         const long U = (long)args.tiles_m * args.tiles_n * (a.K / BK);
         if (U / min_kt < sk_grid) sk_grid = (int)(U / min_kt);
@@ -640,6 +654,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
         case 2: return launch<128, 64, 2, 2>(a, tp.sk, s);
         case 4: return launch<128, 128, 2, 4>(a, tp.sk, s);
         case 5: return launch<128, 64, 4, 2>(a, tp.sk, s);
+        case 6: return launch<256, 128, 4, 2>(a, tp.sk, s);
         default: return launch<128, 32, 4, 1>(a, tp.sk, s);
     }
 }
@@ -675,7 +690,7 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
     const int M = dp->per_sample_w ? dp->Ho * dp->Wo : dp->B * dp->Ho * dp->Wo;
     const int mod = (dp->a_chan_scale || dp->a_pix_scale) ? 1 : 0;
     const int fast = (dp->Cin % somi::BK == 0 && dp->kh * dp->kw <= 32) ? 1 : 0;
-    static const char *tiles[6] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1", "128,128,2,4", "128,64,4,2"};
+    static const char *tiles[7] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1", "128,128,2,4", "128,64,4,2", "256,128,4,2"};
     static thread_local char name[96];
     snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::plan_tiles(*dp, M, 0).variant], mod ? "true" : "false",
              fast ? "true" : "false");
@@ -684,7 +699,7 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
 
 extern "C" int somi_conv2d_stat_rows(const somi_conv_desc *dp) {
     if (!dp || dp->Cout <= 0 || dp->Ho <= 0 || dp->Wo <= 0 || dp->B <= 0 || dp->per_sample_w) return 0;
-    static const int waves_m[6] = {2, 1, 2, 4, 2, 4};
+    static const int waves_m[7] = {2, 1, 2, 4, 2, 4, 4};
     const int M = dp->B * dp->Ho * dp->Wo;
     const int v = somi::plan_tiles(*dp, M, 0).variant;
     return somi::cdiv(M, somi::kTileBM[v]) * waves_m[v];
