@@ -72,7 +72,7 @@ struct RowMap {
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][BM / WAVES_M / 32], float *lds, const ConvArgs &a,
                                               const RowMap &rm, int m0, int n0) {
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32;
     // the whole D tile staged at once when it fits the operand buffers, else one 32-column slab of every wave tile per pass
     constexpr bool SPLIT = WAVES_M * WAVES_N * WM * (WN + 4) > 2 * (BM + BN) * LDS_LD;
     constexpr int SW = SPLIT ? 32 : WN, NPASS = WN / SW, SLD = SW + 4;
@@ -520,9 +520,11 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
     static const int eight = getenv("SOMI_CONV_8WAVE") ? atoi(getenv("SOMI_CONV_8WAVE")) : 2;
     if (eight && p.variant == 0) p.variant = 4;
     if (eight > 1 && p.variant == 2) p.variant = 5;
-    // 256 x 128 tile, 8 waves of 64 x 64: a third fewer LDS operand bytes per MFMA than the 64 x 32 wave tile (the 128 x 128 form keeps
-    // the LDS port ~98 % busy at full MFMA rate); one workgroup per CU, so only for problems with many row tiles
-    static const int big = getenv("SOMI_CONV_BIG") ? atoi(getenv("SOMI_CONV_BIG")) : 1;
+    // 256 x 128 tile, 8 waves of 64 x 64: a third fewer LDS operand bytes per MFMA than the 64 x 32 wave tile (at full MFMA rate the
+    // 128 x 128 form would keep the LDS port ~98 % busy).  Measured (round 2): SLOWER - 109.7 vs 118.8 TFLOP/s on 128->128 3x3 at
+    // 160x160, 109 vs 114 at 80x80: its 110 KB of LDS leave one workgroup per CU, i.e. two waves per SIMD instead of four, and the
+    // lost latency hiding outweighs the LDS saving.  Kept behind SOMI_CONV_BIG=1 for experiments.
+    static const int big = getenv("SOMI_CONV_BIG") ? atoi(getenv("SOMI_CONV_BIG")) : 0;
     if (big && p.variant == 4 && fast_path(d) && !d.per_sample_w && !d.a_chan_scale && !d.a_pix_scale && M >= 256 * 256) p.variant = 6;
     if (sk_ok) {
         const int bm = kTileBM[p.variant], bn = kTileBN[p.variant];
