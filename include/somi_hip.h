@@ -390,6 +390,10 @@ int somi_odconv_synth_bwd_f32(const float *dWb, const float *attn, const float *
  * axpby: y = a*y + b*x (EMA of the BN running statistics). */
 int somi_adam_ema_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema, long n, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int step, float ema_decay, somi_stream_t stream);
+/* The other optimizer branch of train.py:136-138: torch.optim.SGD(momentum, nesterov=True) + the same EMA update in one pass
+ * (g' = g + weight_decay*p; buf = step == 1 ? g' : momentum*buf + g'; p -= lr*(g' + momentum*buf)).  momentum_buf plays exp_avg's role. */
+int somi_sgd_ema_step_f32(float *param, const float *grad, float *momentum_buf, float *ema, long n, float lr, float momentum,
+                          float weight_decay, int step, float ema_decay, somi_stream_t stream);
 int somi_axpby_f32(float *y, const float *x, long n, float a, float b, somi_stream_t stream);
 /* Forward-packed conv weights [Cout][taps][Cin] -> the packing somi_conv2d_dgrad_nhwc_f32 reads, [Cin][taps][Cout].  Run once
  * per optimizer step on the master weights (which the training path keeps in the forward packing). */

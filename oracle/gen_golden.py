@@ -469,6 +469,13 @@ def gen_nms():
         out = RG.non_max_suppression(z.clone(), **kw)
         for b, o in enumerate(out):
             rec[f'{tag}_{b}'] = o
+    # a-priori labels (autolabelling, utils/general.py:651-658; val.py:161-164 passes `lb` when save_hybrid): [cls, x, y, w, h] in pixels
+    lb = [torch.tensor([[3., 40., 40., 20., 24.], [0., 12., 70., 10., 10.], [7., z[0, 10, 0], z[0, 10, 1], z[0, 10, 2], z[0, 10, 3]]]),
+          torch.zeros(0, 5)]
+    out = RG.non_max_suppression(z.clone(), conf_thres=0.3, iou_thres=0.5, labels=lb, multi_label=True)
+    rec['labels_in0'] = lb[0]
+    for b, o in enumerate(out):
+        rec[f'withlabels_{b}'] = o
     save('nms', **rec)
     b1 = z[0, :50, :4].clone(); b1[:, 2:] += b1[:, :2]
     b2 = z[1, :40, :4].clone(); b2[:, 2:] += b2[:, :2]

@@ -76,6 +76,19 @@ def test_nms_80_class_head(kw):
     assert sum(int(w.shape[0]) for w in want) > 0
 
 
+def test_nms_with_a_priori_labels(golden):
+    """utils/general.py:651-658 (`labels=`, the save_hybrid path of val.py:161-164): label rows join the candidates behind the image's
+    own predictions; against the reference's own output."""
+    from somi_amd.nms import non_max_suppression
+    g = golden('nms')
+    lb = [T(g['labels_in0']).cuda(), torch.zeros(0, 5, device='cuda')]
+    out = non_max_suppression(T(g['pred']).cuda(), conf_thres=0.3, iou_thres=0.5, labels=lb, multi_label=True)
+    for b, o in enumerate(out):
+        want = T(g[f'withlabels_{b}'])
+        assert o.shape == want.shape and torch.equal(o.cpu(), want), f'image {b}'
+    assert any(float(o[:, 4].max()) == 1.0 for o in out if len(o))          # a label row (confidence 1) survived
+
+
 def test_nms_argument_errors():
     from somi_amd.nms import non_max_suppression
     p = torch.zeros(1, 10, 15, device='cuda')

@@ -328,6 +328,47 @@ def test_odconv_train_forward_backward(B):
     _run_block_train(mine, ref, x, 41 + B, f'ODConv B={B}', 16)
 
 
+def test_fused_sgd_nesterov_ema_matches_torch():
+    """The reference's other optimizer branch (train.py:138: SGD(momentum, nesterov=True), same three parameter groups) fused with the
+    EMA update: four steps with a changing lr and momentum (the warm-up of train.py:250-256 ramps both) vs torch.optim.SGD."""
+    import copy
+    from somi_amd.optim import FusedAdamEMA, reference_param_groups
+    g = torch.Generator().manual_seed(6)
+    net = nn.Sequential(nn.Conv2d(4, 8, 3, bias=False), nn.BatchNorm2d(8), nn.Conv2d(8, 6, 1), nn.Linear(6, 5))
+    ref = copy.deepcopy(net)
+    ema_ref = copy.deepcopy(net)
+    g0, g1, g2 = reference_param_groups(ref)
+    opt = torch.optim.SGD(g0, lr=0.0032, momentum=0.843, nesterov=True)
+    opt.add_param_group({'params': g1, 'weight_decay': 0.00036})
+    opt.add_param_group({'params': g2})
+    net = net.cuda()
+    mine = FusedAdamEMA(net, lr=0.0032, betas=(0.843, 0.999), weight_decay=0.00036, sgd=True)
+    assert all(pg['momentum'] == 0.843 and pg['nesterov'] for pg in mine.param_groups)
+    for step in range(1, 5):
+        for pg, qg in zip(opt.param_groups, mine.param_groups):
+            pg['lr'] = qg['lr'] = 0.0032 * step
+            pg['momentum'] = qg['momentum'] = 0.5 + 0.08 * step
+        grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
+        for p, q, gr in zip(ref.parameters(), net.parameters(), grads):
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        opt.step()
+        mine.step()
+        d = 0.9999 * (1 - math.exp(-step / 2000))
+        with torch.no_grad():
+            msd = ref.state_dict()
+            for k, v in ema_ref.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v *= d
+                    v += (1 - d) * msd[k].detach()
+    for (n, p), (_, q) in zip(ref.named_parameters(), net.named_parameters()):
+        rel_close(q, p, rel=1e-5, what=f'param {n}')
+    esd = mine.ema_state_dict()
+    for k, v in ema_ref.state_dict().items():
+        if v.dtype.is_floating_point:
+            rel_close(esd[k], v, rel=1e-5, what=f'ema {k}')
+
+
 def test_fused_adam_ema_matches_torch():
     """Three optimizer steps of the fused Adam+EMA kernel vs torch.optim.Adam with the reference's parameter groups and
     the reference's ModelEMA rule (utils/torch_utils.py:331-345)."""

@@ -34,6 +34,21 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float *__restrict__ p, co
     }
 }
 
+// torch.optim.SGD(momentum, nesterov=True, dampening 0) + the EMA update, one pass: g' = g + wd p; buf = first ? g' : mom buf + g';
+// p -= lr (g' + mom buf)   (train.py:138: the branch the reference keeps behind `opt.adam = False`)
+__global__ __launch_bounds__(256) void sgd_ema_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf, float *__restrict__ ema,
+                                                      long n, float lr, float mom, float wd, int first, float ema_d) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float pv = p[i];
+        const float gv = g[i] + wd * pv;
+        const float bv = first ? gv : mom * buf[i] + gv;
+        pv -= lr * (gv + mom * bv);
+        p[i] = pv;
+        buf[i] = bv;
+        if (ema) ema[i] = ema_d * ema[i] + (1.f - ema_d) * pv;
+    }
+}
+
 // y = a*y + b*x  (EMA of the non-parameter float state: BN running statistics)
 __global__ __launch_bounds__(256) void axpby_kernel(float *__restrict__ y, const float *__restrict__ x, long n, float a, float b) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a * y[i] + b * x[i];
@@ -73,6 +88,14 @@ extern "C" int somi_adam_ema_step_f32(float *param, const float *grad, float *ex
     hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, ema, n, lr, beta1,
                        beta2, eps, weight_decay, bc1, sqrtf(bc2), ema_decay);
     return launch_status("somi_adam_ema_step_f32");
+}
+
+extern "C" int somi_sgd_ema_step_f32(float *param, const float *grad, float *momentum_buf, float *ema, long n, float lr, float momentum,
+                                     float weight_decay, int step, float ema_decay, somi_stream_t stream) {
+    SOMI_REQUIRE(param && grad && momentum_buf && n > 0 && step >= 1, SOMI_EINVAL, "sgd: bad arguments");
+    hipLaunchKernelGGL(sgd_ema_kernel, dim3(grid_for(n * 4)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, ema, n, lr, momentum,
+                       weight_decay, step == 1 ? 1 : 0, ema_decay);
+    return launch_status("somi_sgd_ema_step_f32");
 }
 
 extern "C" int somi_axpby_f32(float *y, const float *x, long n, float a, float b, somi_stream_t stream) {

@@ -126,6 +126,7 @@ SIGNATURES = {
     'somi_odconv_synth_bwd_workspace_floats': (Z, [I, I, I, I, I]),
     'somi_odconv_synth_bwd_f32': (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, S]),
     'somi_adam_ema_step_f32': (I, [P, P, P, P, P, C.c_long, F, F, F, F, F, I, F, S]),
+    'somi_sgd_ema_step_f32': (I, [P, P, P, P, C.c_long, F, F, F, I, F, S]),
     'somi_pack_dgrad_weights_f32': (I, [P, P, I, I, I, S]),
     'somi_axpby_f32': (I, [P, P, C.c_long, F, F, S]),
     'somi_nms_workspace_bytes': (Z, [I, I, I, I]),

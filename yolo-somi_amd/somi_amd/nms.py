@@ -2,7 +2,7 @@
 
 Returns a list of (n_i, 6) [x1, y1, x2, y2, conf, cls] tensors on the prediction's device.  One device->host copy of
 the per-image counts happens at the end (the reference syncs per image inside its Python loop, and val.py:189 copies
-results to the CPU anyway).  `labels` (a-priori boxes for autolabelling) are not on the hot path.
+results to the CPU anyway).  `labels` (a-priori boxes for autolabelling, :651-658) are appended as rows of the prediction tensor.
 """
 import torch
 
@@ -15,14 +15,26 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
                         labels=(), max_det=300):
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
-    if labels:
-        raise NotImplementedError('a-priori labels (utils/general.py:651-658) are outside the hot path')
     if not prediction.is_cuda:
         raise RuntimeError('somi_amd NMS runs on the MI355X only (no CPU fallback)')
     if prediction.dtype != torch.float32 or not prediction.is_contiguous():
         raise RuntimeError('prediction tensor has to be contiguous float32')
     B, n, no = prediction.shape
     nc = no - 5
+    if labels and any(len(l) for l in labels):
+        # a-priori labels (utils/general.py:651-658): each image's label rows [cls, x, y, w, h] become predictions with objectness 1 and a
+        # one-hot class, appended BEHIND the image's own rows (the candidate order the reference builds); padding rows have
+        # objectness 0 and drop out at the first threshold
+        kmax = max(len(l) for l in labels)
+        aug = torch.zeros(B, n + kmax, no, dtype=torch.float32, device=prediction.device)
+        aug[:, :n] = prediction
+        for xi, l in enumerate(labels):
+            if len(l):
+                l = torch.as_tensor(l, dtype=torch.float32, device=prediction.device)
+                aug[xi, n:n + len(l), :4] = l[:, 1:5]
+                aug[xi, n:n + len(l), 4] = 1.0
+                aug[xi, torch.arange(n, n + len(l), device=prediction.device), l[:, 0].long() + 5] = 1.0
+        prediction, n = aug, n + kmax
     ml = bool(multi_label) and nc > 1
     mask = None                                                  # NULL: keep every class
     if classes is not None:

@@ -69,7 +69,10 @@ class FusedAdamEMA:
     """Adam with the reference's group layout and an optional fused EMA shadow.  `param_groups[i]['lr']` etc. can be edited
     between steps exactly like torch.optim (the warm-up of train.py:250-256 does that)."""
 
-    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.9999, ema=True):
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.9999, ema=True, sgd=False):
+        """sgd=True: the reference's other branch (train.py:138) - SGD with Nesterov momentum betas[0]; the groups then carry a
+        'momentum' key (the warm-up of train.py:255-256 ramps it) and `lr` should be hyp['lr0']."""
+        self.sgd = bool(sgd)
         dev = next(model.parameters()).device
         if dev.type != 'cuda':
             raise RuntimeError('FusedAdamEMA runs on the MI355X only (no CPU fallback)')
@@ -100,7 +103,10 @@ class FusedAdamEMA:
             st = dict(p=fp, g=fg, m=torch.zeros_like(fp.data), v=torch.zeros_like(fp.data),
                       ema=fp.data.clone() if ema else None)
             self._flat.append(st)
-            self.param_groups.append(dict(params=plist, lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=wd))
+            grp = dict(params=plist, lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=wd)
+            if self.sgd:
+                grp.update(momentum=betas[0], nesterov=True)
+            self.param_groups.append(grp)
         # float buffers (BN running statistics): re-homed into one flat buffer as well, so their EMA is one launch
         self._buf_owner = []
         for mod in model.modules():
@@ -157,6 +163,11 @@ class FusedAdamEMA:
         for grp, st in zip(self.param_groups, self._flat):
             if st['p'].n == 0:
                 continue
+            if self.sgd:
+                check(L.somi_sgd_ema_step_f32(_ptr(st['p'].data), _ptr(st['g'].data), _ptr(st['m']), _ptr(st['ema']), st['p'].n_pad, float(grp['lr']),
+                                              float(grp['momentum']), float(grp['weight_decay']), self.steps, float(d if d is not None else 0.0),
+                                              _stream()), 'sgd_ema_step')
+                continue
             check(L.somi_adam_ema_step_f32(_ptr(st['p'].data), _ptr(st['g'].data), _ptr(st['m']), _ptr(st['v']), _ptr(st['ema']), st['p'].n_pad,
                                            float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']),
                                            float(grp['weight_decay']), self.steps, float(d if d is not None else 0.0), _stream()), 'adam_ema_step')
@@ -183,8 +194,11 @@ class FusedAdamEMA:
         return sd
 
 
-def build_optimizer(model, hyp, batch_size, nbs=64, ema=True):
-    """train.py:121-140: weight decay scaled by batch_size*accumulate/nbs, Adam(lr=3e-4, betas=(momentum, 0.999))."""
+def build_optimizer(model, hyp, batch_size, nbs=64, ema=True, adam=True):
+    """train.py:121-140: weight decay scaled by batch_size*accumulate/nbs; Adam(lr=3e-4, betas=(momentum, 0.999)) - what the reference
+    always runs (`opt.adam = True`, :134) - or, adam=False, SGD(lr=hyp['lr0'], momentum, nesterov=True) (:138)."""
     accumulate = max(round(nbs / batch_size), 1)
     wd = hyp['weight_decay'] * batch_size * accumulate / nbs
+    if not adam:
+        return FusedAdamEMA(model, lr=hyp['lr0'], betas=(hyp['momentum'], 0.999), weight_decay=wd, ema=ema, sgd=True)
     return FusedAdamEMA(model, lr=3e-4, betas=(hyp['momentum'], 0.999), weight_decay=wd, ema=ema)

@@ -47,7 +47,7 @@ def scheduler_step(optimizer, epoch, lf):
 
 
 class TrainStep:
-    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1):
+    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True):
         """accumulate: optimizer step every `accumulate` batches (train.py:121,252,272: max(round(nbs / total_batch), 1) in the
         reference loop; gradients simply keep accumulating in the flat buffers in between).  Default 1: every batch."""
         if not next(model.parameters()).is_cuda:
@@ -56,7 +56,7 @@ class TrainStep:
         self.world = dist.get_world_size() if dist is not None else 1
         model.hyp = hyp
         model.train()
-        self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True)
+        self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True, adam=adam)
         self.compute_loss = ComputeLoss(model)
         self.accumulate, self._since_step = max(int(accumulate), 1), 0
         self.buckets = None
