@@ -424,6 +424,15 @@ int somi_detect_plain_decode_f32(const float *t, int t_cs, const float *anchors_
                                  int ny, int nx, int na, int nc, int total, int row_off, somi_stream_t stream);
 int somi_detect_plain_raw_bwd_f32(const float *draw, float *dt, int t_cs, int B, int ny, int nx, int na, int nc, somi_stream_t stream);
 
+/* Test-time augmentation, `Model._forward_augment` (models/yolo.py:1253-1267).
+ * somi_tta_resample_nhwc4_f32: `scale_img(x.flip(3) if flip_lr else x, ratio, gs)` (utils/torch_utils.py:270-282) on the ingested image
+ *   x (B,H,W,4) -> y (B,Hp,Wp,4): bilinear resize to (Hs,Ws) = (int(H*ratio), int(W*ratio)) with torch's align_corners=False arithmetic,
+ *   the rest up to (Hp,Wp) = the next stride multiples filled with `pad` (0.447); channels >= `channels` stay zero.
+ * somi_tta_descale_f32: `_descale_pred` (:1292-1308) in place on z (rows, no): xywh /= scale, x = img_w - x after a left-right flip. */
+int somi_tta_resample_nhwc4_f32(const float *x, float *y, int B, int H, int W, int Hs, int Ws, int Hp, int Wp, int flip_lr, float pad,
+                                int channels, somi_stream_t stream);
+int somi_tta_descale_f32(float *z, long rows, int no, float scale, int flip_lr, float img_w, somi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Post-processing: batched NMS (utils/general.py:629-711 incl. the torchvision.ops.nms core at :694).
  * pred (B,n,5+nc) decoded.  Output: det (B,max_det,6) [x1,y1,x2,y2,conf,cls], count (B) int32.

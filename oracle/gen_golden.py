@@ -198,6 +198,19 @@ def gen_model():
         save(f'model_{tag}', **rec)
 
 
+def gen_tta():
+    """Test-time augmentation: the reference's `Model.forward(x, augment=True)` (models/yolo.py:1253-1267,1292-1318) on the small SOMI
+    graph (DecoupledDetect, 4 levels) and on yolov5 v6.0 (Detect, 3 levels, 3 classes), 64x96 images."""
+    g = torch.Generator().manual_seed(950)
+    x = torch.rand(2, 3, 64, 96, generator=g)
+    m = build_ref_model(0.25, 0.33, SOMI_ANCHORS).eval()
+    m2 = RY.Model(yolov5_cfg(0.25, 0.33, nc=3))
+    fill_state(m2, 1)
+    m2.eval()
+    with torch.no_grad():
+        save('model_tta', x=x, z_somi=m(x.clone(), augment=True)[0], z_yolov5=m2(x.clone(), augment=True)[0])
+
+
 # ------------------------------------------------------------------------------------------------ stock YOLOv5 set
 def gen_stock():
     """The stock YOLOv5 modules north_star names (BASELINE configs[0]) through the reference's own classes: Bottleneck, C3, SPP,
@@ -618,6 +631,6 @@ def gen_augment():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'stock', 'dcn', 'ckpt', 'loss', 'nms', 'val', 'augment']
+    which = sys.argv[1:] or ['dcnv3', 'blocks', 'model', 'tta', 'stock', 'dcn', 'ckpt', 'loss', 'nms', 'val', 'augment']
     for w in which:
         globals()[f'gen_{w}']()

@@ -118,7 +118,37 @@ class Model(nn.Module):
         B.initialize_weights(self)                                    # :1240
 
     def forward(self, x, augment=False, profile=False, visualize=False):
+        if augment:
+            return self._forward_augment(x)
         return self._forward_once(x)
+
+    def _forward_augment(self, x):
+        """Test-time augmentation (models/yolo.py:1253-1267): scales 1 / 0.83 / 0.67, each also flipped left-right; `scale_img`
+        (utils/torch_utils.py:270-282) = bilinear resize to int(size*ratio), padded with 0.447 up to the next stride multiple;
+        predictions de-scaled / un-flipped (:1292-1308), the first pass loses its coarsest level's rows and the last its finest
+        (:1310-1318)."""
+        import torch.nn.functional as F
+        img_size = x.shape[-2:]
+        gs = int(self.stride.max())
+        y = []
+        for si, fi in zip([1, 1, 0.83, 0.83, 0.67, 0.67], [None, 3, None, 3, None, 3]):
+            xi = x.flip(fi) if fi else x
+            if si != 1.0:
+                h, w = xi.shape[2:]
+                s = (int(h * si), int(w * si))
+                xi = F.interpolate(xi, size=s, mode='bilinear', align_corners=False)
+                hp, wp = (math.ceil(v * si / gs) * gs for v in (h, w))
+                xi = F.pad(xi, [0, wp - s[1], 0, hp - s[0]], value=0.447)
+            p = self._forward_once(xi)[0]
+            px, py, pwh = p[..., 0:1] / si, p[..., 1:2] / si, p[..., 2:4] / si
+            if fi == 3:
+                px = img_size[1] - px
+            y.append(torch.cat((px, py, pwh, p[..., 4:]), -1))
+        nl = self.model[-1].nl
+        g = sum(4 ** v for v in range(nl))
+        y[0] = y[0][:, :-(y[0].shape[1] // g)]
+        y[-1] = y[-1][:, (y[-1].shape[1] // g) * 4 ** (nl - 1):]
+        return torch.cat(y, 1), None
 
     def _forward_once(self, x):
         """Walk the layers with the skip list (models/yolo.py:1269-1290)."""

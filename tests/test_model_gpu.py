@@ -227,3 +227,22 @@ def test_attempt_load_checkpoint_written_by_the_reference(golden, tmp_path):
     with torch.no_grad():
         z, _ = model(T(g['x']).cuda())
     rel_close(z, T(g['z']), what='predictions of the loaded EMA weights')
+
+
+def test_tta_forward_augment_matches_reference_vectors(golden):
+    """`model(x, augment=True)` (models/yolo.py:1253-1318; `val.py --augment`): three scales x two flips through one resample kernel each,
+    de-scaled, clipped, concatenated - against the reference's own output for the SOMI graph (4 levels) and yolov5 (3 levels)."""
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg, yolov5_cfg
+    from somi_amd.model import Model
+    g = golden('model_tta')
+    x = T(g['x']).cuda()
+    for key, cfg in (('z_somi', somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS)), ('z_yolov5', yolov5_cfg(0.25, 0.33, nc=3))):
+        mine = Model(cfg)
+        mine.load_state_dict(fill_state(OModel(cfg), 1).state_dict())
+        mine = mine.cuda().eval()
+        with torch.no_grad():
+            z, none = mine(x, augment=True)
+            z8, _ = mine((x * 255).round().to(torch.uint8), augment=True)        # the uint8 batch contract goes through the same path
+        assert none is None and z.shape == T(g[key]).shape and z8.shape == z.shape
+        rel_close(z, T(g[key]), what=f'TTA {key}')

@@ -133,9 +133,66 @@ __global__ __launch_bounds__(256) void detect_plain_raw_bwd_kernel(const float *
     }
 }
 
+// Test-time augmentation input (models/yolo.py:1260 `scale_img(x.flip(fi) if fi else x, si, gs)`, utils/torch_utils.py:270-282): NHWC4 image
+// -> optionally flipped left-right, resized to (Hs, Ws) with torch's bilinear / align_corners=False arithmetic
+// (src = (dst + 0.5) * in/out - 0.5 clamped at 0, neighbour clamped at the border), padded with `pad` up to (Hp, Wp).
+__global__ __launch_bounds__(256) void tta_resample_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H, int W, int Hs, int Ws,
+                                                           int Hp, int Wp, int flip_lr, float pad, int nch) {
+    const long items = (long)B * Hp * Wp;
+    const float sh = (float)H / (float)Hs, sw = (float)W / (float)Ws;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int w = (int)(it % Wp), h = (int)((it / Wp) % Hp);
+        const long b = it / ((long)Wp * Hp);
+        f32x4 v = {pad, pad, pad, pad};
+        if (h < Hs && w < Ws) {
+            float fh = sh * ((float)h + 0.5f) - 0.5f, fw = sw * ((float)w + 0.5f) - 0.5f;
+            fh = fh < 0.f ? 0.f : fh;
+            fw = fw < 0.f ? 0.f : fw;
+            const int h0 = (int)fh, w0 = (int)fw;
+            const int h1 = h0 + (h0 < H - 1 ? 1 : 0), w1 = w0 + (w0 < W - 1 ? 1 : 0);
+            const float lh = fh - (float)h0, lw = fw - (float)w0;
+            const int a0 = flip_lr ? W - 1 - w0 : w0, a1 = flip_lr ? W - 1 - w1 : w1;      // the flip happens before the resize
+            const float *r0 = x + ((b * H + h0) * W) * 4, *r1 = x + ((b * H + h1) * W) * 4;
+            const f32x4 p00 = *reinterpret_cast<const f32x4 *>(r0 + a0 * 4), p01 = *reinterpret_cast<const f32x4 *>(r0 + a1 * 4);
+            const f32x4 p10 = *reinterpret_cast<const f32x4 *>(r1 + a0 * 4), p11 = *reinterpret_cast<const f32x4 *>(r1 + a1 * 4);
+            v = (1.f - lh) * ((1.f - lw) * p00 + lw * p01) + lh * ((1.f - lw) * p10 + lw * p11);
+        }
+        for (int c = nch; c < 4; ++c) v[c] = 0.f;                                          // pad channels stay zero
+        *reinterpret_cast<f32x4 *>(y + it * 4) = v;
+    }
+}
+
+// `_descale_pred` (models/yolo.py:1292-1308) on rows of z (rows, no): xywh /= scale; x = img_w - x after a left-right flip
+__global__ __launch_bounds__(256) void tta_descale_kernel(float *__restrict__ z, long rows, int no, float scale, int flip_lr, float img_w) {
+    for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        float *p = z + r * no;
+        float px = p[0] / scale;
+        if (flip_lr) px = img_w - px;
+        p[0] = px;
+        p[1] = p[1] / scale;
+        p[2] = p[2] / scale;
+        p[3] = p[3] / scale;
+    }
+}
+
 }  // namespace somi
 
 using namespace somi;
+
+extern "C" int somi_tta_resample_nhwc4_f32(const float *x, float *y, int B, int H, int W, int Hs, int Ws, int Hp, int Wp, int flip_lr, float pad,
+                                           int channels, somi_stream_t stream) {
+    SOMI_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && Hp >= Hs && Wp >= Ws && channels >= 1 && channels <= 4 && aligned16(x) &&
+                     aligned16(y), SOMI_EINVAL, "tta resample: bad arguments");
+    hipLaunchKernelGGL(tta_resample_kernel, dim3(ew_grid((long)B * Hp * Wp)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, Hs, Ws, Hp, Wp, flip_lr,
+                       pad, channels);
+    return launch_status("somi_tta_resample_nhwc4_f32");
+}
+
+extern "C" int somi_tta_descale_f32(float *z, long rows, int no, float scale, int flip_lr, float img_w, somi_stream_t stream) {
+    SOMI_REQUIRE(z && rows > 0 && no >= 4 && scale > 0.f, SOMI_EINVAL, "tta descale: bad arguments");
+    hipLaunchKernelGGL(tta_descale_kernel, dim3(ew_grid(rows)), dim3(256), 0, (hipStream_t)stream, z, rows, no, scale, flip_lr, img_w);
+    return launch_status("somi_tta_descale_f32");
+}
 
 extern "C" int somi_resample_slice_nhwc_f32(const float *src, int src_cs, int src_coff, float *dst, int dst_cs, int dst_coff, int B, int Hs,
                                             int Ws, int C, int up, int reduce, int accumulate, somi_stream_t stream) {

@@ -115,6 +115,8 @@ SIGNATURES = {
     'somi_space_to_depth_nhwc_f32': (I, [P, I, I, P, I, I, I, I, I, I, I, S]),
     'somi_detect_plain_decode_f32': (I, [P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
     'somi_detect_plain_raw_bwd_f32': (I, [P, P, I, I, I, I, I, I, S]),
+    'somi_tta_resample_nhwc4_f32': (I, [P, P, I, I, I, I, I, I, I, I, F, I, S]),
+    'somi_tta_descale_f32': (I, [P, C.c_long, I, F, I, F, S]),
     'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, P, I, I, I, I, I, I, S]),
     'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), P, F, I, P, P, P, I, I, I, I, S]),
     'somi_dwconv3x3_bwd_workspace_floats': (Z, [I, I, I]),

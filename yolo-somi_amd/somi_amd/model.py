@@ -195,8 +195,30 @@ class Model(nn.Module):
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, x, augment=False, profile=False, visualize=False):
         if augment:
-            raise NotImplementedError('TTA (_forward_augment, models/yolo.py:1253-1267) is outside the hot path')
+            return self._forward_augment(x)
         return self._forward_once(x)
+
+    def _forward_augment(self, x):
+        """Test-time augmentation, models/yolo.py:1253-1267: scales 1 / 0.83 / 0.67, each also flipped left-right.  The image is ingested
+        once; every variant is one resample launch (flip + torch-bilinear resize + 0.447 padding to the stride multiple), the
+        predictions are de-scaled / un-flipped in place (:1292-1308) and clipped (:1310-1318)."""
+        if self.training:
+            raise RuntimeError('augmented inference runs in eval mode')
+        H, W = x.shape[-2:]
+        base = ops.image_to_nhwc4(x.contiguous(), scale=1.0 / 255.0 if x.dtype == torch.uint8 else 1.0)
+        gs = int(self.stride.max())
+        y = []
+        for si, fl in zip([1, 1, 0.83, 0.83, 0.67, 0.67], [False, True, False, True, False, True]):
+            xi = base if (si == 1 and not fl) else ops.tta_resample(base, float(si), gs, fl)
+            z = self._forward_once(None, ingested=xi)[0]
+            if si != 1 or fl:
+                ops.tta_descale_(z, si, fl, W)
+            y.append(z)
+        nl = self.model[-1].nl
+        g = sum(4 ** v for v in range(nl))
+        y[0] = y[0][:, :-(y[0].shape[1] // g)]                                   # _clip_augmented: drop the first pass's coarsest level
+        y[-1] = y[-1][:, (y[-1].shape[1] // g) * 4 ** (nl - 1):]               # ... and the last pass's finest
+        return torch.cat(y, 1), None
 
     # ---------------------------------------------------------------------------------------------- training
     def _sources(self, m):
@@ -246,13 +268,15 @@ class Model(nn.Module):
             if hook:
                 hook(m.i)
 
-    def _forward_once(self, x):
-        """models/yolo.py:1269-1290: walk the layers with the skip list."""
-        if not x.is_cuda:
-            raise RuntimeError('somi_amd.Model runs on the MI355X only (no CPU fallback); move the batch to cuda')
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise RuntimeError(f'expected a (B,3,H,W) batch, got {tuple(x.shape)}')
-        a = B.Act(ops.image_to_nhwc4(x.contiguous(), scale=1.0 / 255.0 if x.dtype == torch.uint8 else 1.0), 0, 3)
+    def _forward_once(self, x, ingested=None):
+        """models/yolo.py:1269-1290: walk the layers with the skip list.  ingested: an already converted (B,H,W,4) image (TTA variants)."""
+        if ingested is None:
+            if not x.is_cuda:
+                raise RuntimeError('somi_amd.Model runs on the MI355X only (no CPU fallback); move the batch to cuda')
+            if x.dim() != 4 or x.shape[1] != 3:
+                raise RuntimeError(f'expected a (B,3,H,W) batch, got {tuple(x.shape)}')
+            ingested = ops.image_to_nhwc4(x.contiguous(), scale=1.0 / 255.0 if x.dtype == torch.uint8 else 1.0)
+        a = B.Act(ingested, 0, 3)
         y = []
         with B.collect_batches_tracked():                         # one multi-tensor add for all BatchNorm step counters
             for m in self.model:
@@ -264,7 +288,7 @@ class Model(nn.Module):
             # the blocks keep what backward needs on themselves (one set): a later train-mode forward overwrites it, so the
             # graph node remembers which forward it belongs to and refuses a stale backward instead of using wrong activations
             gen = self.__dict__['_fwd_gen'] = self.__dict__.get('_fwd_gen', 0) + 1
-            return list(_ModelGraph.apply(self._anchor(x.device), self, gen, *a))
+            return list(_ModelGraph.apply(self._anchor(ingested.device), self, gen, *a))
         return a
 
     def _anchor(self, dev):

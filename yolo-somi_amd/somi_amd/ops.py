@@ -319,6 +319,25 @@ def space_to_depth(x, x_coff, c, out=None, inverse=False):
     return out
 
 
+def tta_resample(x4, ratio, gs, flip_lr, channels=3, pad=0.447):
+    """scale_img(x.flip(3) if flip_lr else x, ratio, gs=gs) (utils/torch_utils.py:270-282) on an ingested (B,H,W,4) image."""
+    import math
+    B, H, W, _ = x4.shape
+    Hs, Ws = (H, W) if ratio == 1.0 else (int(H * ratio), int(W * ratio))
+    Hp, Wp = (H, W) if ratio == 1.0 else (math.ceil(H * ratio / gs) * gs, math.ceil(W * ratio / gs) * gs)
+    y = torch.empty(B, Hp, Wp, 4, device=x4.device, dtype=torch.float32)
+    check(_lib.lib().somi_tta_resample_nhwc4_f32(_ptr(_f32c(x4)), _ptr(y), B, H, W, Hs, Ws, Hp, Wp, int(bool(flip_lr)), float(pad), channels,
+                                                 _stream()), 'tta_resample')
+    return y
+
+
+def tta_descale_(z, scale, flip_lr, img_w):
+    """_descale_pred (models/yolo.py:1292-1308) in place on z (B, n, no)."""
+    check(_lib.lib().somi_tta_descale_f32(_ptr(_f32c(z)), z.shape[0] * z.shape[1], z.shape[2], float(scale), int(bool(flip_lr)), float(img_w),
+                                          _stream()), 'tta_descale')
+    return z
+
+
 def odconv_weights(gap, fc_w, fc_b, pk, wout, bout, cin, cin_pad, cout, kk, K):
     """Attention heads + per-sample weight synthesis of ODConv (models/common.py:4557-4590), outer BN folded in."""
     B = gap.shape[0]
