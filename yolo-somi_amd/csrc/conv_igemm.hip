@@ -288,9 +288,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
                 a_chnb[i] = (unsigned)(a_chn[i] + kc) * 4u;
             }
         }
-        // wave-uniform tap walk (FAST), positioned on K-tile kt0
-        const int cpt = FAST ? d.Cin / BK : 1;                          // K-tiles per tap
-        int tp_u = FAST ? kt0 / cpt : 0, c0_u = FAST ? (kt0 % cpt) * BK : 0;
+        // wave-uniform K walk (FAST), positioned on K-tile kt0.  Order: channel chunk OUTER, taps INNER - K-tile kt covers channels
+        // [32 (kt / ntap), +32) of tap kt % ntap.  (Tap-major order kept 3 image rows x Cin channels live per workgroup: 64 workgroups
+        // per XCD x 245 KB at 160x160x128 = 15 MB against a 4 MB L2, so every input row was fetched once per kernel row - PMC: 1079 MB
+        // for a 419 MB input.  With the taps inner the live set is 3 rows x 32 channels = 61 KB per workgroup.)
+        const int ntap_u = FAST ? nr_c * nq_c : 1;
+        int tp_u = FAST ? kt0 % ntap_u : 0, c0_u = FAST ? (kt0 / ntap_u) * BK : 0;
         int r_u = tp_u / nq_c, q_u = tp_u % nq_c;
 
         // k -> (tap r,q ; channel c) for this thread's column, advanced incrementally per K-tile (generic path: kt0 == 0)
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
                     ra[i] = v;
                 }
                 const unsigned ko = cls ? (unsigned)(((ph + cstep * r_u) * d.kw + pw + cstep * q_u) * d.Cin + c0_u) * 4u
-                                        : (unsigned)kt_next * (BK * 4u);
+                                        : (unsigned)(tp_u * d.Cin + c0_u) * 4u;
 #pragma unroll
                 for (int i = 0; i < B_ROWS; ++i) rb[i] = buf_load4(rw, b_off[i] + ko);
                 return;
@@ -339,11 +342,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
         };
         auto advance_k = [&]() {
             if constexpr (FAST) {
-                c0_u += BK;
-                if (c0_u == d.Cin) {
-                    c0_u = 0;
-                    ++tp_u;
-                    if (++q_u == nq_c) { q_u = 0; ++r_u; }
+                ++tp_u;
+                if (++q_u == nq_c) { q_u = 0; ++r_u; }
+                if (tp_u == ntap_u) {
+                    tp_u = 0; r_u = 0; q_u = 0;
+                    c0_u += BK;
                 }
                 return;
             }
