@@ -523,10 +523,11 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
     static const int eight = getenv("SOMI_CONV_8WAVE") ? atoi(getenv("SOMI_CONV_8WAVE")) : 2;
     if (eight && p.variant == 0) p.variant = 4;
     if (eight > 1 && p.variant == 2) p.variant = 5;
-    // 256 x 128 tile, 8 waves of 64 x 64: a third fewer LDS operand bytes per MFMA than the 64 x 32 wave tile (at full MFMA rate the
-    // 128 x 128 form would keep the LDS port ~98 % busy).  Measured (round 2): SLOWER - 109.7 vs 118.8 TFLOP/s on 128->128 3x3 at
-    // 160x160, 109 vs 114 at 80x80: its 110 KB of LDS leave one workgroup per CU, i.e. two waves per SIMD instead of four, and the
-    // lost latency hiding outweighs the LDS saving.  Kept behind SOMI_CONV_BIG=1 for experiments.
+    // 256 x 128 tile, 8 waves of 64 x 64 (a third fewer LDS operand bytes per MFMA than the 64 x 32 wave tile).  Measured (round 2):
+    // SLOWER - 109.7 vs 118.8 TFLOP/s on 128->128 3x3 at 160x160, 109 vs 114 at 80x80.  The premise was wrong: a 32x32x2 fp32 MFMA
+    // occupies the pipe for 64 cycles, so the 128 x 128 form's operand reads + tile writes are ~31 B/clk per CU, a quarter of the LDS
+    // port - LDS bandwidth is not what holds the kernel at 72-78 % MFMA busy; and the big tile's 110 KB of LDS leave one workgroup per CU
+    // (two waves per SIMD instead of four), which costs latency hiding.  Kept behind SOMI_CONV_BIG=1 for experiments.
     static const int big = getenv("SOMI_CONV_BIG") ? atoi(getenv("SOMI_CONV_BIG")) : 0;
     if (big && p.variant == 4 && fast_path(d) && !d.per_sample_w && !d.a_chan_scale && !d.a_pix_scale && M >= 256 * 256) p.variant = 6;
     if (sk_ok) {
