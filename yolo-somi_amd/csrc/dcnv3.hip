@@ -344,6 +344,7 @@ struct GinGeo {
     int tiles_h, tiles_w;
     int WH, WW;                  // window extent (input pixels)
     int lo_h, lo_w;              // window origin = tile origin * stride + lo
+    unsigned rkw, rWW;           // floor(65536/d) + 1 for d = kernel_w, WW: x / d == (x * r) >> 16 while x < 65536 / d (win_plan checks)
     float *staging;              // [N][G][tiles][WH*WW][Gc]
     unsigned *overflow;          // taps that fell outside their tile's window (added with fp32 atomics): 0 <=> bit-reproducible
 };
@@ -479,23 +480,36 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
     const double magic = ldexp(1.5, 52 + e2 - 38);               // (x + magic) - magic rounds x to a multiple of 2^(e2-38)
     const bool finite = mx > 0.f && mx < __builtin_huge_valf();
     float *dst = q.staging + (((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile) * (long)ncell * GC;
-    for (int cell = slot; cell < ncell; cell += SLOTS) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;             // exact sums: splitting the chain changes nothing but the latency
-        if (finite) {
-            int e = start[cell];
-            const int e1 = e + cnt[cell];
-            for (; e + 4 <= e1; e += 4) {
-                const float c0 = ent_cf[e], c1 = ent_cf[e + 1], c2 = ent_cf[e + 2], c3 = ent_cf[e + 3];
-                const float t0 = tgt[ent_px[e] * GC + c], t1 = tgt[ent_px[e + 1] * GC + c], t2 = tgt[ent_px[e + 2] * GC + c],
-                            t3 = tgt[ent_px[e + 3] * GC + c];
-                a0 += ((double)(t0 * c0) + magic) - magic;
-                a1 += ((double)(t1 * c1) + magic) - magic;
-                a2 += ((double)(t2 * c2) + magic) - magic;
-                a3 += ((double)(t3 * c3) + magic) - magic;
+    {
+        constexpr int LG4 = GC / 4, SLOTS4 = 256 / LG4;          // four channels per lane: the list entry and its address are read once for them
+        const int c4 = (threadIdx.x % LG4) * 4;
+        for (int cell = threadIdx.x / LG4; cell < ncell; cell += SLOTS4) {
+            double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};   // exact sums: splitting the chain changes nothing but the latency
+            if (finite) {
+                int e = start[cell];
+                const int e1 = e + cnt[cell];
+                for (; e + 2 <= e1; e += 2) {
+                    const float c0 = ent_cf[e], c1 = ent_cf[e + 1];
+                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(tgt + ent_px[e] * GC + c4);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(tgt + ent_px[e + 1] * GC + c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s0[j] += ((double)(t0[j] * c0) + magic) - magic;
+                        s1[j] += ((double)(t1[j] * c1) + magic) - magic;
+                    }
+                }
+                if (e < e1) {
+                    const float c0 = ent_cf[e];
+                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(tgt + ent_px[e] * GC + c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s0[j] += ((double)(t0[j] * c0) + magic) - magic;
+                }
             }
-            for (; e < e1; ++e) a0 += ((double)(tgt[ent_px[e] * GC + c] * ent_cf[e]) + magic) - magic;
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (float)(s0[j] + s1[j]);
+            *reinterpret_cast<f32x4 *>(dst + cell * GC + c4) = r;
         }
-        dst[cell * GC + c] = (float)((a0 + a1) + (a2 + a3));
     }
     // 5. taps beyond the window: fp32 atomics into grad_input like the reference's own kernel (128 contiguous bytes per tap)
     if (novf) {
@@ -540,8 +554,271 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_combine_kernel(const DcnArgs a,
     }
 }
 
-// geometry of the windowed form; false when it does not apply (group width, LDS budget)
-static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &staging_bytes) {
+// ------------------------------------------------------------------------------------------------ windowed gathers: forward, backward A
+// The tiled kernels above fetch every bilinear tap from L2: 4*K taps of 4*Gc bytes per (pixel, group), 59 M cache-line requests at
+// N32 80x80 C256 - they run at the L2 request rate (1.4-1.7 TB/s of algorithmic bytes), although neighbouring pixels sample the same
+// input pixels ~4*K times over.  Here a workgroup owns the 8x8 output tile of ONE group (the geometry of backward B) and first copies
+// the input window around it - tile + kernel reach + R pixels of offset slack, zero outside the image - into LDS with coalesced
+// 4*Gc-byte runs (225 runs instead of 2304 tap fetches at K = 9, R = 2; 4.8x fewer L2 requests measured).  The taps then come from
+// LDS as 16-byte reads, Gc/4 lanes per pixel.  With the memory system out of the way the kernel is bound by its vector instructions
+// (PMC: 900 per wave, 144 of them the multiply-adds), so everything per lane is 32-bit off uniform bases, divisions are reciprocal
+// multiplies, and a record carries the ready LDS offset of its footprint: an unused point aims at a pad of zero cells behind the
+// window, so the loop over the points has no selects.  A pixel with a footprint beyond the window (flag bit in the record) is redone
+// with the tiled kernel's gather from global memory.
+// MODE 0: output.  MODE 1: grad_offset / grad_mask (butterfly over the Gc/4 lanes of a pixel, no atomics).
+// LDS (dynamic): win [WH*WW + WW + 2][GC] floats | rf [64*K] float4 | code [64*K] ints - 42 KB at K = 9, Gc = 32, R = 2.
+constexpr int WIN_FAR = 1 << 30;        // record flag: footprint leaves the window
+constexpr int WIN_OFF = WIN_FAR - 1;
+constexpr int WIN_PF = 3;               // sampling points whose offset / mask loads are issued ahead of the window loads
+
+// sum over an aligned group of LG (2, 4, 8, 16) neighbouring lanes, the same value in every lane: DPP row operations on the VALU
+// (__shfl_xor compiles to ds_bpermute_b32, i.e. LDS traffic: 9 per sampling point in backward A)
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LG>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LG >= 2) v += dpp_get<0xB1>(v);                 // quad_perm [1,0,3,2]
+    if constexpr (LG >= 4) v += dpp_get<0x4E>(v);                 // quad_perm [2,3,0,1]
+    if constexpr (LG >= 8) v += dpp_get<0x141>(v);                // row_half_mirror: the other quad of the 8
+    if constexpr (LG >= 16) v += dpp_get<0x140>(v);               // row_mirror: the other half of the 16
+    return v;
+}
+
+template <int GC, int MODE>
+__global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const GinGeo q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LG = GC / 4, PPW = 256 / LG;                      // lanes per pixel, pixels per pass of the block
+    const int ncell = q.WH * q.WW, nrec = GIN_TP * a.K, ntile = q.tiles_h * q.tiles_w;
+    float *win = reinterpret_cast<float *>(smem);
+    f32x4 *rf = reinterpret_cast<f32x4 *>(win + (size_t)(ncell + q.WW + 2) * GC);
+    int *code = reinterpret_cast<int *>(rf + nrec);
+    // (image, tile, group) with the group fastest: the G workgroups of a tile read neighbouring bytes, and an XCD's L2 sees one
+    // contiguous run of tiles (their halos overlap)
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int g = id % a.G, tile = (id / a.G) % ntile, n = id / (a.G * ntile);
+    const int th0 = (tile / q.tiles_w) * GIN_TH, tw0 = (tile % q.tiles_w) * GIN_TW;
+    const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
+    // uniform 64-bit bases; everything per lane is 32-bit from here (win_plan checks the extents)
+    const float *img = a.input + (long)n * a.H * a.W * a.C + g * GC;
+    const long opix0 = (long)n * a.Ho * a.Wo;
+    const float *ofs_b = a.offset + (opix0 * a.G + g) * a.K * 2;
+    const float *msk_b = a.mask + (opix0 * a.G + g) * a.K;
+    const int GK = a.G * a.K;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // 1. loads first, all in flight together.  A thread builds the records of one (pixel, kernel column): kernel_h consecutive points
+    //    (offsets and masks contiguous), the pixel decode and the base position shared.  Their first WIN_PF loads go out here ...
+    const int ncol = GIN_TP * a.kw;
+    float2 ofs_r[WIN_PF];
+    float m_r[WIN_PF];
+    {
+        const int t = threadIdx.x;
+        const int pl = (int)(((unsigned)t * q.rkw) >> 16), ii = t - pl * a.kw;
+        const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+        const bool on = t < ncol && ho < a.Ho && wo < a.Wo;
+        const int s = (ho * a.Wo + wo) * GK + ii * a.kh;
+#pragma unroll
+        for (int j = 0; j < WIN_PF; ++j) {
+            ofs_r[j] = make_float2(0.f, 0.f);
+            m_r[j] = 0.f;
+            if (on && j < a.kh) {
+                ofs_r[j] = *reinterpret_cast<const float2 *>(ofs_b + (s + j) * 2);
+                m_r[j] = msk_b[s + j];
+            }
+        }
+    }
+    //    ... then the window in batches of four 16-byte runs
+    const int nrun = ncell * LG;
+    for (int i0 = threadIdx.x; i0 < nrun; i0 += 4 * 256) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j * 256;
+            const int cell = i / LG, part = i % LG;
+            const int hr = (int)(((unsigned)cell * q.rWW) >> 16);
+            const int h = win_h0 + hr, w = win_w0 + (cell - hr * q.WW);
+            v[j] = zero;
+            if (i < nrun && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+                v[j] = *reinterpret_cast<const f32x4 *>(img + (h * a.W + w) * a.C + part * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j * 256;
+            if (i < nrun) *reinterpret_cast<f32x4 *>(win + (size_t)i * 4) = v[j];      // (cell, part) -> cell*GC + part*4 == i*4
+        }
+    }
+    for (int i = threadIdx.x; i < (q.WW + 2) * LG; i += 256) *reinterpret_cast<f32x4 *>(win + (size_t)(nrun + i) * 4) = zero;   // the zero pad
+    // 2. the sampling records: byte offset of the footprint's first cell in `win` (the zero pad for an unused point and, flagged
+    //    WIN_FAR, for a footprint beyond the window) and, MODE 0, the four tap coefficients x mask / MODE 1, {lh, lw, mask, -} -
+    //    the arithmetic of make_record
+    const int pad_off = ncell * GC * 4;
+    const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
+    for (int t = threadIdx.x; t < ncol; t += 256) {
+        const int pl = (int)(((unsigned)t * q.rkw) >> 16), ii = t - pl * a.kw;
+        const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+        const bool on = ho < a.Ho && wo < a.Wo;
+        const int s = (ho * a.Wo + wo) * GK + ii * a.kh;
+        const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
+        const float p0h = (float)(half_h - a.ph + ho * a.sh) - (float)half_h * a.offset_scale;
+        const float iw = (float)(ii * a.dw);
+        const int r0 = pl * a.K + ii * a.kh;
+        for (int jj = 0; jj < a.kh; ++jj) {
+            int cd = pad_off;
+            f32x4 f = zero;
+            if (on) {
+                float2 ofs;
+                float m;
+                if (t < 256 && jj < WIN_PF) {
+                    ofs = jj == 0 ? ofs_r[0] : (jj == 1 ? ofs_r[1] : ofs_r[2]);
+                    m = jj == 0 ? m_r[0] : (jj == 1 ? m_r[1] : m_r[2]);
+                } else {
+                    ofs = *reinterpret_cast<const float2 *>(ofs_b + (s + jj) * 2);
+                    m = msk_b[s + jj];
+                }
+                const float loc_w = p0w + (iw + ofs.x) * a.offset_scale;
+                const float loc_h = p0h + ((float)(jj * a.dh) + ofs.y) * a.offset_scale;
+                const float fh = floorf(loc_h), fw = floorf(loc_w);
+                const float lh = loc_h - fh, lw = loc_w - fw;
+                if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)a.H && loc_w < (float)a.W) {
+                    const int wh = (int)fh - win_h0, ww = (int)fw - win_w0;
+                    const bool inside = wh >= 0 && wh + 1 < q.WH && ww >= 0 && ww + 1 < q.WW;
+                    cd = inside ? (wh * q.WW + ww) * (GC * 4) : (pad_off | WIN_FAR);
+                    if constexpr (MODE == 0) {                       // taps outside the image read zeros of the window: no validity tests
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        f[0] = hh * hw * m;
+                        f[1] = hh * lw * m;
+                        f[2] = lh * hw * m;
+                        f[3] = lh * lw * m;
+                    }
+                }
+                if constexpr (MODE == 1) { f[0] = lh; f[1] = lw; f[2] = m; }
+            }
+            code[r0 + jj] = cd;
+            rf[r0 + jj] = f;
+        }
+    }
+    __syncthreads();
+    // 3. Gc/4 lanes per pixel, three points = 12 LDS reads in flight
+    const int part = threadIdx.x % LG;
+    const int rowB = q.WW * GC * 4;
+    const char *wbase = reinterpret_cast<const char *>(win + part * 4);
+    for (int p0 = 0; p0 < GIN_TP; p0 += PPW) {
+        const int pl = p0 + threadIdx.x / LG;
+        const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+        const bool live = pl < GIN_TP && ho < a.Ho && wo < a.Wo;
+        if (MODE == 0 && !live) continue;
+        const int plc = live ? pl : 0;
+        const int lpix = live ? ho * a.Wo + wo : 0;                  // pixel inside the image
+        const long pix = opix0 + lpix;
+        const float *src = img + part * 4;
+        const int *cr = code + plc * a.K;
+        const f32x4 *fr = rf + plc * a.K;
+        if constexpr (MODE == 0) {
+            f32x4 acc = zero;
+            int flags = 0;
+            int k = 0;
+            for (; k + 3 <= a.K; k += 3) {
+                int cd[3];
+                f32x4 f[3], u[12];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { cd[j] = cr[k + j]; f[j] = fr[k + j]; }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    flags |= cd[j];
+                    const char *b = wbase + (cd[j] & WIN_OFF);
+                    u[j * 4] = *reinterpret_cast<const f32x4 *>(b);
+                    u[j * 4 + 1] = *reinterpret_cast<const f32x4 *>(b + GC * 4);
+                    u[j * 4 + 2] = *reinterpret_cast<const f32x4 *>(b + rowB);
+                    u[j * 4 + 3] = *reinterpret_cast<const f32x4 *>(b + rowB + GC * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += f[j][0] * u[j * 4] + f[j][1] * u[j * 4 + 1] + f[j][2] * u[j * 4 + 2] + f[j][3] * u[j * 4 + 3];
+            }
+            for (; k < a.K; ++k) {
+                const int cd = cr[k];
+                flags |= cd;
+                const f32x4 f = fr[k];
+                const char *b = wbase + (cd & WIN_OFF);
+                acc += f[0] * *reinterpret_cast<const f32x4 *>(b) + f[1] * *reinterpret_cast<const f32x4 *>(b + GC * 4) +
+                       f[2] * *reinterpret_cast<const f32x4 *>(b + rowB) + f[3] * *reinterpret_cast<const f32x4 *>(b + rowB + GC * 4);
+            }
+            if (flags & WIN_FAR) {                                 // rare: the far points (they added zeros above) by the tiled kernel's gather
+                for (k = 0; k < a.K; ++k) {
+                    if (!(cr[k] & WIN_FAR)) continue;
+                    const Rec r = make_record<false>(a, pix, g, k);
+                    acc += r.f[0] * *reinterpret_cast<const f32x4 *>(src + r.off[0]) + r.f[1] * *reinterpret_cast<const f32x4 *>(src + r.off[1]) +
+                           r.f[2] * *reinterpret_cast<const f32x4 *>(src + r.off[2]) + r.f[3] * *reinterpret_cast<const f32x4 *>(src + r.off[3]);
+                }
+            }
+            *reinterpret_cast<f32x4 *>(a.output + opix0 * a.C + g * GC + (lpix * a.C + part * 4)) = acc;
+        } else {
+            const f32x4 tg = live ? *reinterpret_cast<const f32x4 *>(a.grad_output + opix0 * a.C + g * GC + (lpix * a.C + part * 4)) : zero;
+            float *gm_b = a.grad_mask + (opix0 * a.G + g) * a.K + lpix * GK;
+            float *go_b = a.grad_offset + ((opix0 * a.G + g) * a.K + lpix * GK) * 2;
+            for (int k0 = 0; k0 < a.K; k0 += 3) {
+                const int nk = min(3, a.K - k0);
+                int cd[3];
+                f32x4 f[3], u[12];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int kk = k0 + (j < nk ? j : 0);
+                    cd[j] = live ? cr[kk] : pad_off;
+                    f[j] = fr[kk];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const char *b = wbase + (cd[j] & WIN_OFF);
+                    u[j * 4] = *reinterpret_cast<const f32x4 *>(b);
+                    u[j * 4 + 1] = *reinterpret_cast<const f32x4 *>(b + GC * 4);
+                    u[j * 4 + 2] = *reinterpret_cast<const f32x4 *>(b + rowB);
+                    u[j * 4 + 3] = *reinterpret_cast<const f32x4 *>(b + rowB + GC * 4);
+                }
+                if ((cd[0] | cd[1] | cd[2]) & WIN_FAR) {              // rare: the far points by the tiled kernel's gather
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        if (!(cd[j] & WIN_FAR) || j >= nk) continue;
+                        const Rec r = make_record<true>(a, pix, g, k0 + j);
+                        const int bits = __float_as_int(r.f[3]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) u[j * 4 + t] = (bits >> t) & 1 ? *reinterpret_cast<const f32x4 *>(src + r.off[t]) : zero;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (j >= nk) break;                                  // wave-uniform
+                    const f32x4 v1 = u[j * 4], v2 = u[j * 4 + 1], v3 = u[j * 4 + 2], v4 = u[j * 4 + 3];
+                    const float lh = f[j][0], lw = f[j][1], m = f[j][2], hh = 1.f - lh, hw = 1.f - lw;
+                    // dcnv3_col2im_bilinear: value, grad_h_weight, grad_w_weight (dcnv3_im2col_cuda.cuh:112-141)
+                    const f32x4 val = (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
+                    const f32x4 ghw = hw * (v3 - v1) + lw * (v4 - v2);
+                    const f32x4 gww = hh * (v2 - v1) + lh * (v4 - v3);
+                    const float gm = group_sum<LG>((tg[0] * val[0] + tg[1] * val[1]) + (tg[2] * val[2] + tg[3] * val[3]));
+                    const float gw = group_sum<LG>(((tg[0] * gww[0] + tg[1] * gww[1]) + (tg[2] * gww[2] + tg[3] * gww[3])) * m);
+                    const float gh = group_sum<LG>(((tg[0] * ghw[0] + tg[1] * ghw[1]) + (tg[2] * ghw[2] + tg[3] * ghw[3])) * m);
+                    if (live && part == 0) {
+                        gm_b[k0 + j] = gm;
+                        *reinterpret_cast<float2 *>(go_b + (k0 + j) * 2) = make_float2(a.offset_scale * gw, a.offset_scale * gh);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MODE>
+static void launch_win(const DcnArgs &a, const GinGeo &q, size_t lds, hipStream_t s) {
+    const dim3 grid((unsigned)(a.N * a.G * q.tiles_h * q.tiles_w));
+    switch (a.Gc) {
+    case 8: hipLaunchKernelGGL((dcnv3_win_kernel<8, MODE>), grid, dim3(256), lds, s, a, q); break;
+    case 16: hipLaunchKernelGGL((dcnv3_win_kernel<16, MODE>), grid, dim3(256), lds, s, a, q); break;
+    case 32: hipLaunchKernelGGL((dcnv3_win_kernel<32, MODE>), grid, dim3(256), lds, s, a, q); break;
+    default: hipLaunchKernelGGL((dcnv3_win_kernel<64, MODE>), grid, dim3(256), lds, s, a, q); break;
+    }
+}
+
+// geometry of the windowed forms (tile + kernel reach + R pixels of offset slack); false for other group widths
+static bool win_geo(const DcnArgs &a, GinGeo &q) {
     if (!(a.Gc == 8 || a.Gc == 16 || a.Gc == 32 || a.Gc == 64)) return false;
     static const int slack = [] { const char *e = getenv("SOMI_DCN_SLACK"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
     q.R = slack;
@@ -554,6 +831,26 @@ static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &staging_b
     q.WW = (GIN_TW - 1) * a.sw + lo_rw + hi_rw + 2 * q.R + 2;
     q.tiles_h = (a.Ho + GIN_TH - 1) / GIN_TH;
     q.tiles_w = (a.Wo + GIN_TW - 1) / GIN_TW;
+    return true;
+}
+
+// the gathering kernels (forward, backward A): LDS bytes, or 0 when the window does not fit / the grid does not index
+static size_t win_plan(const DcnArgs &a, GinGeo &q) {
+    if (!win_geo(a, q)) return 0;
+    const char *e = getenv("SOMI_DCN_DIRECT");                    // read per call: tools flip it to time the two forms side by side
+    if (e && e[0] == '1') return 0;
+    const size_t lds = ((size_t)q.WH * q.WW + q.WW + 2) * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(f32x4) + sizeof(int));
+    if (lds > 64 * 1024 || (long)a.N * a.G * q.tiles_h * q.tiles_w >= (1L << 31)) return 0;
+    if ((long)a.Ho * a.Wo * a.G * a.K * 2 >= (1L << 31) || (long)a.Ho * a.Wo * a.C >= (1L << 31)) return 0;      // 32-bit indices inside one image
+    if (GIN_TP * a.kw + 256 >= 65536 / a.kw || q.WH * q.WW >= 65536 / q.WW) return 0;                             // the reciprocal divisions
+    q.rkw = 65536u / a.kw + 1;
+    q.rWW = 65536u / q.WW + 1;
+    return lds;
+}
+
+// backward B/C; false when it does not apply (group width, LDS budget)
+static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &staging_bytes) {
+    if (!win_geo(a, q)) return false;
     lds = (size_t)GIN_TP * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(RecG) + 4 * sizeof(float) + 4) + GIN_OVF_CAP * sizeof(OvfG) +
           3 * ((size_t)q.WH * q.WW + 1) * sizeof(int);
     if (lds > 150 * 1024 || (long)q.tiles_h * q.tiles_w > 65535L * 32) return false;
@@ -602,6 +899,12 @@ extern "C" int somi_dcnv3_forward_f32(const float *input, const float *offset, c
     SOMI_REQUIRE((reinterpret_cast<uintptr_t>(offset) & 7u) == 0, SOMI_EINVAL, "dcnv3: offset must be 8 B aligned");
     const size_t lds = (size_t)a.TP * G * a.K * sizeof(Rec);
     const bool vec = (Gc % 4 == 0) && aligned16(input) && aligned16(output);
+    GinGeo q{};
+    const size_t wlds = vec ? win_plan(a, q) : 0;
+    if (wlds) {
+        launch_win<0>(a, q, wlds, (hipStream_t)stream);
+        return launch_status("somi_dcnv3_forward_f32 (windowed)");
+    }
     if (vec) hipLaunchKernelGGL(dcnv3_fwd_kernel<4>, dim3(a.ntile), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(dcnv3_fwd_kernel<1>, dim3(a.ntile), dim3(256), lds, (hipStream_t)stream, a);
     return launch_status("somi_dcnv3_forward_f32");
@@ -641,7 +944,10 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
                           aligned16(grad_output);
     if (windowed) {
         // A: grad_offset / grad_mask (float4 gathers, no atomics)
-        hipLaunchKernelGGL(dcnv3_bwd_om_kernel, dim3(a.ntile), dim3(256), (size_t)a.TP * G * a.K * sizeof(Rec), s, a);
+        GinGeo qa{};
+        const size_t wlds = aligned16(input) ? win_plan(a, qa) : 0;
+        if (wlds) launch_win<1>(a, qa, wlds, s);
+        else hipLaunchKernelGGL(dcnv3_bwd_om_kernel, dim3(a.ntile), dim3(256), (size_t)a.TP * G * a.K * sizeof(Rec), s, a);
         // B: grad_input windows, C: combine
         q.staging = static_cast<float *>(workspace);
         q.overflow = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + gbytes - 256);
