@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 8
+#define SOMI_ABI_VERSION 9
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -293,6 +293,27 @@ int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int 
 int somi_bn_stats_partials_f32(const float *part_sum, const float *part_sumsq, int rows, long npix, int C, float eps, float momentum,
                                const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
                                float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
+/* SyncBatchNorm (reference train.py:165-167, torch.nn.SyncBatchNorm.convert_sync_batchnorm under --sync-bn): the statistics of a
+ * BatchNorm layer over the batches of ALL ranks.  The library has no communicator: the caller exchanges one small record per layer.
+ *   forward   somi_bn_local_sums_f64 -> record [2*C + 1] doubles {sum(x - pivot), sum((x - pivot)^2), pixel count} of this rank, from x
+ *             or (part_sum != NULL) from a convolution's partial rows; pivot = the running mean, equal on every rank.
+ *             all-gather the records ([nranks][2*C + 1]); somi_bn_stats_from_sums_f64 adds them in rank order (identical results
+ *             on every rank) -> mean / rstd / scale / shift and the running statistics (unbiased variance over the global count).
+ *   backward  somi_bn_act_backward_sums_f64 -> record {sum d, sum d*(v - mean), count}; all-gather; ..._apply_sync_f32 builds the
+ *             input gradient from the global sums and ACCUMULATES dgamma / dbeta from the LOCAL ones (the gradient exchange sums them).
+ * workspace: max(2*1024*C, 2*somi_red_nchunk(npix)*C) floats (sums), 3*C floats (apply). */
+int somi_bn_local_sums_f64(const float *x, int x_cs, int x_coff, long npix, int C, const float *pivot /* or NULL */, const float *part_sum,
+                           const float *part_sumsq, int rows, double *sums, float *workspace, somi_stream_t stream);
+int somi_bn_stats_from_sums_f64(const double *all_sums, int nranks, int C, float eps, float momentum, const float *gamma, const float *beta,
+                                float *mean, float *rstd, float *scale, float *shift, float *running_mean, float *running_var,
+                                somi_stream_t stream);
+int somi_bn_act_backward_sums_f64(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
+                                  const float *scale, const float *shift, int act, int order, long npix, int C, double *sums, float *workspace,
+                                  somi_stream_t stream);
+int somi_bn_act_backward_apply_sync_f32(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
+                                        const float *rstd, const float *scale, const float *shift, int act, int order,
+                                        const double *local_sums, const double *all_sums, int nranks, float *dx, int dx_cs, int dx_coff,
+                                        float *dgamma, float *dbeta, long npix, int C, float *workspace, somi_stream_t stream);
 int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act,
                                   int order, float *z, int z_cs, int z_coff, long npix, int C, const float *residual /* or NULL: added last */,
                                   int res_cs, int res_coff, somi_stream_t stream);

@@ -517,6 +517,20 @@ def test_data_parallel_rehearsal_two_ranks_one_gpu():
     assert r.returncode == 0 and 'ddp rehearsal ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_sync_bn_two_ranks_one_gpu():
+    """tools/syncbn_rehearsal.py (--sync-bn, train.py:165-167): BatchNorm statistics over the batches of both ranks - a Conv/BN chain
+    against the CPU oracle on the whole batch, and one TrainStep(sync_bn=True) on two half-batches against one process on the whole."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29551', os.path.join(root, 'tools', 'syncbn_rehearsal.py')], capture_output=True, text=True,
+                       timeout=420, env=env, cwd=root)
+    assert r.returncode == 0 and 'sync-bn rehearsal ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_train_step_gradient_accumulation():
     """accumulate=2 (train.py:121,272): the first batch only accumulates gradients, the second steps the optimizer on the sum."""
     from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch
@@ -780,13 +794,17 @@ def test_uavdt_1280_nc3_training_step_gradients():
         # cancelling terms over 10^5 pixels where the fp32 CPU path is itself 0.2 ... 0.7 of the scale away from fp64
         if rel_mine[-1] > max(0.5, 4 * rel_o32[-1]):
             bad.append((n, rel_mine[-1], rel_o32[-1]))
-    # ... with one discontinuous exception: the first layer of the channel-attention MLPs sits behind a ReLU fed by pooled values; a
-    # hidden unit whose pre-activation is within rounding of zero has its gate open in one arithmetic and shut in the other, which
-    # moves its whole weight row (the fp32 CPU path shows the same flips against fp64, at 8 ... 28 % of the scale here)
-    # ... and the bias of the 7x7 spatial-attention conv: the plain sum of its logit gradients over every pixel of the batch (2 x 320 x 320
-    # at layer 2), terms of both signs that cancel to a few ulps of their size (test_whole_model_train_step_gradients carries an absolute
-    # floor for the same parameter): the fp32 CPU path is 6 ... 17 % of the scale away from fp64 on it here
-    gated = [b for b in bad if '.channel_attention.shared_MLP.0.' in b[0] or b[0].endswith('.spatial_attention.cv1.bias')]
+    # ... with one family of exceptions, the parameters inside the CBAM attention blocks on which the fp32 CPU path is ITSELF more than 5 % of
+    # the scale away from fp64 (it is 8 ... 80 % off on the ones that show up here):
+    #  * the first layer of the channel-attention MLPs sits behind a ReLU fed by pooled values; a hidden unit whose pre-activation is within
+    #    rounding of zero has its gate open in one arithmetic and shut in the other, which moves its whole weight row - and, through the
+    #    channel weights, the statistics the spatial attention of the same block sees;
+    #  * the 7x7 spatial-attention conv: its bias gradient is the plain sum of the logit gradients over every pixel of the batch (2 x 320 x 320
+    #    at layer 2), terms of both signs that cancel to a few ulps of their size, and its weight gradients are that same sum weighted by
+    #    the (mostly positive) channel mean / max maps (test_whole_model_train_step_gradients carries an absolute floor for the bias).
+    # The values are stable from run to run and under changes of the accumulation precision of those sums (tried: double), i.e. they are
+    # a different, equally valid, fp32 realisation - not noise of this implementation.
+    gated = [b for b in bad if ('.channel_attention.' in b[0] or '.spatial_attention.' in b[0]) and b[2] > 0.05]
     assert len(gated) == len(bad) and len(bad) <= max(6, len(rel_mine) // 100), [b for b in bad if b not in gated][:8] or bad[:8]
     rm, ro = torch.tensor(rel_mine), torch.tensor(rel_o32)
     print(f'1280 nc=3: HIP median {float(rm.median()):.2e} q90 {float(rm.quantile(0.9)):.2e} max {float(rm.max()):.2e}; '

@@ -14,11 +14,13 @@ def first(pattern):
     return fs[0] if fs else None
 
 
-print('# rocprofv3 --kernel-trace --stats : python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-infer')
+infer = len(sys.argv) <= 2                                          # called without a traffic file for the inference profile
+print('# rocprofv3 --kernel-trace --stats : python bench.py ' + ('--mode infer --batch 128 --steps 5 --warmup 2 --no-cpu-baseline' if infer else
+                                                              '--steps 3 --warmup 1 --no-cpu-baseline --no-infer'))
 f = first(f'{d}/stats/**/*_kernel_stats.csv')
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-print(f'# total kernel time {tot / 1e6:.1f} ms over 4 steps (1 warm-up + 3)')
+print(f'# total kernel time {tot / 1e6:.1f} ms over ' + ('7 steps (2 warm-up + 5)' if infer else '4 steps (1 warm-up + 3)'))
 print(f'{"kernel":100s} {"calls":>6s} {"total_ms":>10s} {"avg_us":>10s} {"pct":>6s}')
 for r in rows[:60]:
     print(f'{r["Name"][:100]:100s} {r["Calls"]:>6s} {float(r["TotalDurationNs"]) / 1e6:10.2f} {float(r["AverageNs"]) / 1e3:10.1f} '

@@ -44,7 +44,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return start + idx;
 }
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // BiFPN fusion weights w_i / (sum_j swish(w_j) + eps) (models/common.py:3696, Swish :8210) from the raw parameter on the device
 __device__ __forceinline__ void bifpn_norm(const float *__restrict__ w, int n_in, float eps, float (&wn)[3]) {

@@ -16,8 +16,9 @@
 // HBM-bound: algorithmic bytes per output pixel = 4*(2*C + 3*G*K) forward (input once + output + offset + mask).
 // Backward, two forms.
 //   windowed (the fast path; needs a caller workspace, group widths 8/16/32/64):
-//     A  dcnv3_bwd_om_kernel: grad_offset / grad_mask - the forward's gather plus the grad_output read and an in-wave
-//        reduction over a group's channels (shuffle butterflies instead of the reference's shared-memory tree); no atomics.
+//     A  dcnv3_win_kernel<Gc, 1> (dcnv3_bwd_om_kernel where the window does not fit): grad_offset / grad_mask - the forward's
+//        gather plus the grad_output read and an in-wave reduction over a group's channels (DPP row operations / shuffle
+//        butterflies instead of the reference's shared-memory tree); no atomics.
 //     B  dcnv3_bwd_gin_kernel: grad_input.  The reference scatters 4 taps x K points x C channels of fp32 atomics per output pixel
 //        (36.9 KB/px at C=256: the kernel sat on the chip's 1.3 TB/s float-atomic rate, 2.6 % of the HBM roofline).  Here a
 //        workgroup owns an 8x8 tile of output pixels of ONE group and a window of the input around it (tile + kernel reach + R
@@ -25,8 +26,9 @@
 //        scan, fill), then every (cell, channel) lane sums its cell's list in a register.  The addends are first rounded onto a
 //        power-of-two grid 2^-38 of the tile's largest |grad_output|, so every partial sum is exactly representable: the double sum
 //        is EXACT, hence independent of the (arbitrary) order inside a list.  No float atomics (LDS double atomics measured 35
-//        cycles per wave instruction: 1.7 ms at N32 80x80; this form ... see DESIGN.md).  The window leaves as plain stores into a
-//        staging slab [tile][cell][Gc].
+//        cycles per wave instruction: 1.7 ms at N32 80x80; this form 1.0 ms with 4 channels per lane.  Sorting every list by
+//        tap id - rank of each tap among its list - and summing in fp32 in that fixed order was tried: the rank scans are dependent
+//        short LDS reads, 1.4 ms).  The window leaves as plain stores into a staging slab [tile][cell][Gc].
 //     C  dcnv3_bwd_combine_kernel: every input pixel adds the (at most 2x2) windows that cover it in ascending tile order.
 //     grad_input is therefore run-to-run bit-identical whenever every tap stays within R pixels of the kernel footprint; taps
 //     beyond the window (the reference test's offsets of +-20 pixels) go to grad_input as fp32 atomics like the reference's own.

@@ -141,6 +141,63 @@ __global__ __launch_bounds__(256) void rows_fold_kernel(const float *__restrict_
     o2[(size_t)blockIdx.x * C + c] = b;
 }
 
+// ---- SyncBatchNorm (train.py:165-167 --sync-bn): the same two reductions with the exchange between ranks in the middle.  A rank
+// folds its partial sums to doubles [2][C] + its pixel count; the caller all-gathers those records; every rank then adds the
+// records in rank order (the same order everywhere: identical statistics on every rank, bit for bit) and finishes as above.
+__global__ __launch_bounds__(256) void sums_fold_f64_kernel(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C, long npix,
+                                                            double *__restrict__ sums) {
+    int c;
+    double s1, s2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * (size_t)C] = (double)npix;
+    if (!stage2_sums(p1, p2, nchunk, C, c, s1, s2)) return;
+    sums[c] = s1;
+    sums[(size_t)C + c] = s2;
+}
+__global__ __launch_bounds__(256) void bn_stats_from_sums_kernel(const double *__restrict__ all, int nranks, int C, float eps, float momentum,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ scale,
+                                                                 float *__restrict__ shift, float *running_mean, float *running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const size_t rec = 2 * (size_t)C + 1;
+    double s = 0.0, q = 0.0, cnt = 0.0;
+    for (int r = 0; r < nranks; ++r) { s += all[r * rec + c]; q += all[r * rec + C + c]; cnt += all[r * rec + 2 * (size_t)C]; }
+    const double dm = s / cnt;
+    const double m = (running_mean ? (double)running_mean[c] : 0.0) + dm;
+    double var = q / cnt - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    rstd[c] = rs;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * rs;
+    shift[c] = b - (float)m * g * rs;
+    if (running_mean) {
+        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+// coefficients of the input gradient from the sums of ALL ranks (torch.nn.SyncBatchNorm's backward: the two sums are all-reduced, the
+// parameter gradients stay local and are summed by the gradient exchange like every other parameter)
+__global__ __launch_bounds__(256) void bn_act_bwd_sync_stage2(const double *__restrict__ local, const double *__restrict__ all, int nranks, int C,
+                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                              const float *__restrict__ scale, float *__restrict__ coefA,
+                                                              float *__restrict__ coefB, float *__restrict__ coefC, float *dgamma, float *dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const size_t rec = 2 * (size_t)C + 1;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (int r = 0; r < nranks; ++r) { s1 += all[r * rec + c]; s2 += all[r * rec + C + c]; cnt += all[r * rec + 2 * (size_t)C]; }
+    const double rs = rstd[c], sc = scale[c];
+    const double D = rs * s2;
+    coefA[c] = (float)sc;
+    coefB[c] = (float)(-sc * rs * D / cnt);
+    coefC[c] = (float)(-sc * s1 / cnt);
+    if (dgamma) dgamma[c] += (float)(rs * local[(size_t)C + c]);
+    if (dbeta) dbeta[c] += (float)local[c];
+}
+
 // ------------------------------------------------------------------------------------------------ affine + activation
 // order 0: z = act(x*scale + shift) ; order 1: z = act(x)*scale + shift        (x, z: channel slices; in place allowed)
 __global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__restrict__ x, int x_cs, int x_coff,
@@ -195,9 +252,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float *__restrict
         s2 += d * (w - mu);
     });
 }
-// finalize: per channel coefficients of dv = A*d + Bc*v + Cc, and the parameter gradients (accumulated into dgamma / dbeta)
-//   batch statistics (train):  D = rstd*S2 = sum d*vhat  (S2 = sum d*(v - mean));  A = scale, Bc = -scale*rstd*D/N, Cc = scale*(rstd*D*mean - S1)/N
+// finalize: per channel coefficients of dv = A*d + Bc*(v - mean) + Cc, and the parameter gradients (accumulated into dgamma / dbeta)
+//   batch statistics (train):  D = rstd*S2 = sum d*vhat  (S2 = sum d*(v - mean));  A = scale, Bc = -scale*rstd*D/N, Cc = -scale*S1/N
 //   frozen statistics (eval):  A = scale, Bc = Cc = 0
+// The centred form matters: expanded to Bc*v + (Cc + scale*rstd*D*mean/N) the two terms cancel to |v - mean| / |mean| of their size, and that
+// rounding lands in exactly the property the layers above rely on (sum over pixels of dv == 0): the gradients of parameters that are
+// sums over all pixels (the spatial-attention conv) came out 5-8x noisier than the fp32 CPU path's at 1280x1280.
 __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C,
                                                          long npix, const float *__restrict__ mean, const float *__restrict__ rstd,
                                                          const float *__restrict__ scale, int batch_stats, float *__restrict__ coefA,
@@ -205,12 +265,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict
     int c;
     double s1, s2;
     if (!stage2_sums(p1, p2, nchunk, C, c, s1, s2)) return;
-    const double m = mean[c], rs = rstd[c], sc = scale[c];
+    const double rs = rstd[c], sc = scale[c];
     const double D = rs * s2;
     coefA[c] = (float)sc;
     if (batch_stats) {
         coefB[c] = (float)(-sc * rs * D / (double)npix);
-        coefC[c] = (float)(sc * (rs * D * m - s1) / (double)npix);
+        coefC[c] = (float)(-sc * s1 / (double)npix);
     } else {
         coefB[c] = 0.f;
         coefC[c] = 0.f;
@@ -218,13 +278,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict
     if (dgamma) dgamma[c] += (float)D;
     if (dbeta) dbeta[c] += (float)s1;
 }
-// apply: order 0: dx = A*d + Bc*x + Cc with d = dz*act'(x*scale+shift)
-//        order 1: dx = (A*dz + Bc*act(x) + Cc) * act'(x)
+// apply: order 0: dx = A*d + Bc*(x - mean) + Cc with d = dz*act'(x*scale+shift)
+//        order 1: dx = (A*dz + Bc*(act(x) - mean) + Cc) * act'(x)
 __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
                                                         int x_cs, int x_coff, const float *__restrict__ scale,
-                                                        const float *__restrict__ shift, const float *__restrict__ coefA,
-                                                        const float *__restrict__ coefB, const float *__restrict__ coefC, int act, int order,
-                                                        float *__restrict__ dx, int dx_cs, int dx_coff, long npix, int C) {
+                                                        const float *__restrict__ shift, const float *__restrict__ mean,
+                                                        const float *__restrict__ coefA, const float *__restrict__ coefB,
+                                                        const float *__restrict__ coefC, int act, int order, float *__restrict__ dx, int dx_cs,
+                                                        int dx_coff, long npix, int C) {
     const int C4 = C >> 2;
     const long items = npix * C4;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
@@ -233,15 +294,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float *__restrict_
         const f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
         const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
         const f32x4 A = *reinterpret_cast<const f32x4 *>(coefA + c), Bc = *reinterpret_cast<const f32x4 *>(coefB + c),
-                    Cc = *reinterpret_cast<const f32x4 *>(coefC + c);
+                    Cc = *reinterpret_cast<const f32x4 *>(coefC + c), M = *reinterpret_cast<const f32x4 *>(mean + c);
         f32x4 r;
         if (order == 0) {
             const f32x4 u = v * *reinterpret_cast<const f32x4 *>(scale + c) + *reinterpret_cast<const f32x4 *>(shift + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = A[e] * (g[e] * act_grad(u[e], act)) + Bc[e] * v[e] + Cc[e];
+            for (int e = 0; e < 4; ++e) r[e] = A[e] * (g[e] * act_grad(u[e], act)) + Bc[e] * (v[e] - M[e]) + Cc[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (A[e] * g[e] + Bc[e] * act_fwd(v[e], act) + Cc[e]) * act_grad(v[e], act);
+            for (int e = 0; e < 4; ++e) r[e] = (A[e] * g[e] + Bc[e] * (act_fwd(v[e], act) - M[e]) + Cc[e]) * act_grad(v[e], act);
         }
         *reinterpret_cast<f32x4 *>(dx + p * dx_cs + dx_coff + c) = r;
     }
@@ -349,9 +410,78 @@ extern "C" int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_
                        p1, p2, red_chunk(npix));
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
                        dgamma, dbeta);
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, cA, cB,
-                       cC, act, order, dx, dx_cs, dx_coff, npix, C);
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, cA,
+                       cB, cC, act, order, dx, dx_cs, dx_coff, npix, C);
     return launch_status("somi_bn_act_backward_nhwc_f32");
+}
+
+extern "C" int somi_bn_local_sums_f64(const float *x, int x_cs, int x_coff, long npix, int C, const float *pivot, const float *part_sum,
+                                      const float *part_sumsq, int rows, double *sums, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(npix > 0 && C > 0 && C % 4 == 0 && sums && workspace, SOMI_EINVAL, "bn local sums: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const float *p1, *p2;
+    int nchunk;
+    if (part_sum) {                                              // the partial rows a convolution's epilogue left (taken around `pivot` there)
+        SOMI_REQUIRE(part_sumsq && rows > 0, SOMI_EINVAL, "bn local sums: bad partial rows");
+        p1 = part_sum; p2 = part_sumsq; nchunk = rows;
+        if (rows > 1024) {
+            const int per = cdiv(rows, 1024);
+            nchunk = cdiv(rows, per);
+            float *o1 = workspace, *o2 = workspace + (size_t)1024 * C;
+            hipLaunchKernelGGL(rows_fold_kernel, dim3(nchunk, cdiv(C, 256)), dim3(256), 0, s, part_sum, part_sumsq, rows, C, per, o1, o2);
+            p1 = o1; p2 = o2;
+        }
+    } else {
+        SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C), SOMI_EINVAL, "bn local sums: bad slice");
+        nchunk = somi_red_nchunk(npix);
+        float *o1 = workspace, *o2 = workspace + (size_t)nchunk * C;
+        hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, pivot, o1, o2, red_chunk(npix));
+        p1 = o1; p2 = o2;
+    }
+    hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums);
+    return launch_status("somi_bn_local_sums_f64");
+}
+
+extern "C" int somi_bn_stats_from_sums_f64(const double *all_sums, int nranks, int C, float eps, float momentum, const float *gamma,
+                                           const float *beta, float *mean, float *rstd, float *scale, float *shift, float *running_mean,
+                                           float *running_var, somi_stream_t stream) {
+    SOMI_REQUIRE(all_sums && nranks > 0 && C > 0 && mean && rstd && scale && shift, SOMI_EINVAL, "bn stats from sums: bad arguments");
+    SOMI_REQUIRE(!running_mean == !running_var, SOMI_EINVAL, "bn stats: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, all_sums, nranks, C, eps, momentum, gamma,
+                       beta, mean, rstd, scale, shift, running_mean, running_var);
+    return launch_status("somi_bn_stats_from_sums_f64");
+}
+
+extern "C" int somi_bn_act_backward_sums_f64(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
+                                             const float *scale, const float *shift, int act, int order, long npix, int C, double *sums,
+                                             float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(dz, dz_cs, dz_coff, C) && slice_ok(x, x_cs, x_coff, C) && mean && scale && shift && sums && workspace && npix > 0 &&
+                     C % 4 == 0 && (order == 0 || order == 1), SOMI_EINVAL, "bn act backward sums: bad arguments");
+    const int nchunk = somi_red_nchunk(npix);
+    float *p1 = workspace, *p2 = p1 + (size_t)nchunk * C;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order, npix, C,
+                       p1, p2, red_chunk(npix));
+    hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums);
+    return launch_status("somi_bn_act_backward_sums_f64");
+}
+
+extern "C" int somi_bn_act_backward_apply_sync_f32(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff,
+                                                   const float *mean, const float *rstd, const float *scale, const float *shift, int act,
+                                                   int order, const double *local_sums, const double *all_sums, int nranks, float *dx, int dx_cs,
+                                                   int dx_coff, float *dgamma, float *dbeta, long npix, int C, float *workspace,
+                                                   somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(dz, dz_cs, dz_coff, C) && slice_ok(x, x_cs, x_coff, C) && slice_ok(dx, dx_cs, dx_coff, C) && mean && rstd && scale &&
+                     shift && local_sums && all_sums && nranks > 0 && workspace && npix > 0 && C % 4 == 0 && (order == 0 || order == 1),
+                 SOMI_EINVAL, "bn act backward apply (sync): bad arguments");
+    const size_t cpad = ((size_t)C + 3) / 4 * 4;
+    float *cA = workspace, *cB = cA + cpad, *cC = cB + cpad;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_act_bwd_sync_stage2, dim3(cdiv(C, 256)), dim3(256), 0, s, local_sums, all_sums, nranks, C, mean, rstd, scale, cA, cB, cC,
+                       dgamma, dbeta);
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, cA,
+                       cB, cC, act, order, dx, dx_cs, dx_coff, npix, C);
+    return launch_status("somi_bn_act_backward_apply_sync_f32");
 }
 
 extern "C" int somi_chan_sum_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float *out_accumulate, float *workspace,

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')
 
-ABI_VERSION = 8          # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
+ABI_VERSION = 9          # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
 
@@ -98,6 +98,10 @@ SIGNATURES = {
     'somi_red_nchunk': (I, [C.c_long]),
     'somi_bn_stats_nhwc_f32': (I, [P, I, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
     'somi_bn_stats_partials_f32': (I, [P, P, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
+    'somi_bn_local_sums_f64': (I, [P, I, I, C.c_long, I, P, P, P, I, P, P, S]),
+    'somi_bn_stats_from_sums_f64': (I, [P, I, I, F, F, P, P, P, P, P, P, P, P, S]),
+    'somi_bn_act_backward_sums_f64': (I, [P, I, I, P, I, I, P, P, P, I, I, C.c_long, I, P, P, S]),
+    'somi_bn_act_backward_apply_sync_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, P, P, I, P, I, I, P, P, C.c_long, I, P, S]),
     'somi_chan_affine_act_nhwc_f32': (I, [P, I, I, P, P, I, I, P, I, I, C.c_long, I, P, I, I, S]),
     'somi_bn_act_backward_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, P, I, I, P, P, C.c_long, I, P, S]),
     'somi_add_nhwc_f32': (I, [P, I, I, P, I, I, P, I, I, C.c_long, I, S]),

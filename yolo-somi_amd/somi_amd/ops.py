@@ -476,11 +476,43 @@ def _npix(t):
     return t.shape[0] * t.shape[1] * t.shape[2]
 
 
+# --sync-bn (reference train.py:165-167, torch.nn.SyncBatchNorm): set to the torch.distributed module (train.TrainStep(sync_bn=True) does
+# it around its step) and every BatchNorm statistic below spans the batches of all ranks: one small all-gather per layer and direction.
+SYNC_BN = None
+
+
+def _gather_records(rec):
+    """all-gather of one [2C + 1] double record per rank -> (flat [world * (2C + 1)] tensor, world)."""
+    world = SYNC_BN.get_world_size()
+    out = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
+    SYNC_BN.all_gather_into_tensor(out, rec)
+    return out, world
+
+
+def _bn_stats_sync(x, x_coff, n, c, part, rows, gamma, beta, eps, momentum, running_mean, running_var):
+    L, dev = _lib.lib(), (x if x is not None else part).device
+    mean, rstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
+    rec = torch.empty(2 * c + 1, device=dev, dtype=torch.float64)
+    ws = torch.empty(2 * max(1024, L.somi_red_nchunk(n)) * c, device=dev, dtype=torch.float32)
+    if part is not None:
+        check(L.somi_bn_local_sums_f64(None, 0, 0, n, c, _ptr(running_mean), part[0].data_ptr(), part[1].data_ptr(), rows, _ptr(rec), _ptr(ws),
+                                       _stream()), 'bn_local_sums')
+    else:
+        check(L.somi_bn_local_sums_f64(_ptr(_f32c(x)), x.shape[3], x_coff, n, c, _ptr(running_mean), None, None, 0, _ptr(rec), _ptr(ws),
+                                       _stream()), 'bn_local_sums')
+    allrec, world = _gather_records(rec)
+    check(L.somi_bn_stats_from_sums_f64(_ptr(allrec), world, c, float(eps), float(momentum), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+                                        _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var), _stream()), 'bn_stats_from_sums')
+    return mean, rstd, scale, shift
+
+
 def bn_stats(x, c, x_coff, gamma, beta, eps, momentum, running_mean=None, running_var=None):
     """Batch statistics of a channel slice -> (mean, rstd, scale, shift); optionally updates the running statistics."""
     dev = x.device
-    mean, rstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
     n = _npix(x)
+    if SYNC_BN is not None:
+        return _bn_stats_sync(x, x_coff, n, c, None, 0, gamma, beta, eps, momentum, running_mean, running_var)
+    mean, rstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
     ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c, device=dev, dtype=torch.float32)
     check(_lib.lib().somi_bn_stats_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, n, c, float(eps), float(momentum), _ptr(gamma), _ptr(beta),
                                             _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var),
@@ -492,6 +524,8 @@ def bn_stats_from_partials(part, rows, npix, c, gamma, beta, eps, momentum, runn
     """Batch statistics from the partial sums a convolution's epilogue left (conv2d_nhwc(..., bn_stats={'pivot': running_mean}));
     `running_mean` must be that same pivot.  -> (mean, rstd, scale, shift); updates the running statistics."""
     dev = part.device
+    if SYNC_BN is not None:
+        return _bn_stats_sync(None, 0, npix, c, part, rows, gamma, beta, eps, momentum, running_mean, running_var)
     mean, rstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
     ws = torch.empty(2 * 1024 * c, device=dev, dtype=torch.float32)
     check(_lib.lib().somi_bn_stats_partials_f32(part[0].data_ptr(), part[1].data_ptr(), rows, npix, c, float(eps), float(momentum), _ptr(gamma),
@@ -518,6 +552,18 @@ def pack_dgrad_weights(w_packed, cout, taps, cin):
 def bn_act_backward(dz, dz_coff, x, x_coff, c, mean, rstd, scale, shift, act, order, batch_stats, dx, dx_coff=0, dgamma=None,
                     dbeta=None):
     n = _npix(x)
+    if SYNC_BN is not None and batch_stats:
+        L = _lib.lib()
+        rec = torch.empty(2 * c + 1, device=x.device, dtype=torch.float64)
+        ws = torch.empty(2 * L.somi_red_nchunk(n) * c + 3 * ((c + 3) // 4 * 4), device=x.device, dtype=torch.float32)
+        check(L.somi_bn_act_backward_sums_f64(_ptr(_f32c(dz)), dz.shape[3], dz_coff, _ptr(_f32c(x)), x.shape[3], x_coff, _ptr(mean), _ptr(scale),
+                                              _ptr(shift), ACT[act], order, n, c, _ptr(rec), _ptr(ws), _stream()), 'bn_act_backward_sums')
+        allrec, world = _gather_records(rec)
+        check(L.somi_bn_act_backward_apply_sync_f32(_ptr(dz), dz.shape[3], dz_coff, _ptr(x), x.shape[3], x_coff, _ptr(mean), _ptr(rstd),
+                                                    _ptr(scale), _ptr(shift), ACT[act], order, _ptr(rec), _ptr(allrec), world, _ptr(_f32c(dx)),
+                                                    dx.shape[3], dx_coff, _ptr(dgamma), _ptr(dbeta), n, c, _ptr(ws), _stream()),
+              'bn_act_backward_apply_sync')
+        return dx
     ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c + 3 * ((c + 3) // 4 * 4), device=x.device, dtype=torch.float32)
     check(_lib.lib().somi_bn_act_backward_nhwc_f32(_ptr(_f32c(dz)), dz.shape[3], dz_coff, _ptr(_f32c(x)), x.shape[3], x_coff, _ptr(mean),
                                                    _ptr(rstd), _ptr(scale), _ptr(shift), ACT[act], order, int(batch_stats), _ptr(_f32c(dx)),

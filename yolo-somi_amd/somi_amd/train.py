@@ -47,13 +47,16 @@ def scheduler_step(optimizer, epoch, lf):
 
 
 class TrainStep:
-    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True):
+    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True, sync_bn=False):
         """accumulate: optimizer step every `accumulate` batches (train.py:121,252,272: max(round(nbs / total_batch), 1) in the
-        reference loop; gradients simply keep accumulating in the flat buffers in between).  Default 1: every batch."""
+        reference loop; gradients simply keep accumulating in the flat buffers in between).  Default 1: every batch.
+        sync_bn: --sync-bn (train.py:165-167, SyncBatchNorm.convert_sync_batchnorm): every BatchNorm layer takes its training
+        statistics - forward mean / variance, backward sums - over the batches of all ranks (ops.SYNC_BN)."""
         if not next(model.parameters()).is_cuda:
             raise RuntimeError('TrainStep runs on the MI355X only (no CPU fallback)')
         self.model, self.dist = model, dist
         self.world = dist.get_world_size() if dist is not None else 1
+        self.sync_bn = dist if (sync_bn and dist is not None) else None   # like the reference: only under DDP (RANK != -1)
         model.hyp = hyp
         model.train()
         self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True, adam=adam)
@@ -80,9 +83,14 @@ class TrainStep:
         if self.buckets:
             self.buckets.reset()
             self.buckets.enabled = stepping                       # local accumulation only on the others (DDP's no_sync)
-        pred = self.model(imgs)
-        loss, items = self.compute_loss(pred, targets)
-        loss.backward()                                           # unscaled: the SUM all-reduce supplies the WORLD_SIZE factor
+        from . import ops
+        ops.SYNC_BN = self.sync_bn
+        try:
+            pred = self.model(imgs)
+            loss, items = self.compute_loss(pred, targets)
+            loss.backward()                                       # unscaled: the SUM all-reduce supplies the WORLD_SIZE factor
+        finally:
+            ops.SYNC_BN = None
         if self.buckets and stepping:
             self.buckets.finish()
         self._since_step += 1
