@@ -488,10 +488,14 @@ typedef struct somi_loss_desc {
     float fl_gamma;     /* hyp['fl_gamma']: > 0 wraps both BCE terms in FocalLoss(gamma, alpha 0.25) (utils/loss.py:125-127,35-60) */
     int32_t slide;      /* hyp['slide_ratio'] > 0: SlideLoss around them (:129-131,378-402), weighted by the level's mean IoU */
     float nwd_ratio;    /* 0, or iou_ratio = 0.5 when hyp['nwdloss'] > 0: box term (1-r)(1-CIoU) + r(1-NWD) (:148,162-169) */
+    float nwd_constant; /* 12.8 = wasserstein_loss (utils/metrics.py:341); 2.5 = wasserstein under hyp['shapeloss'] > 0 (:373, its shape
+                         * weights are 1 at the scale1 = 0 the loss calls it with) */
 } somi_loss_desc;
 
 size_t somi_loss_workspace_bytes(const somi_loss_desc *d);
-int somi_yolo_loss_f32(const somi_loss_desc *d, float *out4, void *workspace, size_t workspace_bytes,
+/* out8: 8 device floats = {loss * B, lbox, lobj, lcls, obji[0..3]}; obji[l] = the level's mean objectness BCE before `balance`, the value
+ * ComputeLoss(autobalance=True) updates its balance with after the call (utils/loss.py:197-201; host state, the kernel only reports). */
+int somi_yolo_loss_f32(const somi_loss_desc *d, float *out8, void *workspace, size_t workspace_bytes,
                        somi_stream_t stream);
 
 /* Repulsion loss, RepGT + RepBox (utils/RepulsionLoss.py:47-95; imported by utils/loss.py:8 but never called by ComputeLoss,

@@ -434,6 +434,31 @@ def gen_loss():
             rec[f'p{i}'] = p[i]
             rec[f'g{i}'] = grads[i] if grads[i] is not None else torch.zeros_like(p[i])
         save(f'loss_branch_{tag}', **rec)
+    # ... the shapeloss NWD variant (utils/loss.py:163-164 -> utils/metrics.py:373) and autobalance (:137,197-201: three consecutive calls,
+    # the balance list after each; the first call's weights are scaled so that the objectness means differ between the levels)
+    m.hyp = dict(HYP_VISDRONE, nwdloss=1.0, shapeloss=1.0)
+    crit_b = RefComputeLoss(m)
+    p = [t.clone().requires_grad_(True) for t in p0]
+    loss, items = crit_b(p, targets)
+    grads = torch.autograd.grad(loss, p, allow_unused=True)
+    rec = dict(targets=targets, loss=loss, items=items, anchors=det.anchors, stride=m.stride, hyp_keys=np.array(['nwdloss', 'shapeloss']),
+               hyp_vals=np.array([1.0, 1.0]))
+    for i in range(len(p)):
+        rec[f'p{i}'] = p[i]
+        rec[f'g{i}'] = grads[i] if grads[i] is not None else torch.zeros_like(p[i])
+    save('loss_branch_shapeloss', **rec)
+    m.hyp = dict(HYP_VISDRONE)
+    crit_b = RefComputeLoss(m, autobalance=True)
+    rec = dict(targets=targets, anchors=det.anchors, stride=m.stride, ssi=np.array(crit_b.ssi))
+    for call in range(3):
+        p = [(t * (1.0 + 0.5 * call) + 0.3 * i * call).clone().requires_grad_(True) for i, t in enumerate(p0)]
+        loss, items = crit_b(p, targets)
+        grads = torch.autograd.grad(loss, p, allow_unused=True)
+        rec[f'loss{call}'], rec[f'items{call}'], rec[f'balance{call}'] = loss, items, np.array(crit_b.balance, dtype=np.float64)
+        for i in range(len(p)):
+            rec[f'c{call}_p{i}'] = p[i]
+            rec[f'c{call}_g{i}'] = grads[i] if grads[i] is not None else torch.zeros_like(p[i])
+    save('loss_autobalance', **rec)
     m.hyp = dict(HYP_VISDRONE)
     # bbox_iou CIoU (utils/metrics.py:476-518)
     g = torch.Generator().manual_seed(350)

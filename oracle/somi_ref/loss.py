@@ -53,8 +53,11 @@ class ComputeLoss:
         h = model.hyp
         det = model.model[-1]
         self.hyp = h
-        if autobalance or (h['nwdloss'] > 0 and h.get('shapeloss', 0) > 0):
-            raise NotImplementedError('autobalance / the shapeloss NWD variant are not restated')
+        self.autobalance = autobalance
+        self.ssi = list(det.stride).index(16) if autobalance else 0                        # :137
+        # hyp['shapeloss'] > 0 swaps wasserstein_loss for wasserstein (utils/metrics.py:373-397, :163-164): called with its default
+        # scale1 = 0 the shape weights ww, hh are 2 * x^0 / (x^0 + y^0) = 1, so the only difference left is the constant, 2.5 for 12.8
+        self.nwd_constant = 2.5 if h.get('shapeloss', 0) > 0 else 12.8
         self.fl_gamma, self.slide, self.nwd = float(h['fl_gamma']), h['slide_ratio'] > 0, h['nwdloss'] > 0
         self.cls_pw, self.obj_pw = float(h['cls_pw']), float(h['obj_pw'])
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
@@ -107,7 +110,7 @@ class ComputeLoss:
                 pbox = torch.cat((pxy, pwh), 1)
                 iou = bbox_ciou_xywh(pbox.T, tbox[i])
                 if self.nwd:                                                               # :162-169, iou_ratio = 0.5 (:148)
-                    nwd = self._wasserstein(pbox, tbox[i]).squeeze()
+                    nwd = self._wasserstein(pbox, tbox[i], constant=self.nwd_constant).squeeze()
                     lbox = lbox + 0.5 * (1.0 - iou).mean() + 0.5 * (1.0 - nwd).mean()
                     iou = (iou.detach() * 0.5 + nwd.detach() * 0.5).clamp(0, 1).type(tobj.dtype)
                 else:
@@ -121,7 +124,12 @@ class ComputeLoss:
                     t = torch.full_like(ps[:, 5:], self.cn)
                     t[range(n), tcls[i]] = self.cp
                     lcls = lcls + self._bce(ps[:, 5:], t, self.cls_pw, auto_iou)
-            lobj = lobj + self._bce(pi[..., 4], tobj, self.obj_pw, auto_iou if n else None) * self.balance[i]
+            obji = self._bce(pi[..., 4], tobj, self.obj_pw, auto_iou if n else None)
+            lobj = lobj + obji * self.balance[i]
+            if self.autobalance:                                                           # :197-198
+                self.balance[i] = self.balance[i] * 0.9999 + 0.0001 / obji.detach().item()
+        if self.autobalance:                                                               # :200-201
+            self.balance = [x / self.balance[self.ssi] for x in self.balance]
         lbox = lbox * self.hyp['box']
         lobj = lobj * self.hyp['obj']
         lcls = lcls * self.hyp['cls']

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from somi_amd._lib import ConvDesc, LossDesc
     assert ctypes.sizeof(ConvDesc) == 9 * 8 + 22 * 4 + 8 + 8 + 8 + 3 * 8
-    assert ctypes.sizeof(LossDesc) == 4 * 8 + 4 * 8 + 4 * 4 + 4 * 4 + 5 * 4 + 4 + 2 * 8 + 4 * 4 + 12 * 4
+    assert ctypes.sizeof(LossDesc) == 4 * 8 + 4 * 8 + 4 * 4 + 4 * 4 + 5 * 4 + 4 + 2 * 8 + 4 * 4 + 13 * 4 + 4
 
 
 @pytest.mark.parametrize('width,depth,anchors', [(0.25, 0.33, 4), (1.0, 1.0, 'visdrone')])

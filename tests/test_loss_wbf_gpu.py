@@ -42,7 +42,7 @@ def test_compute_loss_matches_reference_vectors(golden, tag):
     rel_close(l2, g['loss'], rel=1e-4, what='loss (no grad)')
 
 
-@pytest.mark.parametrize('tag', ['focal', 'slide', 'focal_slide', 'nwd', 'all'])
+@pytest.mark.parametrize('tag', ['focal', 'slide', 'focal_slide', 'nwd', 'all', 'shapeloss'])
 def test_compute_loss_branches_match_reference_vectors(golden, tag):
     """FocalLoss / SlideLoss / both stacked / the NWD box term / everything with label smoothing (utils/loss.py:35-60,125-131,162-169,
     378-402; hyp.VisDrone.yaml leaves them off): loss, items and gradients against the reference's own ComputeLoss under those
@@ -64,13 +64,25 @@ def test_compute_loss_branches_match_reference_vectors(golden, tag):
     rel_close(l2, g['loss'], rel=1e-4, what=f'{tag}: loss (no grad)')
 
 
-def test_compute_loss_rejects_what_is_not_restated():
+def test_compute_loss_autobalance_matches_reference_vectors(golden):
+    """ComputeLoss(autobalance=True) (utils/loss.py:137,197-201): three consecutive calls against the reference's own - loss, items,
+    gradients and the balance list each call leaves behind (the kernel reports the per-level objectness means, the list is host state)."""
     from somi_amd.configs import HYP_VISDRONE
     from somi_amd.loss import ComputeLoss
-    with pytest.raises(NotImplementedError):
-        ComputeLoss(_M(torch.ones(4, 4, 2), dict(HYP_VISDRONE, nwdloss=1.0, shapeloss=1.0)))
-    with pytest.raises(NotImplementedError):
-        ComputeLoss(_M(torch.ones(4, 4, 2), dict(HYP_VISDRONE)), autobalance=True)
+    g = golden('loss_autobalance')
+    mdl = _M(T(g['anchors']), dict(HYP_VISDRONE))
+    mdl.model[0].stride = T(g['stride'])
+    crit = ComputeLoss(mdl, autobalance=True)
+    assert crit.ssi == int(g['ssi'])
+    for call in range(3):
+        p = [T(g[f'c{call}_p{i}']).cuda().requires_grad_(True) for i in range(4)]
+        loss, items = crit(p, T(g['targets']).cuda())
+        rel_close(loss, g[f'loss{call}'], rel=1e-4, what=f'call {call}: loss')
+        rel_close(items, g[f'items{call}'], rel=1e-4, what=f'call {call}: loss_items')
+        np.testing.assert_allclose(np.array(crit.balance), g[f'balance{call}'], rtol=1e-5, err_msg=f'balance after call {call}')
+        loss.backward()
+        for i in range(4):
+            rel_close(p[i].grad, g[f'c{call}_g{i}'], rel=1e-3, what=f'call {call}: d loss / d p[{i}]')
 
 
 def _wbf_inputs(seed, nm=2, n=120):

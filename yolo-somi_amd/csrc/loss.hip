@@ -21,7 +21,7 @@
 // The branches hyp.VisDrone.yaml leaves off are here too: FocalLoss (utils/loss.py:35-60) and SlideLoss (:378-402) as per-element
 // weights of both BCE terms (stacked like :125-131), the NWD box term (:162-169, utils/metrics.py:341-354) blended into the box loss,
 // its gradient and the objectness target.  SlideLoss needs the level's mean IoU before any BCE can be weighted, so the class BCE of
-// the matched entries is evaluated in pass 1b (after a one-workgroup-per-level mean, 1a).  autobalance is rejected by the host layer.
+// the matched entries is evaluated in pass 1b (after a one-workgroup-per-level mean, 1a).  autobalance is host state: the per-level objectness means it feeds on leave in out[4..7].
 #include "common.h"
 
 namespace somi {
@@ -29,7 +29,7 @@ namespace somi {
 constexpr float CIOU_EPS = 1e-7f;
 constexpr int NOFF = 5;
 constexpr int SLOT = 3;
-constexpr float NWD_EPS = 1e-7f, NWD_CONSTANT = 12.8f, FOCAL_ALPHA = 0.25f;
+constexpr float NWD_EPS = 1e-7f, FOCAL_ALPHA = 0.25f;
 
 struct LossArgs {
     somi_loss_desc d;
@@ -73,14 +73,14 @@ __device__ __forceinline__ Dual dexp(Dual a) { Dual r; r.v = expf(a.v); for (int
 
 // wasserstein_loss (utils/metrics.py:341-354): written for x1y1x2y2 boxes but fed (x, y, w, h) by ComputeLoss (utils/loss.py:166) - the
 // columns are used exactly as the reference uses them
-__device__ __forceinline__ Dual nwd_xywh(Dual px, Dual py, Dual pw, Dual ph, float tx, float ty, float tw, float th) {
+__device__ __forceinline__ Dual nwd_xywh(Dual px, Dual py, Dual pw, Dual ph, float tx, float ty, float tw, float th, float constant) {
     const Dual w1 = pw - px, h1 = (ph - py) + NWD_EPS;
     const float w2 = tw - tx, h2 = (th - ty) + NWD_EPS;
     const Dual dcx = (px + pw) * 0.5f + (-(tx + tw) / 2), dcy = (py + ph) * 0.5f + (-(ty + th) / 2);
     const Dual cd = (dcx * dcx + dcy * dcy) + NWD_EPS;
     const Dual dw = w1 + (-w2), dh = h1 + (-h2);
     const Dual whd = (dw * dw + dh * dh) * 0.25f;
-    return dexp(dsqrt(cd + whd) * (-1.f / NWD_CONSTANT));
+    return dexp(dsqrt(cd + whd) * (-1.f / constant));
 }
 
 // CIoU of predicted (px,py,pw,ph) vs target (tx,ty,tw,th), xywh (utils/metrics.py:476-518 with alpha=1)
@@ -190,7 +190,7 @@ __device__ __forceinline__ Entry eval_entry(const somi_loss_desc &d, int no, con
     const float pwv = (e.s2 * 2.f) * (e.s2 * 2.f) * r.aw, phv = (e.s3 * 2.f) * (e.s3 * 2.f) * r.ah;
     e.c = ciou_xywh(dvar(pxv, 0), dvar(pyv, 1), dvar(pwv, 2), dvar(phv, 3), tbx, tby, r.gw, r.gh);
     if (d.nwd_ratio > 0.f) {                                                              // utils/loss.py:162-169
-        const Dual w = nwd_xywh(dvar(pxv, 0), dvar(pyv, 1), dvar(pwv, 2), dvar(phv, 3), tbx, tby, r.gw, r.gh);
+        const Dual w = nwd_xywh(dvar(pxv, 0), dvar(pyv, 1), dvar(pwv, 2), dvar(phv, 3), tbx, tby, r.gw, r.gh, d.nwd_constant);
         e.c = e.c * (1.f - d.nwd_ratio) + w * d.nwd_ratio;
     }
     e.iou01 = fminf(fmaxf(e.c.v, 0.f), 1.f);
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const LossArgs a, floa
             if (d.nc > 1) lcls += vals[1] / ((double)n * d.nc);
         }
         lobj += vals[2] / (double)a.cells[l] * d.balance[l];
+        if (threadIdx.x == 0) out4[4 + l] = (float)(vals[2] / (double)a.cells[l]);   // obji of the level: what autobalance feeds on
     }
     if (threadIdx.x == 0) {
         const float fb = (float)lbox * d.box_gain, fo = (float)lobj * d.obj_gain, fc = (float)lcls * d.cls_gain;
@@ -454,7 +455,8 @@ extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *w
     if (any_grad && d.nt > 0) (void)hipMemsetAsync(a.head, 0xFF, tobj_b, s);   // -1: empty lists
     for (int l = 0; l < d.nl; ++l)
         if (d.grad[l]) (void)hipMemsetAsync(d.grad[l], 0, (size_t)a.cells[l] * a.no * 4, s);
-    SOMI_REQUIRE(d.fl_gamma >= 0.f && d.nwd_ratio >= 0.f && d.nwd_ratio <= 1.f, SOMI_EINVAL, "loss: bad focal gamma / NWD ratio");
+    SOMI_REQUIRE(d.fl_gamma >= 0.f && d.nwd_ratio >= 0.f && d.nwd_ratio <= 1.f && (d.nwd_ratio == 0.f || d.nwd_constant > 0.f), SOMI_EINVAL,
+                 "loss: bad focal gamma / NWD ratio / NWD constant");
     if (d.nt > 0) {
         hipLaunchKernelGGL(loss_match_kernel, dim3(cdiv((long)d.na * d.nt, 256), d.nl), dim3(256), 0, s, a);
         if (d.slide) hipLaunchKernelGGL(loss_level_mean_kernel, dim3(d.nl), dim3(256), 0, s, a);

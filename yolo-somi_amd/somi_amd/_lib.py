@@ -33,7 +33,7 @@ class LossDesc(C.Structure):
                 ('targets', C.c_void_p), ('anchors', C.c_void_p), ('balance', C.c_float * 4),
                 ('box_gain', C.c_float), ('obj_gain', C.c_float), ('cls_gain', C.c_float), ('cls_pw', C.c_float),
                 ('obj_pw', C.c_float), ('anchor_t', C.c_float), ('cp', C.c_float), ('cn', C.c_float), ('gr', C.c_float),
-                ('fl_gamma', C.c_float), ('slide', C.c_int32), ('nwd_ratio', C.c_float)]
+                ('fl_gamma', C.c_float), ('slide', C.c_int32), ('nwd_ratio', C.c_float), ('nwd_constant', C.c_float)]
 
 
 class AugSource(C.Structure):

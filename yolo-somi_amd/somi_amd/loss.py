@@ -4,7 +4,8 @@
 outputs, targets (nt,6) = [image, class, x, y, w, h] normalised.  The loss value and d loss / d p come out of the same
 fused launches; autograd sees one node.  hyp keys read: cls_pw, obj_pw, fl_gamma, slide_ratio, nwdloss, shapeloss, box, obj, cls,
 anchor_t (+label_smoothing) - the ones the reference's __init__ / __call__ read.  FocalLoss (fl_gamma > 0), SlideLoss (slide_ratio > 0)
-and the NWD box term (nwdloss > 0) run inside the same kernels; autobalance and the shapeloss NWD variant raise NotImplementedError.
+and the NWD box term (nwdloss > 0; constant 12.8, or 2.5 under shapeloss > 0) run inside the same kernels; autobalance is host state
+(the balance list, updated from the per-level objectness means the launch reports) as in the reference.
 """
 import ctypes as C
 
@@ -37,12 +38,11 @@ class ComputeLoss:
     def __init__(self, model, autobalance=False):
         self.sort_obj_iou = False
         h = model.hyp
-        if autobalance or (h['nwdloss'] > 0 and h.get('shapeloss', 0) > 0):
-            raise NotImplementedError('autobalance and the shapeloss NWD variant (utils/metrics.py:373) are not on the HIP path')
         det = model.model[-1]
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
         self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, 0.02])       # utils/loss.py:135
         self.gr, self.hyp, self.autobalance = 1.0, h, autobalance
+        self.ssi = list(det.stride).index(16) if autobalance else 0                           # stride 16 index (:137)
         self.na, self.nc, self.nl, self.anchors = det.na, det.nc, det.nl, det.anchors
         if self.nl > 4:
             raise NotImplementedError('at most 4 detection levels')
@@ -76,12 +76,17 @@ class ComputeLoss:
         d.cp, d.cn, d.gr = float(self.cp), float(self.cn), float(self.gr)
         d.fl_gamma, d.slide = float(h['fl_gamma']), int(h['slide_ratio'] > 0)
         d.nwd_ratio = 0.5 if h['nwdloss'] > 0 else 0.0           # iou_ratio, utils/loss.py:148
+        d.nwd_constant = 2.5 if h.get('shapeloss', 0) > 0 else 12.8   # wasserstein (utils/metrics.py:373) / wasserstein_loss (:341), :163-166
         L = _lib.lib()
         nbytes = L.somi_loss_workspace_bytes(C.byref(d))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        out = torch.empty(4, dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
         check(L.somi_yolo_loss_f32(C.byref(d), _ptr(out), _ptr(ws), nbytes, _stream()), 'ComputeLoss')
-        return out, grads
+        if self.autobalance:                                      # utils/loss.py:197-201 (a host sync per call, like the reference's .item())
+            obji = out[4:4 + len(p)].tolist()
+            bal = [self.balance[i] * 0.9999 + 0.0001 / obji[i] for i in range(len(p))] + list(self.balance[len(p):])
+            self.balance = [x / bal[self.ssi] for x in bal]
+        return out[:4], grads
 
     def __call__(self, p, targets):
         if len(p) != self.nl:
