@@ -153,6 +153,27 @@ def pmc_traffic(kernel_name):
     return None
 
 
+# the kernels behind the two DCNv3 operator entries that ops.PROFILE times (forward = one launch; backward = A + B + C of the windowed form)
+DCN_OP_KERNELS = {'dcnv3_fwd_kernel': (r'dcnv3_win_kernel<\d+,0>|dcnv3_fwd_kernel',),
+                  'dcnv3_bwd_kernel': (r'dcnv3_win_kernel<\d+,1>|dcnv3_bwd_om_kernel', r'dcnv3_bwd_gin_kernel', r'dcnv3_bwd_combine_kernel')}
+
+
+def pmc_traffic_op(op):
+    """Sum of pmc_traffic over the kernels of one DCNv3 operator call (None when the committed profile lacks one of them)."""
+    import re
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(path) or op not in DCN_OP_KERNELS:
+        return None
+    kern = {k.replace(' ', ''): v['hbm_bytes_per_launch'] for k, v in json.load(open(path)).get('kernels', {}).items()}
+    total = 0
+    for pat in DCN_OP_KERNELS[op]:
+        hit = [v for k, v in kern.items() if re.search(pat, k)]
+        if not hit:
+            return None
+        total += hit[0]
+    return total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -303,7 +324,7 @@ def main():
             for k, (c_, b_, s_) in sorted(dcn.items()):
                 kernels[k] = {'launches': c_, 'avg_launch_us': round(s_ / c_ * 1e6, 2), 'avg_launch_MB': round(b_ / c_ / 1e6, 1),
                               'achieved_GBps': round(b_ / s_ / 1e9, 1), 'frac': round(b_ / s_ / 1e9 / HBM_PEAK_GBPS, 4),
-                              'traffic': pmc_traffic(k)}
+                              'traffic': pmc_traffic_op(k)}
             tb, ts = sum(v[1] for v in dcn.values()), sum(v[2] for v in dcn.values())
             out['roofline_dcnv3'] = {'bound': 'hbm', 'achieved': round(tb / ts / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                      'frac': round(tb / ts / 1e9 / HBM_PEAK_GBPS, 4), 'share_of_step': round(ts / dt, 4), 'kernels': kernels,
