@@ -318,13 +318,15 @@ def main():
                          'all_conv_tflops': round(all_flops / all_secs / 1e12, 2),
                          'conv_share_of_step': round(all_secs / dt, 3)},
         }
-        out['roofline']['traffic'] = pmc_traffic(name)
+        # the committed counter passes are of the DEFAULT command (DCN graph, training, batch 32, 640): null for any other workload
+        profiled = args.model == 'somi-dcn' and args.mode == 'train' and args.batch == 32 and args.size == 640
+        out['roofline']['traffic'] = pmc_traffic(name) if profiled else None
         if dcn:                                                  # the DCNv3 operator kernels of the step against the HBM roofline
             kernels = {}
             for k, (c_, b_, s_) in sorted(dcn.items()):
                 kernels[k] = {'launches': c_, 'avg_launch_us': round(s_ / c_ * 1e6, 2), 'avg_launch_MB': round(b_ / c_ / 1e6, 1),
                               'achieved_GBps': round(b_ / s_ / 1e9, 1), 'frac': round(b_ / s_ / 1e9 / HBM_PEAK_GBPS, 4),
-                              'traffic': pmc_traffic_op(k)}
+                              'traffic': pmc_traffic_op(k) if profiled else None}
             tb, ts = sum(v[1] for v in dcn.values()), sum(v[2] for v in dcn.values())
             out['roofline_dcnv3'] = {'bound': 'hbm', 'achieved': round(tb / ts / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                      'frac': round(tb / ts / 1e9 / HBM_PEAK_GBPS, 4), 'share_of_step': round(ts / dt, 4), 'kernels': kernels,
