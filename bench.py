@@ -40,12 +40,13 @@ XGMI_LINKS, XGMI_LINK_GBPS = 7, 153  # per GPU: 7 point-to-point xGMI links of ~
 MODELS = {'somi-dcn': 'yolov5l-SOMI (DCNv3 blocks)', 'somi': 'yolov5l-SOMI', 'yolov5s': 'yolov5s'}
 
 
-def model_cfg(name):
-    """-> (layer table, number of classes).  somi: models/modules/YOLO-SOMI.yaml (C2fEACBAM -> C2fCBAM) with the yaml's 16 anchor pairs."""
+def model_cfg(name, nc=None):
+    """-> (layer table, number of classes).  somi: models/modules/YOLO-SOMI.yaml (C2fEACBAM -> C2fCBAM) with the yaml's 16 anchor pairs.
+    nc: 10 (VisDrone) unless given - 3 for the UAVDT shape of BASELINE configs[3] (`--size 1280 --batch 8 --nc 3` is its per-GPU share)."""
     from somi_amd.configs import somi_cfg, yolov5_cfg, SOMI_ANCHORS
     if name == 'yolov5s':
-        return yolov5_cfg(), 80
-    return somi_cfg(1.0, 1.0, nc=10, anchors=SOMI_ANCHORS, dcn=(name == 'somi-dcn')), 10
+        return yolov5_cfg(nc=nc or 80), nc or 80
+    return somi_cfg(1.0, 1.0, nc=nc or 10, anchors=SOMI_ANCHORS, dcn=(name == 'somi-dcn')), nc or 10
 
 
 def synthetic_images(batch, size, seed, device):
@@ -181,6 +182,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 32: BASELINE configs[1]; 2 for yolov5s)')
     ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--nc', type=int, default=None, help='classes (default 10, yolov5s 80; 3 = UAVDT, BASELINE configs[3])')
     ap.add_argument('--model', choices=list(MODELS), default='somi-dcn')
     ap.add_argument('--no-dcn', action='store_true', help='same as --model somi')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -225,7 +227,7 @@ def main():
     from somi_amd.nms import non_max_suppression
 
     torch.manual_seed(0)
-    cfg, nc = model_cfg(args.model)
+    cfg, nc = model_cfg(args.model, args.nc)
     model = Model(cfg)
     nparams = sum(p.numel() for p in model.parameters())
     from somi_amd.configs import fill_state
