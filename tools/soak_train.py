@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Soak run of the full-size training step on synthetic data: loss trend, finite checks, steady memory.  usage: soak_train.py [steps]"""
+"""Soak run of the full-size training step on synthetic data: loss trend, finite checks, steady memory.
+usage: soak_train.py [steps] [dcn]   (dcn: the bench graph with its two DCNv3 sites; reports the taps that left the backward's windows)"""
 import json
 import os
 import sys
@@ -14,8 +15,9 @@ from somi_amd.model import Model  # noqa: E402
 from somi_amd.train import TrainStep, one_cycle, warmup_lr  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+dcn = len(sys.argv) > 2 and sys.argv[2] == 'dcn'
 dev = torch.device('cuda')
-model = fill_state(Model(somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS)), 1).to(dev)
+model = fill_state(Model(somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS, dcn=dcn)), 1).to(dev)
 hyp = dict(HYP_VISDRONE)
 tr = TrainStep(model, hyp, 32)
 lf = one_cycle(1, hyp['lrf'], 300)
@@ -32,4 +34,9 @@ for it in range(steps):
         assert torch.isfinite(loss).all(), log[-1]
 torch.cuda.synchronize()
 finite = all(bool(torch.isfinite(b).all()) for b in tr.optimizer.flat_params)
-print(json.dumps({'steps': steps, 'seconds': round(time.time() - t0, 1), 'weights_finite': finite, 'log': log}))
+out = {'steps': steps, 'seconds': round(time.time() - t0, 1), 'weights_finite': finite, 'log': log}
+if dcn:
+    from somi_amd import ops
+    out['dcn_graph'] = True
+    out['taps_outside_window_last_backward'] = ops.dcn_overflow_taps()
+print(json.dumps(out))
