@@ -441,3 +441,43 @@ def test_dcnv3_backward_windowed_form(N, H, W, G, Gc, k, s, p, d, osc, spread):
         ops.DCN_DIRECT = False
     for got, ref, what in zip(c, want, ('grad_input', 'grad_offset', 'grad_mask')):
         rel_close(got, ref, rel=1e-4, what=f'direct {what}')
+
+
+def test_dcnv3_full_size_properties():
+    """The operator at the bench graph's full site shape (N32, 80x80, C256, G8, K9 - too large for the CPU oracle in a test) through
+    properties that do not depend on the size: the forward is LINEAR in its input, the LDS-window form equals the tiled form and the
+    windowed backward the direct (fp32-atomic) one, and grad_input is the ADJOINT of the forward: <go, f(x)> == <grad_input(go), x>."""
+    import os
+    from somi_amd import ops
+    from somi_amd.dcnv3 import dcnv3_backward, dcnv3_forward
+    d = torch.device('cuda:0')
+    g = torch.Generator(device='cuda').manual_seed(5)
+    N, H, C, G, k = 32, 80, 256, 8, 3
+    K = k * k
+    x1, x2 = (torch.randn(N, H, H, C, device=d, generator=g) for _ in range(2))
+    off = torch.randn(N, H, H, G * K * 2, device=d, generator=g) * 0.7
+    m = torch.softmax(torch.randn(N, H, H, G, K, device=d, generator=g), -1).reshape(N, H, H, G * K).contiguous()
+    go = torch.randn(N, H, H, C, device=d, generator=g)
+    cfg = (k, k, 1, 1, 1, 1, 1, 1, G, C // G, 1.0)
+    f1, f2 = dcnv3_forward(x1, off, m, *cfg, 256), dcnv3_forward(x2, off, m, *cfg, 256)
+    f12 = dcnv3_forward(0.5 * x1 - 2.0 * x2, off, m, *cfg, 256)
+    rel_close(f12, 0.5 * f1 - 2.0 * f2, rel=1e-5, what='linearity of the forward in its input')
+    gi, gof, gm = dcnv3_backward(x1, off, m, *cfg, go, 256)
+    assert ops.dcn_overflow_taps() is not None, 'the windowed backward did not run'
+    lhs, rhs = (go.double() * f1.double()).sum().item(), (gi.double() * x1.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * (go.double() * f1.double()).abs().sum().item(), (lhs, rhs)
+    # mask gradient: f is linear in the mask too, <go, f> == <grad_mask, mask>
+    rhs_m = (gm.double() * m.double()).sum().item()
+    assert abs(lhs - rhs_m) <= 1e-5 * (go.double() * f1.double()).abs().sum().item(), (lhs, rhs_m)
+    os.environ['SOMI_DCN_DIRECT'] = '1'                           # the library reads it per call: tiled gathers from L2 ...
+    ops.DCN_DIRECT = True                                         # ... and the one-kernel backward with fp32 atomics
+    try:
+        f1_t = dcnv3_forward(x1, off, m, *cfg, 256)
+        gi_t, gof_t, gm_t = dcnv3_backward(x1, off, m, *cfg, go, 256)
+    finally:
+        os.environ['SOMI_DCN_DIRECT'] = '0'
+        ops.DCN_DIRECT = False
+    rel_close(f1, f1_t, rel=1e-5, what='LDS-window forward vs tiled forward')
+    rel_close(gi, gi_t, rel=2e-5, what='windowed vs direct grad_input')
+    rel_close(gof, gof_t, rel=2e-5, what='windowed vs direct grad_offset')
+    rel_close(gm, gm_t, rel=2e-5, what='windowed vs direct grad_mask')
