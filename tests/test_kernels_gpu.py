@@ -435,3 +435,32 @@ def test_conv_forward_dgrad_wgrad_random_shapes(case):
     rel_close(gx, nhwc(x.grad), what='dgrad')
     gw = ops.conv2d_wgrad_nhwc(nhwc(x.detach()).to(d), nhwc(dy).to(d), kh=k, kw=k, stride=s, pad=p)
     rel_close(gw, pack_conv_weight(w.grad, cin_pad=Cin), what='wgrad')
+
+
+@pytest.mark.parametrize('B,H,Cin,Cout,k,s', [(32, 160, 128, 128, 3, 1), (32, 80, 256, 256, 3, 1), (32, 160, 256, 256, 1, 1),
+                                              (32, 160, 256, 256, 3, 2)])
+def test_conv_full_size_adjoint_identities(B, H, Cin, Cout, k, s):
+    """The three conv kernels at the bench step's dominant layer shapes (batch 32: far beyond what a CPU reference finishes in a test)
+    through identities that do not depend on the size: y = conv(x, w) is bilinear, so for random dy
+        <dy, conv(x, w)> == <dgrad(dy, w), x> == <wgrad(x, dy), w>,
+    and conv is linear in x.  Sums in float64 on the device."""
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator(device='cuda').manual_seed(B + H + Cin + k)
+    p = k // 2
+    x = torch.randn(B, H, H, Cin, device=d, generator=g)
+    x2 = torch.randn(B, H, H, Cin, device=d, generator=g)
+    w = torch.randn(Cout, k * k * Cin, device=d, generator=g) / math.sqrt(Cin * k * k)
+    y = ops.conv2d_nhwc(x, w, None, kh=k, kw=k, stride=s, pad=p)
+    dy = torch.randn(y.shape, device=d, generator=g)
+    dx = ops.conv2d_dgrad_nhwc(dy, ops.pack_dgrad_weights(w, Cout, k * k, Cin), B=B, H=H, W=H, cin=Cin, kh=k, kw=k, stride=s, pad=p)
+    dw = ops.conv2d_wgrad_nhwc(x, dy, kh=k, kw=k, stride=s, pad=p)
+    dot = lambda a, b: (a.double() * b.double()).sum().item()      # noqa: E731
+    ref = dot(dy, y)
+    size = (dy.double() * y.double()).abs().sum().item()
+    assert abs(dot(dx, x) - ref) <= 1e-5 * size, ('dgrad adjoint', dot(dx, x), ref)
+    assert abs(dot(dw.view_as(w), w) - ref) <= 1e-5 * size, ('wgrad adjoint', dot(dw.view_as(w), w), ref)
+    y12 = ops.conv2d_nhwc(0.5 * x - 2.0 * x2, w, None, kh=k, kw=k, stride=s, pad=p)
+    y2 = ops.conv2d_nhwc(x2, w, None, kh=k, kw=k, stride=s, pad=p)
+    err = (y12 - (0.5 * y - 2.0 * y2)).abs().max().item()
+    assert err <= 2e-5 * y.abs().max().item(), ('linearity', err)
