@@ -193,3 +193,38 @@ def test_compute_loss_random_against_oracle(B, nc, nl, na, nt, S, ls):
     for i in range(nl):
         gr, gm = pr[i].grad, pm[i].grad.cpu()
         assert (gm - gr).abs().max().item() <= 1e-3 * gr.abs().max().item() + 1e-9, f'd loss / d p[{i}]'
+
+
+def test_compute_loss_full_size_by_replication():
+    """ComputeLoss at the bench step's size (batch 32, 640x640: grids 160 / 80 / 40 / 20, 4 anchors, 10 classes, ~2000 targets) tied to
+    the CPU oracle through a size-independent property: a batch made of 16 copies of a 2-image batch has the same per-term means, so
+    loss items(32) == items(2), total(32) == 16 x total(2), and every copy's gradient equals the 2-image gradient - and the 2-image
+    case is checked against the oracle directly."""
+    from oracle.somi_ref.loss import ComputeLoss as OLoss
+    from somi_amd.configs import HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    g = torch.Generator().manual_seed(77)
+    nc, na, S, rep = 10, 4, 640, 16
+    anchors = torch.rand(4, na, 2, generator=g) * 6 + 0.5
+    p2 = [torch.randn(2, na, S // s_, S // s_, nc + 5, generator=g) for s_ in (4, 8, 16, 32)]
+    nt = 130
+    tg = torch.zeros(nt, 6)
+    tg[:, 0] = torch.randint(0, 2, (nt,), generator=g).float()
+    tg[:, 1] = torch.randint(0, nc, (nt,), generator=g).float()
+    tg[:, 2:4] = torch.rand(nt, 2, generator=g) * 0.98 + 0.01
+    tg[:, 4:6] = torch.exp(torch.randn(nt, 2, generator=g) * 0.7 - 3.0).clamp(0.005, 0.4)
+    hyp = dict(HYP_VISDRONE)
+    pr = [t.clone().requires_grad_(True) for t in p2]
+    want, want_items = OLoss(_M(anchors, hyp, nc))(pr, tg)
+    want.backward()
+    p32 = [t.repeat(rep, 1, 1, 1, 1).cuda().requires_grad_(True) for t in p2]
+    tg32 = torch.cat([torch.cat([tg[:, :1] + 2 * r, tg[:, 1:]], 1) for r in range(rep)])
+    got, items = ComputeLoss(_M(anchors, hyp, nc))(p32, tg32.cuda())
+    rel_close(items, want_items, rel=1e-4, what='loss items of the replicated batch')
+    rel_close(got, want.detach() * rep, rel=1e-4, what='total loss of the replicated batch')
+    got.backward()
+    for i in range(4):
+        gm, gr = p32[i].grad.cpu(), pr[i].grad
+        scale = gr.abs().max().item()
+        for r in (0, 7, 15):
+            assert (gm[2 * r:2 * r + 2] - gr).abs().max().item() <= 1e-3 * scale + 1e-9, f'd loss / d p[{i}], copy {r}'
