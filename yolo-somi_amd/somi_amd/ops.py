@@ -554,14 +554,15 @@ def bn_act_backward(dz, dz_coff, x, x_coff, c, mean, rstd, scale, shift, act, or
     n = _npix(x)
     if SYNC_BN is not None and batch_stats:
         L = _lib.lib()
+        dzc, xc, dxc = _f32c(dz), _f32c(x), _f32c(dx)
         rec = torch.empty(2 * c + 1, device=x.device, dtype=torch.float64)
         ws = torch.empty(2 * L.somi_red_nchunk(n) * c + 3 * ((c + 3) // 4 * 4), device=x.device, dtype=torch.float32)
-        check(L.somi_bn_act_backward_sums_f64(_ptr(_f32c(dz)), dz.shape[3], dz_coff, _ptr(_f32c(x)), x.shape[3], x_coff, _ptr(mean), _ptr(scale),
+        check(L.somi_bn_act_backward_sums_f64(_ptr(dzc), dzc.shape[3], dz_coff, _ptr(xc), xc.shape[3], x_coff, _ptr(mean), _ptr(scale),
                                               _ptr(shift), ACT[act], order, n, c, _ptr(rec), _ptr(ws), _stream()), 'bn_act_backward_sums')
         allrec, world = _gather_records(rec)
-        check(L.somi_bn_act_backward_apply_sync_f32(_ptr(dz), dz.shape[3], dz_coff, _ptr(x), x.shape[3], x_coff, _ptr(mean), _ptr(rstd),
-                                                    _ptr(scale), _ptr(shift), ACT[act], order, _ptr(rec), _ptr(allrec), world, _ptr(_f32c(dx)),
-                                                    dx.shape[3], dx_coff, _ptr(dgamma), _ptr(dbeta), n, c, _ptr(ws), _stream()),
+        check(L.somi_bn_act_backward_apply_sync_f32(_ptr(dzc), dzc.shape[3], dz_coff, _ptr(xc), xc.shape[3], x_coff, _ptr(mean), _ptr(rstd),
+                                                    _ptr(scale), _ptr(shift), ACT[act], order, _ptr(rec), _ptr(allrec), world, _ptr(dxc),
+                                                    dxc.shape[3], dx_coff, _ptr(dgamma), _ptr(dbeta), n, c, _ptr(ws), _stream()),
               'bn_act_backward_apply_sync')
         return dx
     ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c + 3 * ((c + 3) // 4 * 4), device=x.device, dtype=torch.float32)
