@@ -178,8 +178,8 @@ def pmc_traffic_op(op):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)       # >= 20 timed iterations after >= 10 warm-ups
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 32: BASELINE configs[1]; 2 for yolov5s)')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--nc', type=int, default=None, help='classes (default 10, yolov5s 80; 3 = UAVDT, BASELINE configs[3])')
