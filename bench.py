@@ -185,6 +185,7 @@ def main():
     ap.add_argument('--nc', type=int, default=None, help='classes (default 10, yolov5s 80; 3 = UAVDT, BASELINE configs[3])')
     ap.add_argument('--model', choices=list(MODELS), default='somi-dcn')
     ap.add_argument('--no-dcn', action='store_true', help='same as --model somi')
+    ap.add_argument('--sync-bn', action='store_true', help='N > 1: BatchNorm statistics over all ranks (train.py:165-167; off in the reference by default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-infer', action='store_true', help='skip the side measurement of the inference rate (profiling runs)')
@@ -259,7 +260,7 @@ def main():
         from somi_amd.train import TrainStep
         _, targets = synthetic_batch(args.batch, args.size, nc=nc, seed=1000 + rank)
         targets = targets.to(dev)
-        trainer = TrainStep(model, dict(HYP_VISDRONE), args.batch, dist=dist)
+        trainer = TrainStep(model, dict(HYP_VISDRONE), args.batch, dist=dist, sync_bn=args.sync_bn)
 
         def step():
             return trainer.step(imgs, targets)
@@ -311,7 +312,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{step_txt}, {args.size}x{args.size}, batch {args.batch}/GPU ({which})',
                        'batch_per_gpu': args.batch, 'imgsz': args.size, 'params': nparams, 'classes': nc,
-                       'parallelism': (f'dp{world}' if args.mode == 'train' else f'replicas x{world}')},
+                       'parallelism': ((f'dp{world}' + (' sync-bn' if args.sync_bn and world > 1 else '')) if args.mode == 'train'
+                                       else f'replicas x{world}')},
             'infer_images_per_s_per_gpu': None if infer_ips is None else round(infer_ips, 2),
             'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
