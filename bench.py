@@ -28,6 +28,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: what RCCL needs between the ranks' processes on this host driver
 for p in (ROOT, os.path.join(ROOT, 'yolo-somi_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
