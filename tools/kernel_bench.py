@@ -48,6 +48,9 @@ def dcn(N, H, C=256, G=8, k=3, spread=2.0):
     tf = timeit(lambda: dcnv3_forward(x, off, m, *args, 256))
     tb = timeit(lambda: dcnv3_backward(x, off, m, *args, go, 256))
     over = ops.dcn_overflow_taps()
+    os.environ['SOMI_DCN_GIN'] = 'exact'                         # grad_input by exact list sums instead of the MFMA product
+    te = timeit(lambda: dcnv3_backward(x, off, m, *args, go, 256))
+    os.environ.pop('SOMI_DCN_GIN')
     ops.DCN_DIRECT = True                                        # the one-kernel form with fp32 atomics into grad_input (the reference's)
     os.environ['SOMI_DCN_DIRECT'] = '1'                          # ... and the tiled gathers from L2 (the library reads this per call)
     td = timeit(lambda: dcnv3_backward(x, off, m, *args, go, 256))
@@ -57,10 +60,11 @@ def dcn(N, H, C=256, G=8, k=3, spread=2.0):
     px = N * H * H
     bf, bb = 4 * (2 * C + 3 * G * K) * px, 4 * (4 * C + 6 * G * K) * px
     for name, t, byt in (('dcnv3_fwd (windowed: taps from an LDS window)', tf, bf), ('dcnv3_fwd (tiled: taps from L2)', tft, bf),
-                         ('dcnv3_bwd (windowed: A + B + C)', tb, bb), ('dcnv3_bwd (direct, fp32 atomics)', td, bb)):
+                         ('dcnv3_bwd (windowed: A + B + C)', tb, bb), ('dcnv3_bwd (windowed, B as exact list sums)', te, bb),
+                         ('dcnv3_bwd (direct, fp32 atomics)', td, bb)):
         rec = {'kernel': name, 'shape': f'N{N} {H}x{H} C{C} G{G} K{K} offsets~N(0,{spread})', 'ms': round(t * 1e3, 4),
                'algorithmic_GB': round(byt / 1e9, 4), 'achieved_GBps': round(byt / t / 1e9, 1), 'frac_of_8TBps': round(byt / t / 1e9 / HBM_PEAK, 4)}
-        if 'bwd (windowed' in name:
+        if 'bwd (windowed: A' in name:
             rec['taps_outside_window'] = over
             rec['taps_total'] = px * G * K * 4
         print(json.dumps(rec), flush=True)

@@ -19,16 +19,17 @@
 //     A  dcnv3_win_kernel<Gc, 1> (dcnv3_bwd_om_kernel where the window does not fit): grad_offset / grad_mask - the forward's
 //        gather plus the grad_output read and an in-wave reduction over a group's channels (DPP row operations / shuffle
 //        butterflies instead of the reference's shared-memory tree); no atomics.
-//     B  dcnv3_bwd_gin_kernel: grad_input.  The reference scatters 4 taps x K points x C channels of fp32 atomics per output pixel
-//        (36.9 KB/px at C=256: the kernel sat on the chip's 1.3 TB/s float-atomic rate, 2.6 % of the HBM roofline).  Here a
-//        workgroup owns an 8x8 tile of output pixels of ONE group and a window of the input around it (tile + kernel reach + R
-//        pixels of offset slack).  The tile's 64*K*4 taps are bucketed by window cell in LDS (integer counting sort: histogram,
-//        scan, fill), then every (cell, channel) lane sums its cell's list in a register.  The addends are first rounded onto a
-//        power-of-two grid 2^-38 of the tile's largest |grad_output|, so every partial sum is exactly representable: the double sum
-//        is EXACT, hence independent of the (arbitrary) order inside a list.  No float atomics (LDS double atomics measured 35
-//        cycles per wave instruction: 1.7 ms at N32 80x80; this form 1.0 ms with 4 channels per lane.  Sorting every list by
-//        tap id - rank of each tap among its list - and summing in fp32 in that fixed order was tried: the rank scans are dependent
-//        short LDS reads, 1.4 ms).  The window leaves as plain stores into a staging slab [tile][cell][Gc].
+//     B  grad_input.  The reference scatters 4 taps x K points x C channels of fp32 atomics per output pixel (36.9 KB/px at C=256: the
+//        kernel sat on the chip's 1.3 TB/s float-atomic rate, 2.6 % of the HBM roofline).  Here a workgroup owns an 8x8 tile of output
+//        pixels of ONE group and a window of the input around it (tile + kernel reach + R pixels of offset slack); the window leaves
+//        as plain stores into a staging slab [tile][cell][Gc].  Two forms, both without float atomics and run-to-run identical:
+//        dcnv3_bwd_gin_mfma_kernel (32-wide groups, window up to ~230 cells): the window's gradient is the product S . go_tile of the (cells x 64 pixels)
+//          coefficient matrix with the tile's grad_output; S is built densely in LDS by (pixel, corner) threads that each own their
+//          column entries (no races, program order), the product runs on the fp32 matrix cores: 0.67 ms at N32 80x80;
+//        dcnv3_bwd_gin_kernel (the other widths, or when S does not fit): taps bucketed by window cell (integer counting sort in LDS),
+//          every (cell, 4 channels) lane sums its list in EXACT fp64 (addends rounded onto a 2^-38 grid of the tile's largest
+//          |grad_output|, so the sum does not depend on list order): 1.0 ms.  (Tried: LDS double atomics, 35 cycles per wave
+//          instruction, 1.7 ms; lists sorted by tap id + fp32 sums in that order, 1.4 ms - the rank scans are dependent LDS reads.)
 //     C  dcnv3_bwd_combine_kernel: every input pixel adds the (at most 2x2) windows that cover it in ascending tile order.
 //     grad_input is therefore run-to-run bit-identical whenever every tap stays within R pixels of the kernel footprint; taps
 //     beyond the window (the reference test's offsets of +-20 pixels) go to grad_input as fp32 atomics like the reference's own.
@@ -39,6 +40,7 @@ namespace somi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct DcnArgs {
     const float *input, *offset, *mask, *grad_output;
@@ -525,6 +527,219 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
     }
 }
 
+// ---- backward B on the matrix cores.  The window's gradient is a product: G[cell][c] = sum_p S[cell][p] * go[p][c] with S the
+// (cells x 64 tile pixels) matrix of tap coefficients - sparse (4*K of ~225 entries per column), but small enough to hold densely in
+// LDS, and a 256 x 64 x 32 fp32 product is 256 MFMAs = 2 us per (tile, group) where the exact list sums above spend ~10.  S is
+// built WITHOUT races or order dependence: thread (pixel p, corner t) walks the K points in order and adds its coefficient to
+// S[cell][p] - the four corners of a point hit four different cells, and nobody else touches column p - so the LDS adds of one
+// address are issued by one lane in program order.  The MFMA sums over p in hardware order: fixed.  No exact-arithmetic tricks needed.
+// LDS: S [ncell][68] floats | recs [64*K] (then, aliased, go^T [GC][68]) | ovf list: 76 KB at K = 9, Gc = 32, R = 2 (two per CU).
+constexpr int GMM_LD = GIN_TP + 4;      // row stride of S and go^T in floats (272 B: a 16-lane group of ds_read_b128 covers all banks)
+constexpr int GMM_OVF_CAP = 256;
+struct RecM {                           // one sampling point: window coordinates of its floor position and the four coefficients x mask
+    int wh, ww;                         // may lie outside [0, WH-2] x [0, WW-2]: those corners go to the overflow list
+    float cf[4];
+};
+static_assert(sizeof(RecM) == 24, "step 2 reads the records as 6 dwords");
+
+template <int GC>
+__global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a, const GinGeo q) {
+    static_assert(GC == 32, "one 32-channel MFMA row block (64-wide groups: S + go^T exceed the LDS of two workgroups per CU, they take the list form)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MB = GC / 32;
+    const int ncell = q.WH * q.WW, nrec = GIN_TP * a.K;
+    float *S = reinterpret_cast<float *>(smem);
+    RecM *recs = reinterpret_cast<RecM *>(S + (size_t)ncell * GMM_LD);
+    float *got = reinterpret_cast<float *>(recs);                 // go^T [GC][GMM_LD], written after the records are consumed
+    const size_t mid = (size_t)nrec * sizeof(RecM) > (size_t)GC * GMM_LD * 4 ? (size_t)nrec * sizeof(RecM) : (size_t)GC * GMM_LD * 4;
+    OvfG *ovf = reinterpret_cast<OvfG *>(reinterpret_cast<char *>(recs) + (mid + 15) / 16 * 16);
+    __shared__ int novf;
+    const int tile = blockIdx.x, n = blockIdx.y, g = blockIdx.z;
+    const int th0 = (tile / q.tiles_w) * GIN_TH, tw0 = (tile % q.tiles_w) * GIN_TW;
+    const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 0. this thread's share of the tile's grad_output (kept in registers until the records are done with their LDS), zeros into S
+    constexpr int GQ = GC / 4, GPT = GIN_TP * GQ / 256;            // channel quads per pixel; float4 loads per thread
+    f32x4 gr[GPT];
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        const int it = tid + j * 256, pl = it / GQ, cq = it % GQ;
+        const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+        gr[j] = (ho < a.Ho && wo < a.Wo) ? *reinterpret_cast<const f32x4 *>(a.grad_output + (((long)n * a.Ho + ho) * a.Wo + wo) * a.C + g * GC + cq * 4)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ... and the offsets / masks of this thread's first three sampling points: every global load of the workgroup is in flight before
+    // anything waits (the chain load -> record -> next load was 3 latencies long: 15 us per workgroup with 8 waves per CU to hide it)
+    constexpr int RB = 3;
+    float2 ofs_r[RB];
+    float m_r[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int i = tid + j * 256;
+        ofs_r[j] = make_float2(0.f, 0.f);
+        m_r[j] = 0.f;
+        if (i < nrec) {
+            const int pl = i / a.K, k = i % a.K;
+            const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+            if (ho < a.Ho && wo < a.Wo) {
+                const long s = ((((long)n * a.Ho + ho) * a.Wo + wo) * a.G + g) * a.K + k;
+                ofs_r[j] = *reinterpret_cast<const float2 *>(a.offset + s * 2);
+                m_r[j] = a.mask[s];
+            }
+        }
+    }
+    for (int i = tid; i < ncell * GMM_LD / 4; i += 256) reinterpret_cast<f32x4 *>(S)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) novf = 0;
+    // 1. records
+    for (int i = tid, j = 0; i < nrec; i += 256, ++j) {
+        const int pl = i / a.K, k = i % a.K;
+        const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+        RecM r;
+        r.wh = r.ww = 0;
+        r.cf[0] = r.cf[1] = r.cf[2] = r.cf[3] = 0.f;
+        if (ho < a.Ho && wo < a.Wo) {
+            float2 ofs;
+            float m;
+            if (j < RB) {
+                ofs = j == 0 ? ofs_r[0] : (j == 1 ? ofs_r[1] : ofs_r[2]);
+                m = j == 0 ? m_r[0] : (j == 1 ? m_r[1] : m_r[2]);
+            } else {
+                const long s = ((((long)n * a.Ho + ho) * a.Wo + wo) * a.G + g) * a.K + k;
+                ofs = *reinterpret_cast<const float2 *>(a.offset + s * 2);
+                m = a.mask[s];
+            }
+            const int ii = k / a.kh, jj = k % a.kh;
+            const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
+            const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
+            const float p0h = (float)(half_h - a.ph + ho * a.sh) - (float)half_h * a.offset_scale;
+            const float loc_w = p0w + ((float)(ii * a.dw) + ofs.x) * a.offset_scale;
+            const float loc_h = p0h + ((float)(jj * a.dh) + ofs.y) * a.offset_scale;
+            if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)a.H && loc_w < (float)a.W) {
+                const float fh = floorf(loc_h), fw = floorf(loc_w);
+                const int h0 = (int)fh, w0 = (int)fw;
+                const float lh = loc_h - fh, lw = loc_w - fw, hh = 1.f - lh, hw = 1.f - lw;
+                const bool h0ok = h0 >= 0, h1ok = h0 + 1 <= a.H - 1, w0ok = w0 >= 0, w1ok = w0 + 1 <= a.W - 1;
+                r.wh = h0 - win_h0;
+                r.ww = w0 - win_w0;
+                r.cf[0] = (h0ok && w0ok) ? hh * hw * m : 0.f;
+                r.cf[1] = (h0ok && w1ok) ? hh * lw * m : 0.f;
+                r.cf[2] = (h1ok && w0ok) ? lh * hw * m : 0.f;
+                r.cf[3] = (h1ok && w1ok) ? lh * lw * m : 0.f;
+            }
+        }
+        recs[i] = r;
+    }
+    __syncthreads();
+    // 2. S: thread (pixel, corner) walks the points in order, three records' fields in flight
+    {
+        const int pl = tid >> 2, tp = tid & 3, dy = tp >> 1, dx = tp & 1;
+        const int *rw = reinterpret_cast<const int *>(recs + pl * a.K);       // RecM = {wh, ww, cf[4]}: 6 dwords
+        auto put = [&](int wh0, int ww0, float cf) {
+            if (cf == 0.f) return;
+            const int wh = wh0 + dy, ww = ww0 + dx;
+            if ((unsigned)wh < (unsigned)q.WH && (unsigned)ww < (unsigned)q.WW) {
+                atomicAdd(&S[(wh * q.WW + ww) * GMM_LD + pl], cf);            // ds_add_f32: this lane is the only writer of column pl
+            } else {
+                const int at = atomicAdd(&novf, 1);
+                if (at < GMM_OVF_CAP) ovf[at] = OvfG{(wh + win_h0) * a.W + ww + win_w0, pl, cf};   // a longer list: all of them again in step 5
+            }
+        };
+        int k = 0;
+        for (; k + 3 <= a.K; k += 3) {
+            int wh[3], ww[3];
+            float cf[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                wh[j] = rw[(k + j) * 6];
+                ww[j] = rw[(k + j) * 6 + 1];
+                cf[j] = __int_as_float(rw[(k + j) * 6 + 2 + tp]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) put(wh[j], ww[j], cf[j]);
+        }
+        for (; k < a.K; ++k) put(rw[k * 6], rw[k * 6 + 1], __int_as_float(rw[k * 6 + 2 + tp]));
+    }
+    __syncthreads();
+    // 3. go^T into the records' LDS: got[c][p]
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        const int it = tid + j * 256, pl = it / GQ, cq = it % GQ;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) got[(cq * 4 + e) * GMM_LD + pl] = gr[j][e];
+    }
+    __syncthreads();
+    // 4. G^T = go^T . S^T on the matrix cores: M = channels (32 per block), N = cells (32 per block), K = the 64 tile pixels.
+    //    Operand fetch as in conv_igemm.hip: a lane reads 4 consecutive k of its row with one ds_read_b128, the two half-waves 4 apart,
+    //    and MFMA step t pairs k = 8j + t (lanes 0-31) with k = 8j + 4 + t (lanes 32-63) - the same permutation on both operands.
+    const int nblk = (ncell + 31) / 32;
+    const int frag = (lane & 31) * GMM_LD + (lane >> 5) * 4;
+    float *dst = q.staging + (((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile) * (long)ncell * GC;
+    for (int cb = wave; cb < nblk; cb += 4) {
+        f32x16 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
+        const int crow = cb * 32 + (lane & 31);
+        const float *srow = S + (crow < ncell ? crow : ncell - 1) * GMM_LD + (lane >> 5) * 4;     // rows past the window: a valid row, never stored
+#pragma unroll
+        for (int j = 0; j < GIN_TP / 8; ++j) {
+            const f32x4 fs = *reinterpret_cast<const f32x4 *>(srow + j * 8);
+            f32x4 fg[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) fg[mb] = *reinterpret_cast<const f32x4 *>(got + mb * 32 * GMM_LD + frag + j * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg[mb][t], fs[t], acc[mb], 0, 0, 0);
+        }
+        // D: lane holds cell n = lane % 32 and channels 8*(e/4) + 4*(lane/32) + e%4 of the block
+        if (crow < ncell) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 v = {acc[mb][qd * 4], acc[mb][qd * 4 + 1], acc[mb][qd * 4 + 2], acc[mb][qd * 4 + 3]};
+                    *reinterpret_cast<f32x4 *>(dst + (long)crow * GC + mb * 32 + qd * 8 + (lane >> 5) * 4) = v;
+                }
+        }
+    }
+    // 5. taps beyond the window: fp32 atomics into grad_input like the reference's own kernel (one channel per lane)
+    if (novf) {
+        constexpr int SLOTS = 256 / GC;
+        const int c = tid % GC, slot = tid / GC;
+        float *gin = a.grad_input + (long)n * a.H * a.W * a.C + g * GC + c;
+        const int nlist = novf < GMM_OVF_CAP ? novf : GMM_OVF_CAP;
+        const bool spilled = novf > GMM_OVF_CAP;
+        if (!spilled) {
+            for (int i = slot; i < nlist; i += SLOTS) {
+                const OvfG o = ovf[i];
+                atomicAdd(gin + (long)o.hw * a.C, got[c * GMM_LD + o.px] * o.cf);
+            }
+        } else {
+            // the list was too short (offsets far beyond the slack everywhere): every out-of-window tap again, from the records' inputs
+            for (int i = slot; i < nrec; i += SLOTS) {
+                const int pl = i / a.K, k = i % a.K;
+                const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+                if (ho >= a.Ho || wo >= a.Wo) continue;
+                const Rec r = make_record<true>(a, ((long)n * a.Ho + ho) * a.Wo + wo, g, k);
+                const int bits = __float_as_int(r.f[3]);
+                const float lh = r.f[0], lw = r.f[1], m = r.f[2], hh = 1.f - lh, hw = 1.f - lw;
+                const float cf4[4] = {hh * hw * m, hh * lw * m, lh * hw * m, lh * lw * m};
+                const float tv = got[c * GMM_LD + pl];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (!((bits >> t) & 1)) continue;
+                    const int hwp = r.off[t] / a.C, h = hwp / a.W, w = hwp % a.W;
+                    if ((unsigned)(h - win_h0) < (unsigned)q.WH && (unsigned)(w - win_w0) < (unsigned)q.WW) continue;   // went through S
+                    atomicAdd(gin + (long)hwp * a.C, tv * cf4[t]);
+                }
+            }
+        }
+        if (tid == 0) atomicAdd(q.overflow, (unsigned)novf);
+    }
+}
+
 // grad_input[n,h,w,c] += sum over the windows covering (h,w), ascending tile order (4 channels per lane)
 __global__ __launch_bounds__(256) void dcnv3_bwd_combine_kernel(const DcnArgs a, const GinGeo q) {
     const int C4 = a.C >> 2;
@@ -962,10 +1177,23 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
                                       (int)glds);                                                                               \
         hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<GC>), grid, dim3(256), glds, s, a, q);                                         \
     } while (0)
-        if (Gc == 8) SOMI_GIN_LAUNCH(8);
+        // B on the matrix cores for 32-wide groups when its LDS image fits (SOMI_DCN_GIN=exact keeps the list sums for comparisons)
+        const char *gsel = getenv("SOMI_DCN_GIN");
+        const size_t ncell_ = (size_t)q.WH * q.WW, recb = (size_t)GIN_TP * a.K * sizeof(RecM), gotb = (size_t)Gc * GMM_LD * sizeof(float);
+        const size_t mlds = ncell_ * GMM_LD * sizeof(float) + ((recb > gotb ? recb : gotb) + 15) / 16 * 16 + GMM_OVF_CAP * sizeof(OvfG);
+        const bool mfma = Gc == 32 && mlds <= 78 * 1024 + 512 && !(gsel && gsel[0] == 'e');
+#define SOMI_GMM_LAUNCH(GC)                                                                                                      \
+    do {                                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_mfma_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)mlds);                                                                               \
+        hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC>), grid, dim3(256), mlds, s, a, q);                                    \
+    } while (0)
+        if (mfma) SOMI_GMM_LAUNCH(32);
+        else if (Gc == 8) SOMI_GIN_LAUNCH(8);
         else if (Gc == 16) SOMI_GIN_LAUNCH(16);
         else if (Gc == 32) SOMI_GIN_LAUNCH(32);
         else SOMI_GIN_LAUNCH(64);
+#undef SOMI_GMM_LAUNCH
 #undef SOMI_GIN_LAUNCH
         long blocks = ((long)N * H * W * (a.C / 4) + 255) / 256;
         hipLaunchKernelGGL(dcnv3_bwd_combine_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, s, a, q);
