@@ -25,7 +25,8 @@
 //        as plain stores into a staging slab [tile][cell][Gc].  Two forms, both without float atomics and run-to-run identical:
 //        dcnv3_bwd_gin_mfma_kernel (32-wide groups, window up to ~230 cells): the window's gradient is the product S . go_tile of the (cells x 64 pixels)
 //          coefficient matrix with the tile's grad_output; S is built densely in LDS by (pixel, corner) threads that each own their
-//          column entries (no races, program order), the product runs on the fp32 matrix cores: 0.67 ms at N32 80x80;
+//          column entries (no races, program order; plain LDS read-add-write - ds_add_f32 atomics for the same adds cost 0.16 ms more),
+//          the product runs on the fp32 matrix cores: 0.48 ms at N32 80x80;
 //        dcnv3_bwd_gin_kernel (the other widths, or when S does not fit): taps bucketed by window cell (integer counting sort in LDS),
 //          every (cell, 4 channels) lane sums its list in EXACT fp64 (addends rounded onto a 2^-38 grid of the tile's largest
 //          |grad_output|, so the sum does not depend on list order): 1.0 ms.  (Tried: LDS double atomics, 35 cycles per wave
@@ -531,8 +532,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
 // (cells x 64 tile pixels) matrix of tap coefficients - sparse (4*K of ~225 entries per column), but small enough to hold densely in
 // LDS, and a 256 x 64 x 32 fp32 product is 256 MFMAs = 2 us per (tile, group) where the exact list sums above spend ~10.  S is
 // built WITHOUT races or order dependence: thread (pixel p, corner t) walks the K points in order and adds its coefficient to
-// S[cell][p] - the four corners of a point hit four different cells, and nobody else touches column p - so the LDS adds of one
-// address are issued by one lane in program order.  The MFMA sums over p in hardware order: fixed.  No exact-arithmetic tricks needed.
+// S[cell][p] - the four corners of a point hit four different cells, and nobody else touches column p - so the LDS updates of one
+// address are issued by one lane in program order (as plain read-add-write: LDS float atomics measured 35 % slower for the kernel).  The MFMA sums over p in hardware order: fixed.  No exact-arithmetic tricks needed.
 // LDS: S [ncell][68] floats | recs [64*K] (then, aliased, go^T [GC][68]) | ovf list: 76 KB at K = 9, Gc = 32, R = 2 (two per CU).
 constexpr int GMM_LD = GIN_TP + 4;      // row stride of S and go^T in floats (272 B: a 16-lane group of ds_read_b128 covers all banks)
 constexpr int GMM_OVF_CAP = 256;
@@ -542,8 +543,10 @@ struct RecM {                           // one sampling point: window coordinate
 };
 static_assert(sizeof(RecM) == 24, "step 2 reads the records as 6 dwords");
 
+constexpr int GMM_NT = 512;           // threads: LDS (S is 61 KB) allows two workgroups per CU, so each brings 8 waves for the non-MFMA phases
+
 template <int GC>
-__global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a, const GinGeo q) {
+__global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a, const GinGeo q) {
     static_assert(GC == 32, "one 32-channel MFMA row block (64-wide groups: S + go^T exceed the LDS of two workgroups per CU, they take the list form)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MB = GC / 32;
@@ -559,23 +562,25 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a
     const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 0. this thread's share of the tile's grad_output (kept in registers until the records are done with their LDS), zeros into S
-    constexpr int GQ = GC / 4, GPT = GIN_TP * GQ / 256;            // channel quads per pixel; float4 loads per thread
+    constexpr int NT = GMM_NT;
+    constexpr int GQ = GC / 4, GPT = GIN_TP * GQ / NT;             // channel quads per pixel; float4 loads per thread
+    static_assert(GPT >= 1 && GIN_TP * 4 <= NT, "thread count");
     f32x4 gr[GPT];
 #pragma unroll
     for (int j = 0; j < GPT; ++j) {
-        const int it = tid + j * 256, pl = it / GQ, cq = it % GQ;
+        const int it = tid + j * NT, pl = it / GQ, cq = it % GQ;
         const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
         gr[j] = (ho < a.Ho && wo < a.Wo) ? *reinterpret_cast<const f32x4 *>(a.grad_output + (((long)n * a.Ho + ho) * a.Wo + wo) * a.C + g * GC + cq * 4)
                                         : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // ... and the offsets / masks of this thread's first three sampling points: every global load of the workgroup is in flight before
+    // ... and the offsets / masks of this thread's first two sampling points: every global load of the workgroup is in flight before
     // anything waits (the chain load -> record -> next load was 3 latencies long: 15 us per workgroup with 8 waves per CU to hide it)
-    constexpr int RB = 3;
+    constexpr int RB = 2;
     float2 ofs_r[RB];
     float m_r[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int i = tid + j * 256;
+        const int i = tid + j * NT;
         ofs_r[j] = make_float2(0.f, 0.f);
         m_r[j] = 0.f;
         if (i < nrec) {
@@ -588,10 +593,10 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a
             }
         }
     }
-    for (int i = tid; i < ncell * GMM_LD / 4; i += 256) reinterpret_cast<f32x4 *>(S)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < ncell * GMM_LD / 4; i += NT) reinterpret_cast<f32x4 *>(S)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid == 0) novf = 0;
     // 1. records
-    for (int i = tid, j = 0; i < nrec; i += 256, ++j) {
+    for (int i = tid, j = 0; i < nrec; i += NT, ++j) {
         const int pl = i / a.K, k = i % a.K;
         const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
         RecM r;
@@ -601,8 +606,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a
             float2 ofs;
             float m;
             if (j < RB) {
-                ofs = j == 0 ? ofs_r[0] : (j == 1 ? ofs_r[1] : ofs_r[2]);
-                m = j == 0 ? m_r[0] : (j == 1 ? m_r[1] : m_r[2]);
+                ofs = j == 0 ? ofs_r[0] : ofs_r[1];
+                m = j == 0 ? m_r[0] : m_r[1];
             } else {
                 const long s = ((((long)n * a.Ho + ho) * a.Wo + wo) * a.G + g) * a.K + k;
                 ofs = *reinterpret_cast<const float2 *>(a.offset + s * 2);
@@ -630,15 +635,15 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a
         recs[i] = r;
     }
     __syncthreads();
-    // 2. S: thread (pixel, corner) walks the points in order, three records' fields in flight
-    {
+    // 2. S: thread (pixel, corner) walks the points in order, three records' fields in flight (the first 256 threads)
+    if (tid < GIN_TP * 4) {
         const int pl = tid >> 2, tp = tid & 3, dy = tp >> 1, dx = tp & 1;
         const int *rw = reinterpret_cast<const int *>(recs + pl * a.K);       // RecM = {wh, ww, cf[4]}: 6 dwords
         auto put = [&](int wh0, int ww0, float cf) {
             if (cf == 0.f) return;
             const int wh = wh0 + dy, ww = ww0 + dx;
             if ((unsigned)wh < (unsigned)q.WH && (unsigned)ww < (unsigned)q.WW) {
-                atomicAdd(&S[(wh * q.WW + ww) * GMM_LD + pl], cf);            // ds_add_f32: this lane is the only writer of column pl
+                S[(wh * q.WW + ww) * GMM_LD + pl] += cf;                      // plain read-add-write: this lane is the only writer of column pl
             } else {
                 const int at = atomicAdd(&novf, 1);
                 if (at < GMM_OVF_CAP) ovf[at] = OvfG{(wh + win_h0) * a.W + ww + win_w0, pl, cf};   // a longer list: all of them again in step 5
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a
     // 3. go^T into the records' LDS: got[c][p]
 #pragma unroll
     for (int j = 0; j < GPT; ++j) {
-        const int it = tid + j * 256, pl = it / GQ, cq = it % GQ;
+        const int it = tid + j * NT, pl = it / GQ, cq = it % GQ;
 #pragma unroll
         for (int e = 0; e < 4; ++e) got[(cq * 4 + e) * GMM_LD + pl] = gr[j][e];
     }
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a
     const int nblk = (ncell + 31) / 32;
     const int frag = (lane & 31) * GMM_LD + (lane >> 5) * 4;
     float *dst = q.staging + (((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile) * (long)ncell * GC;
-    for (int cb = wave; cb < nblk; cb += 4) {
+    for (int cb = wave; cb < nblk; cb += NT / 64) {
         f32x16 acc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a
     }
     // 5. taps beyond the window: fp32 atomics into grad_input like the reference's own kernel (one channel per lane)
     if (novf) {
-        constexpr int SLOTS = 256 / GC;
+        constexpr int SLOTS = NT / GC;
         const int c = tid % GC, slot = tid / GC;
         float *gin = a.grad_input + (long)n * a.H * a.W * a.C + g * GC + c;
         const int nlist = novf < GMM_OVF_CAP ? novf : GMM_OVF_CAP;
@@ -1186,7 +1191,7 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
     do {                                                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_mfma_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)mlds);                                                                               \
-        hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC>), grid, dim3(256), mlds, s, a, q);                                    \
+        hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC>), grid, dim3(GMM_NT), mlds, s, a, q);                                    \
     } while (0)
         if (mfma) SOMI_GMM_LAUNCH(32);
         else if (Gc == 8) SOMI_GIN_LAUNCH(8);
