@@ -157,7 +157,7 @@ def pmc_traffic(kernel_name):
 
 # the kernels behind the two DCNv3 operator entries that ops.PROFILE times (forward = one launch; backward = A + B + C of the windowed form)
 DCN_OP_KERNELS = {'dcnv3_fwd_kernel': (r'dcnv3_win_kernel<\d+,0>|dcnv3_fwd_kernel',),
-                  'dcnv3_bwd_kernel': (r'dcnv3_win_kernel<\d+,1>|dcnv3_bwd_om_kernel', r'dcnv3_bwd_gin_kernel', r'dcnv3_bwd_combine_kernel')}
+                  'dcnv3_bwd_kernel': (r'dcnv3_win_kernel<\d+,1>|dcnv3_bwd_om_kernel', r'dcnv3_bwd_gin_(mfma_)?kernel', r'dcnv3_bwd_combine_kernel')}
 
 
 def pmc_traffic_op(op):
