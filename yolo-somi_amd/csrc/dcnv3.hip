@@ -24,9 +24,9 @@
 //        pixels of ONE group and a window of the input around it (tile + kernel reach + R pixels of offset slack); the window leaves
 //        as plain stores into a staging slab [tile][cell][Gc].  Two forms, both without float atomics and run-to-run identical:
 //        dcnv3_bwd_gin_mfma_kernel (32-wide groups, window up to ~230 cells): the window's gradient is the product S . go_tile of the (cells x 64 pixels)
-//          coefficient matrix with the tile's grad_output; S is built densely in LDS by (pixel, corner) threads that each own their
-//          column entries (no races, program order; plain LDS read-add-write - ds_add_f32 atomics for the same adds cost 0.16 ms more),
-//          the product runs on the fp32 matrix cores: 0.48 ms at N32 80x80;
+//          coefficient matrix with the tile's grad_output; S is built densely in LDS by (pixel, corner) lanes - the four writers of a
+//          column sit in one wave and never share a cell within an instruction, so plain read-add-write in program order is race-free
+//          (ds_add_f32 atomics for the same adds cost 0.16 ms more) - and the product runs on the fp32 matrix cores: 0.48 ms at N32 80x80;
 //        dcnv3_bwd_gin_kernel (the other widths, or when S does not fit): taps bucketed by window cell (integer counting sort in LDS),
 //          every (cell, 4 channels) lane sums its list in EXACT fp64 (addends rounded onto a 2^-38 grid of the tile's largest
 //          |grad_output|, so the sum does not depend on list order): 1.0 ms.  (Tried: LDS double atomics, 35 cycles per wave
@@ -531,9 +531,12 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
 // ---- backward B on the matrix cores.  The window's gradient is a product: G[cell][c] = sum_p S[cell][p] * go[p][c] with S the
 // (cells x 64 tile pixels) matrix of tap coefficients - sparse (4*K of ~225 entries per column), but small enough to hold densely in
 // LDS, and a 256 x 64 x 32 fp32 product is 256 MFMAs = 2 us per (tile, group) where the exact list sums above spend ~10.  S is
-// built WITHOUT races or order dependence: thread (pixel p, corner t) walks the K points in order and adds its coefficient to
-// S[cell][p] - the four corners of a point hit four different cells, and nobody else touches column p - so the LDS updates of one
-// address are issued by one lane in program order (as plain read-add-write: LDS float atomics measured 35 % slower for the kernel).  The MFMA sums over p in hardware order: fixed.  No exact-arithmetic tricks needed.
+// built WITHOUT races or order dependence: lane (pixel p, corner t) walks the K points in order and adds its coefficient to
+// S[cell][p].  Column p is written by the four corner lanes of pixel p only; they are neighbouring lanes of ONE wave (tid = 4p + t)
+// and step through the points together: inside one LDS instruction they address four different cells (the corners of one point),
+// and a wave's LDS instructions execute in program order, so a later point that lands on the same cell reads the earlier update.
+// Hence plain read-add-write, no atomics (ds_add_f32 for the same adds made the kernel 35 % slower), and one fixed order of the adds.
+// The MFMA sums over p in hardware order: fixed.  No exact-arithmetic tricks needed.
 // LDS: S [ncell][68] floats | recs [64*K] (then, aliased, go^T [GC][68]) | ovf list: 76 KB at K = 9, Gc = 32, R = 2 (two per CU).
 constexpr int GMM_LD = GIN_TP + 4;      // row stride of S and go^T in floats (272 B: a 16-lane group of ds_read_b128 covers all banks)
 constexpr int GMM_OVF_CAP = 256;
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
             if (cf == 0.f) return;
             const int wh = wh0 + dy, ww = ww0 + dx;
             if ((unsigned)wh < (unsigned)q.WH && (unsigned)ww < (unsigned)q.WW) {
-                S[(wh * q.WW + ww) * GMM_LD + pl] += cf;                      // plain read-add-write: this lane is the only writer of column pl
+                S[(wh * q.WW + ww) * GMM_LD + pl] += cf;                      // plain read-add-write: see the note on column writers above
             } else {
                 const int at = atomicAdd(&novf, 1);
                 if (at < GMM_OVF_CAP) ovf[at] = OvfG{(wh + win_h0) * a.W + ww + win_w0, pl, cf};   // a longer list: all of them again in step 5
