@@ -86,7 +86,8 @@ def main(steps=300, S=128, B=16, nc=4, width=0.25, depth=0.33):
         last = float(loss)
     torch.cuda.synchronize()
     t_train = time.time() - t0
-    val_batches = [rect_batch(B, S, nc, 100 + i) for i in range(4)] + [rect_batch(B, S, nc, 900 + i) for i in range(2)]
+    # three validation batches (two seen in training, one not): the CPU oracle's pass over them is what this test's time goes to
+    val_batches = [rect_batch(B, S, nc, 100 + i) for i in range(2)] + [rect_batch(B, S, nc, 900)]
     from somi_amd.metrics import ConfusionMatrix
     cm = ConfusionMatrix(nc)
     mp, mr, m50, m, det = V.run(model, val_batches, conf_thres=0.001, iou_thres=0.6, confusion_matrix=cm)
