@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 9
+#define SOMI_ABI_VERSION 10
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -517,6 +517,17 @@ int somi_wbf_f32(const float *boxes, const float *scores, const int32_t *labels,
                  int n_models, const float *weights_host, float iou_thr, float skip_box_thr, float *out_boxes,
                  float *out_scores, int32_t *out_labels, int32_t *out_count, void *workspace, size_t workspace_bytes,
                  somi_stream_t stream);
+/* Batched form (BASELINE configs[4]: val.py's NMS followed by wbf.py over the detections of several models): one workgroup per image.
+ * det[t] (B,max_det,6) [x1,y1,x2,y2,conf,cls] in pixels and count[t] (B) are somi_nms_f32's outputs for model t (host arrays of
+ * n_models device pointers).  Image b's members are model 0's rows, then model 1's, ... (the order wbf.py:44-59 appends them in),
+ * boxes divided by (img_w, img_h) and clipped to [0,1].  Outputs are strided per image by N = n_models * max_det:
+ * out_boxes (B,N,4), out_scores (B,N), out_labels (B,N), out_count (B).  Same arithmetic as somi_wbf_f32, image by image.
+ */
+size_t somi_wbf_batch_workspace_bytes(int B, int max_det, int n_models);
+int somi_wbf_batch_f32(const float *const *det, const int32_t *const *count, int B, int max_det, int n_models,
+                       const float *weights_host, float img_w, float img_h, float iou_thr, float skip_box_thr, float *out_boxes,
+                       float *out_scores, int32_t *out_labels, int32_t *out_count, void *workspace, size_t workspace_bytes,
+                       somi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Validation metrics after NMS.

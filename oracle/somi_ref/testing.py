@@ -160,3 +160,149 @@ def tiny_somi_cfg(nc=10):
           [-1, 1, 'SEAM', [32, 1, 16]], [-1, 1, 'C2fCBAM', [32]], [[10, 6], 1, 'DecoupledDetect', ['nc', 'anchors']]]
     return dict(nc=nc, depth_multiple=1.0, width_multiple=1.0, anchors=[[4, 6, 12, 8, 7, 14, 20, 12], [13, 22, 31, 18, 21, 33, 46, 23]],
                 backbone=copy.deepcopy(bb), head=copy.deepcopy(hd))
+
+
+class AbsTermSums:
+    """Condition numbers of parameter gradients, measured - test infrastructure for the training-parity tests.
+
+    A parameter gradient is a sum of products, g = sum_t a_t * b_t (pixels x samples for a conv weight, pixels for a bias or a
+    BatchNorm scale, ...).  An fp32 realisation of that sum - whatever its order - is off from the exact value by a multiple of
+    2^-24 * S with S = sum_t |a_t * b_t|; when the terms cancel (S >> |g|) a RELATIVE bar on g is meaningless, and a bar on
+    |error| / (2^-24 * S) is the principled one.  This context computes S for every parameter of a model during ONE ordinary
+    fp64 autograd pass (forward hooks keep the layer inputs, tensor hooks on the layer outputs see the output gradients):
+
+        with AbsTermSums(model64) as cond:
+            loss(model64(x)).backward()
+        S = cond.sums            # {parameter name: tensor like the parameter}
+
+    Covered: nn.Conv2d / nn.Linear / nn.BatchNorm2d / nn.LayerNorm (everything the graphs are built from), the candidate kernels and
+    biases of ODConv2d_3rd, the BiFPN fusion weights.  A parameter of any other kind is simply absent from `sums`.
+    """
+
+    def __init__(self, model):
+        self.model, self.sums, self._handles = model, {}, []
+        self._names = {id(p): n for n, p in model.named_parameters()}
+
+    def _add(self, p, s):
+        n = self._names.get(id(p))
+        if n is not None:
+            s = s.detach().reshape(p.shape)
+            self.sums[n] = self.sums[n] + s if n in self.sums else s
+
+    def __enter__(self):
+        import torch.nn as nn
+        import torch.nn.functional as F
+        from .blocks import BiFPN, ODConv2d_3rd
+
+        def on_output(mod, fn):
+            def fwd(m, inp, out):
+                if torch.is_grad_enabled() and isinstance(out, torch.Tensor) and out.requires_grad:
+                    saved = [t.detach() if isinstance(t, torch.Tensor) else t for t in inp]
+                    out.register_hook(lambda g: fn(m, saved, g.detach()))
+            self._handles.append(mod.register_forward_hook(fwd))
+
+        def conv(m, inp, dy):
+            x = inp[0]
+            self._add(m.weight, torch.nn.grad.conv2d_weight(x.abs(), m.weight.shape, dy.abs(), m.stride, m.padding, m.dilation, m.groups))
+            if m.bias is not None:
+                self._add(m.bias, dy.abs().sum((0, 2, 3)))
+
+        def linear(m, inp, dy):
+            x = inp[0].reshape(-1, inp[0].shape[-1])
+            d = dy.reshape(-1, dy.shape[-1])
+            self._add(m.weight, d.abs().t() @ x.abs())
+            if m.bias is not None:
+                self._add(m.bias, d.abs().sum(0))
+
+        def bnorm(m, inp, dy):
+            x = inp[0]
+            if m.training or m.running_mean is None:
+                mean, var = x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False)
+            else:
+                mean, var = m.running_mean, m.running_var
+            xh = (x - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + m.eps)
+            if m.weight is not None:
+                self._add(m.weight, (dy * xh).abs().sum((0, 2, 3)))
+                self._add(m.bias, dy.abs().sum((0, 2, 3)))
+
+        def lnorm(m, inp, dy):
+            x = inp[0]
+            dims = tuple(range(-len(m.normalized_shape), 0))
+            xh = (x - x.mean(dims, keepdim=True)) / torch.sqrt(x.var(dims, unbiased=False, keepdim=True) + m.eps)
+            lead = tuple(range(x.dim() - len(m.normalized_shape)))
+            if m.weight is not None:
+                self._add(m.weight, (dy * xh).abs().sum(lead))
+                self._add(m.bias, dy.abs().sum(lead))
+
+        def odconv(m, inp, dy):
+            # dW[k] = sum_b attn[b,k] * dW_b with dW_b the weight gradient of sample b's own convolution (blocks.ODConv2d_3rd.get_weight_bias)
+            x = inp[0]
+            ctx = inp[1] if len(inp) > 1 and isinstance(inp[1], torch.Tensor) else x
+            B = x.shape[0]
+            with torch.no_grad():
+                a_f, a_s, a_c, a_w = m.attentions(ctx)
+                attn = a_f.view(B, 1, -1, 1, 1, 1)
+                if a_s is not None:
+                    attn = attn * a_s.view(B, 1, 1, 1, *m.kernel_size)
+                if a_c is not None:
+                    attn = attn * a_c.view(B, 1, 1, -1, 1, 1)
+                if a_w is not None:
+                    attn = attn * a_w.view(B, -1, 1, 1, 1, 1)
+                per = m.weight.shape[1:]
+                s = torch.zeros_like(m.weight)
+                for b in range(B):
+                    sb = torch.nn.grad.conv2d_weight(x[b:b + 1].abs(), per, dy[b:b + 1].abs(), m.stride, m.padding, m.dilation, m.groups)
+                    s += attn[b].abs() * sb[None]
+                self._add(m.weight, s)
+                if m.bias is not None:
+                    w = a_w.abs() if a_w is not None else torch.ones(B, m.K, dtype=dy.dtype)
+                    self._add(m.bias, w.t() @ dy.abs().sum((2, 3)))
+
+        def bifpn(m, inp, dy):
+            xs = inp[0]
+            s = torch.stack([(dy * x).abs().sum() for x in xs])                   # |terms| of d(loss)/d(w_i)
+            wgt = m.weight.detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                jac = torch.autograd.functional.jacobian(lambda v: v / (m.swish(v).sum(dim=0) + m.epsilon), wgt)   # d w_i / d weight_j
+            self._add(m.weight, (jac.abs() * s[:len(xs), None]).sum(0))
+
+        for mod in self.model.modules():
+            if isinstance(mod, ODConv2d_3rd):
+                on_output(mod, odconv)
+            elif type(mod) is nn.Conv2d:
+                on_output(mod, conv)
+            elif isinstance(mod, nn.Linear):
+                on_output(mod, linear)
+            elif isinstance(mod, nn.BatchNorm2d):
+                on_output(mod, bnorm)
+            elif isinstance(mod, nn.LayerNorm):
+                on_output(mod, lnorm)
+            elif isinstance(mod, BiFPN):
+                on_output(mod, bifpn)
+        return self
+
+    def __exit__(self, *exc):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        return False
+
+
+def conditioned_errors(named_grads, named_ref64, sums, eps=2.0 ** -24, rel=1e-3):
+    """Per parameter that has both a reference gradient and a measured S (AbsTermSums):
+        (name, c_req, rel_err, cond)
+    rel_err = max |g - g64| / max |g64|; cond = max S / max |g64| (how ill-conditioned the sums are); c_req = the smallest c with
+        |g - g64|_e <= rel * max |g64| + c * eps * S_e      for every element e,
+    i.e. 0 when the plain relative bar holds, else the error beyond it in units of one fp32 rounding of the gradient's own terms."""
+    out = []
+    for n, g in named_grads:
+        g64 = named_ref64.get(n)
+        s = sums.get(n)
+        if g64 is None or s is None:
+            continue
+        d = (g.detach().cpu().double() - g64.double()).abs()
+        scale = g64.abs().max().item() + 1e-300
+        s = s.double().clamp_min(1e-300)
+        c_req = ((d - rel * scale).clamp_min(0) / (eps * s)).max().item()
+        out.append((n, c_req, d.max().item() / scale, s.max().item() / scale))
+    return out

@@ -126,6 +126,47 @@ def test_wbf_empty():
     assert gb.shape == (0, 4)
 
 
+def test_wbf_batch_matches_oracle_image_by_image():
+    """somi_wbf_batch_f32 (one workgroup per image, fed by NMS-shaped (B, max_det, 6) + count tensors of two models, wbf.py:44-68)
+    against the oracle run per image on the same normalised, clipped boxes - bit-exact, including an image where one model and an
+    image where both models have no detections."""
+    import torch
+    from oracle.somi_ref.wbf import weighted_boxes_fusion as oracle
+    from somi_amd.wbf import weighted_boxes_fusion_batch
+    B, max_det, nm, S = 6, 40, 2, 640.0
+    rng = np.random.default_rng(11)
+    dets, counts = [], []
+    for t in range(nm):
+        d = np.zeros((B, max_det, 6), np.float32)
+        c = rng.integers(5, max_det + 1, B).astype(np.int32)
+        c[3] = 0 if t == 0 else c[3]                            # image 3: model 0 found nothing
+        c[4] = 0                                                # image 4: nobody did
+        for b in range(B):
+            base = np.random.default_rng(100 + b).uniform(20, 560, (12, 2)).astype(np.float32)   # the models see the same objects
+            pick = rng.integers(0, 12, max_det)
+            xy = base[pick] + rng.normal(0, 3.0, (max_det, 2)).astype(np.float32)
+            wh = rng.uniform(12, 90, (max_det, 2)).astype(np.float32)
+            d[b, :, :2], d[b, :, 2:4] = xy, xy + wh
+            d[b, :, 4] = np.sort(rng.uniform(0.0, 1.0, max_det).astype(np.float32))[::-1]       # NMS rows come sorted by confidence
+            d[b, :, 5] = pick % 10
+        d[0, 1, :4] = [-30, 600, 200, 700]                      # leaves the image: clipped
+        dets.append(d), counts.append(c)
+    gb, gs, gl, gc = weighted_boxes_fusion_batch([torch.from_numpy(d).cuda() for d in dets], [torch.from_numpy(c).cuda() for c in counts],
+                                                 (S, S), weights=None, iou_thr=0.67, skip_box_thr=0.01)
+    gb, gs, gl, gc = gb.cpu().numpy(), gs.cpu().numpy(), gl.cpu().numpy(), gc.cpu().numpy()
+    for b in range(B):
+        bl = [np.clip(d[b, :c[b], :4] / np.float32(S), 0, 1) for d, c in zip(dets, counts)]
+        sl = [d[b, :c[b], 4] for d, c in zip(dets, counts)]
+        ll = [d[b, :c[b], 5].astype(np.int64) for d, c in zip(dets, counts)]
+        wb, wsc, wl = oracle([x.tolist() for x in bl], [x.tolist() for x in sl], [x.tolist() for x in ll], weights=None,
+                             iou_thr=0.67, skip_box_thr=0.01)
+        k = int(gc[b])
+        assert k == len(wsc), f'image {b}: {k} fused boxes, oracle {len(wsc)}'
+        assert np.array_equal(gl[b, :k], np.asarray(wl).astype(np.int32))
+        assert np.array_equal(gb[b, :k], np.asarray(wb, dtype=np.float64).reshape(-1, 4).astype(np.float32))
+        assert np.array_equal(gs[b, :k], np.asarray(wsc).astype(np.float32))
+
+
 def test_repulsion_matches_reference_vector(golden):
     """RepGT / RepBox (utils/RepulsionLoss.py:47-95) against the value the reference's own function produced."""
     from somi_amd.loss import repulsion_loss

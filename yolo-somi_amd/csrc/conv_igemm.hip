@@ -376,14 +376,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[jn][i][e] = 0.f;
 
-        auto mma_group = [&](const float *buf, int j) {
-            f32x4 fa[TM], fb[TN];
+        // Operand fragments are double buffered in registers: group j+1's three ds_read_b128 are issued BEFORE group j's MFMAs, so a
+        // wave never sits on an LDS round trip between groups (round 2's loop read each group's fragments right before using them: four
+        // exposed LDS latencies per K-tile per wave, and the two waves a workgroup puts on a SIMD hit them together).
+        auto load_frag = [&](const float *buf, int j, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(buf + aw_off + i * 32 * LDS_LD + j * 8);
 #pragma unroll
             for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const f32x4 *>(buf + bw_off + i * 32 * LDS_LD + j * 8);
+        };
+        auto mma_steps = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], int t_lo, int t_hi) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = t_lo; t < t_hi; ++t)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
@@ -396,20 +400,34 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
             store_tile(lds);
         }
         __syncthreads();
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        if (kt1 > kt0) load_frag(lds, 0, fa0, fb0);
         for (int kt = kt0; kt < kt1; ++kt) {
             const float *cur = lds + ((kt - kt0) & 1) * TILE;
             float *nxt = lds + ((kt - kt0 + 1) & 1) * TILE;
             const bool more = kt + 1 < kt1;
-            mma_group(cur, 0);
+            load_frag(cur, 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_steps(fa0, fb0, 0, 4);
             if (more) {
                 advance_k();
                 fetch_tile(kt + 1);    // in flight behind the next two MFMA groups
             }
-            mma_group(cur, 1);
-            mma_group(cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(cur, 2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_steps(fa1, fb1, 0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(cur, 3, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_steps(fa0, fb0, 0, 4);
             if (more) store_tile(nxt); // the other buffer: nobody reads it during this K-tile
-            mma_group(cur, 3);
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            mma_steps(fa1, fb1, 0, 1);
+            __syncthreads();           // every wave has read `cur` for the last time and stored its part of `nxt`
+            if (more) load_frag(nxt, 0, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_steps(fa1, fb1, 1, 4);
         }
 
         if (!sk || (kt0 == 0 && kt1 == nkt)) {

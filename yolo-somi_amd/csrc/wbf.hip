@@ -30,7 +30,7 @@ struct WbfArgs {
 
 __device__ __forceinline__ double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
 
-__global__ __launch_bounds__(256) void wbf_kernel(const WbfArgs a) {
+__device__ __forceinline__ void wbf_image(const WbfArgs &a) {
     __shared__ int first_idx[WBF_MAX_LABELS];      // first appearance (member index) of each label, or INT_MAX
     __shared__ int lab_cnt[WBF_MAX_LABELS];
     __shared__ int lab_seq[WBF_MAX_LABELS];        // labels in first-appearance order
@@ -183,7 +183,65 @@ __global__ __launch_bounds__(256) void wbf_kernel(const WbfArgs a) {
     if (tid == 0) *a.out_count = ntot;
 }
 
+__global__ __launch_bounds__(256) void wbf_kernel(const WbfArgs a) { wbf_image(a); }
+
+// Batched form for val.py-style pipelines (BASELINE configs[4]: NMS + WBF over the detections of several models): one workgroup per
+// image.  The image's members are the NMS rows of model 0, then model 1, ... (the order wbf.py:44-59 appends them in), boxes scaled
+// to [0,1] by the image size and clipped; everything after that is wbf_image() on the image's own slice of the workspace.
+struct WbfBatchArgs {
+    const float *det[16];        // per model (B, max_det, 6) [x1,y1,x2,y2,conf,cls] in pixels
+    const int32_t *count[16];    // per model (B)
+    int B, max_det, n_models;
+    float img_w, img_h;          // true division like the caller's `boxes / size` (a reciprocal multiply differs in the last bit)
+    WbfArgs img;                 // pointers of image 0; image b uses the same arrays at offset b * N (N = n_models * max_det)
+    float *in_boxes, *in_scores; // workspace: the gathered members
+    int32_t *in_labels, *in_model;
+};
+
+__global__ __launch_bounds__(256) void wbf_batch_kernel(const WbfBatchArgs g) {
+    const int b = blockIdx.x, N = g.n_models * g.max_det;
+    const size_t o = (size_t)b * N;
+    float *boxes = g.in_boxes + o * 4, *scores = g.in_scores + o;
+    int32_t *labels = g.in_labels + o, *model = g.in_model + o;
+    int n = 0;
+    for (int t = 0; t < g.n_models; ++t) {
+        int c = g.count[t][b];
+        c = c < 0 ? 0 : (c > g.max_det ? g.max_det : c);
+        const float *d = g.det[t] + (size_t)b * g.max_det * 6;
+        for (int i = threadIdx.x; i < c; i += 256) {
+            boxes[(n + i) * 4 + 0] = fminf(fmaxf(d[i * 6 + 0] / g.img_w, 0.f), 1.f);
+            boxes[(n + i) * 4 + 1] = fminf(fmaxf(d[i * 6 + 1] / g.img_h, 0.f), 1.f);
+            boxes[(n + i) * 4 + 2] = fminf(fmaxf(d[i * 6 + 2] / g.img_w, 0.f), 1.f);
+            boxes[(n + i) * 4 + 3] = fminf(fmaxf(d[i * 6 + 3] / g.img_h, 0.f), 1.f);
+            scores[n + i] = d[i * 6 + 4];
+            labels[n + i] = (int32_t)d[i * 6 + 5];
+            model[n + i] = t;
+        }
+        n += c;
+    }
+    __syncthreads();
+    WbfArgs a = g.img;
+    a.boxes = boxes; a.scores = scores; a.labels = labels; a.model = model; a.n = n;
+    a.out_boxes += o * 4; a.out_scores += o; a.out_labels += o; a.out_count += b;
+    a.mx1 += o; a.my1 += o; a.mx2 += o; a.my2 += o; a.msc += o; a.mwt += o;
+    a.mlab += o; a.mvalid += o; a.order += o;
+    a.cx1 += o; a.cy1 += o; a.cx2 += o; a.cy2 += o; a.cscore += o; a.cconf += o; a.cwsum += o;
+    a.cacc += o * 4; a.ccnt += o; a.clab += o; a.final_rank += o;
+    wbf_image(a);
+}
+
 static size_t al8(size_t v) { return (v + 255) / 256 * 256; }
+
+// carve the per-member / per-cluster arrays (N entries each) out of `w`
+static char *carve(WbfArgs &a, char *w, size_t N) {
+    auto take = [&](size_t bytes) { char *p = w; w += al8(bytes); return p; };
+    double **d64[] = {&a.mx1, &a.my1, &a.mx2, &a.my2, &a.msc, &a.mwt, &a.cx1, &a.cy1, &a.cx2, &a.cy2, &a.cscore, &a.cconf, &a.cwsum};
+    for (auto pp : d64) *pp = reinterpret_cast<double *>(take(N * 8));
+    int **i32[] = {&a.mlab, &a.mvalid, &a.order, &a.ccnt, &a.clab, &a.final_rank};
+    for (auto pp : i32) *pp = reinterpret_cast<int *>(take(N * 4));
+    a.cacc = reinterpret_cast<float *>(take(N * 16));
+    return w;
+}
 
 }  // namespace somi
 
@@ -209,14 +267,44 @@ extern "C" int somi_wbf_f32(const float *boxes, const float *scores, const int32
     for (int i = 0; i < 16; ++i) a.weights[i] = i < n_models ? (weights_host ? weights_host[i] : 1.f) : 0.f;
     a.iou_thr = iou_thr; a.skip_thr = skip_box_thr;
     a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_labels = out_labels; a.out_count = out_count;
-    char *w = static_cast<char *>(workspace);
-    const size_t N = (size_t)(n > 0 ? n : 1);
-    auto take = [&](size_t bytes) { char *p = w; w += al8(bytes); return p; };
-    double **d64[] = {&a.mx1, &a.my1, &a.mx2, &a.my2, &a.msc, &a.mwt, &a.cx1, &a.cy1, &a.cx2, &a.cy2, &a.cscore, &a.cconf, &a.cwsum};
-    for (auto pp : d64) *pp = reinterpret_cast<double *>(take(N * 8));
-    int **i32[] = {&a.mlab, &a.mvalid, &a.order, &a.ccnt, &a.clab, &a.final_rank};
-    for (auto pp : i32) *pp = reinterpret_cast<int *>(take(N * 4));
-    a.cacc = reinterpret_cast<float *>(take(N * 16));
+    carve(a, static_cast<char *>(workspace), (size_t)(n > 0 ? n : 1));
     hipLaunchKernelGGL(wbf_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return launch_status("somi_wbf_f32");
+}
+
+extern "C" size_t somi_wbf_batch_workspace_bytes(int B, int max_det, int n_models) {
+    if (B <= 0 || max_det <= 0 || n_models <= 0) return 256;
+    const size_t T = (size_t)B * max_det * n_models;
+    return somi_wbf_workspace_bytes((int)T) + al8(T * 16) + 3 * al8(T * 4);
+}
+
+extern "C" int somi_wbf_batch_f32(const float *const *det, const int32_t *const *count, int B, int max_det, int n_models,
+                                  const float *weights_host, float img_w, float img_h, float iou_thr, float skip_box_thr,
+                                  float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_count, void *workspace,
+                                  size_t workspace_bytes, somi_stream_t stream) {
+    SOMI_REQUIRE(det && count && out_boxes && out_scores && out_labels && out_count && workspace, SOMI_EINVAL, "wbf batch: null argument");
+    SOMI_REQUIRE(B > 0 && max_det > 0 && n_models >= 1 && n_models <= 16 && img_w > 0.f && img_h > 0.f, SOMI_EINVAL,
+                 "wbf batch: bad sizes (n_models <= 16)");
+    SOMI_REQUIRE((size_t)B * max_det * n_models < (1u << 30), SOMI_EINVAL, "wbf batch: too many boxes");
+    SOMI_REQUIRE(workspace_bytes >= somi_wbf_batch_workspace_bytes(B, max_det, n_models), SOMI_EWORKSPACE, "wbf batch: workspace too small");
+    WbfBatchArgs g{};
+    for (int t = 0; t < n_models; ++t) {
+        SOMI_REQUIRE(det[t] && count[t], SOMI_EINVAL, "wbf batch: null tensor of model %d", t);
+        g.det[t] = det[t];
+        g.count[t] = count[t];
+    }
+    g.B = B; g.max_det = max_det; g.n_models = n_models;
+    g.img_w = img_w; g.img_h = img_h;
+    const size_t T = (size_t)B * max_det * n_models;
+    char *w = carve(g.img, static_cast<char *>(workspace), T);
+    g.in_boxes = reinterpret_cast<float *>(w); w += al8(T * 16);
+    g.in_scores = reinterpret_cast<float *>(w); w += al8(T * 4);
+    g.in_labels = reinterpret_cast<int32_t *>(w); w += al8(T * 4);
+    g.in_model = reinterpret_cast<int32_t *>(w);
+    g.img.n_models = n_models;
+    for (int i = 0; i < 16; ++i) g.img.weights[i] = i < n_models ? (weights_host ? weights_host[i] : 1.f) : 0.f;
+    g.img.iou_thr = iou_thr; g.img.skip_thr = skip_box_thr;
+    g.img.out_boxes = out_boxes; g.img.out_scores = out_scores; g.img.out_labels = out_labels; g.img.out_count = out_count;
+    hipLaunchKernelGGL(wbf_batch_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return launch_status("somi_wbf_batch_f32");
 }

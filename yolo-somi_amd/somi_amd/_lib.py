@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SOMI_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 9          # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
+ABI_VERSION = 10         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
 
@@ -148,6 +148,8 @@ SIGNATURES = {
     'somi_wbf_workspace_bytes': (Z, [I]),
     'somi_augment_u8': (I, [P, I, I, I, I, P, S]),
     'somi_wbf_f32': (I, [P, P, P, P, I, I, C.POINTER(C.c_float), F, F, P, P, P, P, P, Z, S]),
+    'somi_wbf_batch_workspace_bytes': (Z, [I, I, I]),
+    'somi_wbf_batch_f32': (I, [C.POINTER(P), C.POINTER(P), I, I, I, C.POINTER(C.c_float), F, F, F, F, P, P, P, P, P, Z, S]),
 }
 
 _lib = None
@@ -161,10 +163,13 @@ def lib():
             raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                f'(or `make -C yolo-somi_amd/csrc`). There is no CPU fallback.')
         L = C.CDLL(LIB_PATH)
+        lax = bool(os.environ.get('SOMI_HIP_LIB')) and os.environ.get('SOMI_HIP_LIB_LAX') == '1'   # kernel A/B runs against an older build
         for name, (res, args) in SIGNATURES.items():
+            if lax and not hasattr(L, name):
+                continue
             fn = getattr(L, name)            # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
-        if L.somi_abi_version() != ABI_VERSION:
+        if L.somi_abi_version() != ABI_VERSION and not lax:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -13,6 +13,15 @@ from .ops import _ptr, _stream
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                         labels=(), max_det=300):
+    det, count = non_max_suppression_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det)
+    counts = count.cpu().tolist()
+    return [det[b, :counts[b]] for b in range(det.shape[0])]
+
+
+def non_max_suppression_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                            labels=(), max_det=300):
+    """Same selection, left on the device: det (B, max_det, 6) and count (B) int32 - no host synchronisation, so a following device
+    step (wbf.weighted_boxes_fusion_batch) can consume them stream-ordered."""
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
     if not prediction.is_cuda:
@@ -51,5 +60,4 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     count = torch.empty(B, dtype=torch.int32, device=prediction.device)
     check(L.somi_nms_f32(_ptr(prediction), B, n, nc, float(conf_thres), float(iou_thres), int(ml), int(bool(agnostic)), mask,
                          int(max_det), _ptr(det), _ptr(count), _ptr(ws), nbytes, _stream()), 'non_max_suppression')
-    counts = count.cpu().tolist()
-    return [det[b, :counts[b]] for b in range(B)]
+    return det, count

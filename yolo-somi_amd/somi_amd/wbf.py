@@ -48,3 +48,33 @@ def weighted_boxes_fusion(boxes_list, scores_list, labels_list, weights=None, io
                          _ptr(ob), _ptr(osc), _ptr(ol), _ptr(cnt), _ptr(ws), nbytes, _stream()), 'weighted_boxes_fusion')
     k = int(cnt.item())
     return ob[:k].cpu().numpy(), osc[:k].cpu().numpy(), ol[:k].cpu().numpy().astype(np.float64)
+
+
+def weighted_boxes_fusion_batch(dets, counts, img_size, weights=None, iou_thr=0.55, skip_box_thr=0.0):
+    """wbf.py:44-68 for a whole batch on the device.  dets[t] (B, max_det, 6) / counts[t] (B) = nms.non_max_suppression_raw of model t
+    (pixels); img_size = (width, height) the boxes are normalised by.  Returns device tensors (boxes (B,N,4) in [0,1], scores (B,N),
+    labels (B,N) int32, count (B) int32), N = len(dets) * max_det; row order per image = descending fused score.  No host sync."""
+    nm = len(dets)
+    if nm < 1 or nm != len(counts):
+        raise ValueError('one (det, count) pair per model')
+    B, max_det, six = dets[0].shape
+    for d, c in zip(dets, counts):
+        if not d.is_cuda or d.dtype != torch.float32 or not d.is_contiguous() or d.shape != (B, max_det, 6):
+            raise RuntimeError('det tensors have to be contiguous float32 (B, max_det, 6) on the MI355X')
+        if not c.is_cuda or c.dtype != torch.int32 or c.shape != (B,):
+            raise RuntimeError('count tensors have to be int32 (B) on the MI355X')
+    dev = dets[0].device
+    N = nm * max_det
+    L = _lib.lib()
+    nbytes = L.somi_wbf_batch_workspace_bytes(B, max_det, nm)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ob = torch.empty(B, N, 4, dtype=torch.float32, device=dev)
+    osc = torch.empty(B, N, dtype=torch.float32, device=dev)
+    ol = torch.empty(B, N, dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    w = (C.c_float * nm)(*[float(v) for v in (weights if weights is not None and len(weights) == nm else [1.0] * nm)])
+    dp = (C.c_void_p * nm)(*[_ptr(d) for d in dets])
+    cp = (C.c_void_p * nm)(*[_ptr(c) for c in counts])
+    check(L.somi_wbf_batch_f32(dp, cp, B, max_det, nm, w, float(img_size[0]), float(img_size[1]), float(iou_thr), float(skip_box_thr),
+                               _ptr(ob), _ptr(osc), _ptr(ol), _ptr(cnt), _ptr(ws), nbytes, _stream()), 'weighted_boxes_fusion_batch')
+    return ob, osc, ol, cnt
