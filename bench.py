@@ -321,9 +321,17 @@ def main():
     # timed region, collective over all ranks
     exchange = None
     if (world > 1 or rehearsal) and args.mode == 'train' and trainer.buckets is not None:
+        # one more, instrumented, step: HIP events around every bucket on the side stream against the end of the backward pass on the
+        # compute stream - whether the side-stream overlap works, not only that it ran
+        trainer.buckets.timing = True
+        step()
+        torch.cuda.synchronize()
+        ov = trainer.buckets.overlap_stats()
+        trainer.buckets.timing = False
         secs, nbytes = trainer.buckets.measure_exchange(iters=5)
         alg = nbytes / secs / 1e9
         exchange = {'bytes': nbytes, 'buckets': sum(len(c) for c in trainer.buckets.buckets), 'ms': round(secs * 1e3, 3),
+                    'overlap_frac': None if ov is None else round(ov[0], 4), 'in_step_exchange_ms': None if ov is None else round(ov[1], 3),
                     'algbw_GBps': round(alg, 1), 'busbw_GBps': round(alg * 2 * (world - 1) / world, 1),
                     'xgmi_peak_GBps_per_gpu': XGMI_LINKS * XGMI_LINK_GBPS, 'backend': backend, 'ranks': dist.get_world_size(),
                     'note': 'bucketed SUM all-reduce of the flat fp32 gradient buffers, not overlapped with anything'}

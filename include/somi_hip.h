@@ -295,10 +295,12 @@ int somi_bn_stats_partials_f32(const float *part_sum, const float *part_sumsq, i
                                float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
 /* SyncBatchNorm (reference train.py:165-167, torch.nn.SyncBatchNorm.convert_sync_batchnorm under --sync-bn): the statistics of a
  * BatchNorm layer over the batches of ALL ranks.  The library has no communicator: the caller exchanges one small record per layer.
- *   forward   somi_bn_local_sums_f64 -> record [2*C + 1] doubles {sum(x - pivot), sum((x - pivot)^2), pixel count} of this rank, from x
- *             or (part_sum != NULL) from a convolution's partial rows; pivot = the running mean, equal on every rank.
- *             all-gather the records ([nranks][2*C + 1]); somi_bn_stats_from_sums_f64 adds them in rank order (identical results
- *             on every rank) -> mean / rstd / scale / shift and the running statistics (unbiased variance over the global count).
+ *   forward   somi_bn_local_sums_f64 -> record [2*C + 1] doubles {mean_r, M2_r = sum (x - mean_r)^2, pixel count} of this rank, from x
+ *             or (part_sum != NULL) from a convolution's partial rows (taken around `pivot` there); the record itself is pivot-free,
+ *             so ranks whose running means have drifted apart still combine correctly.
+ *             all-gather the records ([nranks][2*C + 1]); somi_bn_stats_from_sums_f64 combines them in rank order (parallel-variance
+ *             formula in double; identical results on every rank) -> mean / rstd / scale / shift and the running statistics
+ *             (unbiased variance over the global count).
  *   backward  somi_bn_act_backward_sums_f64 -> record {sum d, sum d*(v - mean), count}; all-gather; ..._apply_sync_f32 builds the
  *             input gradient from the global sums and ACCUMULATES dgamma / dbeta from the LOCAL ones (the gradient exchange sums them).
  * workspace: max(2*1024*C, 2*somi_red_nchunk(npix)*C) floats (sums), 3*C floats (apply). */

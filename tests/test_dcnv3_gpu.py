@@ -400,11 +400,15 @@ def test_import_DCNv3_resolves_to_the_drop_in_module_and_custom_ops(golden):
                                                            (3, 21, 17, 4, 8, 3, 2, 1, 1, 1.0, 0.8),      # stride 2
                                                            (1, 24, 24, 2, 64, 3, 1, 2, 2, 1.0, 0.7),     # dilation 2, 64-wide groups
                                                            (2, 19, 23, 2, 16, 5, 1, 2, 1, 1.0, 0.6),     # 5x5
-                                                           (2, 33, 33, 8, 32, 3, 1, 1, 1, 1.0, 6.0)])    # most taps beyond the window
+                                                           (2, 33, 33, 8, 32, 3, 1, 1, 1, 1.0, 3.0),     # half the taps leave the window, all NEAR (MFMA form)
+                                                           (2, 37, 29, 4, 16, 3, 1, 1, 1, 1.0, 3.0),     # ... the list form, ragged tiles
+                                                           (2, 26, 41, 2, 64, 3, 1, 1, 1, 2.0, 2.5),     # ... 64-wide groups, offset_scale 2
+                                                           (2, 33, 33, 8, 32, 3, 1, 1, 1, 1.0, 14.0)])   # most taps beyond the window, many FAR
 def test_dcnv3_backward_windowed_form(N, H, W, G, Gc, k, s, p, d, osc, spread):
-    """The windowed backward (grad_input summed per tile in LDS in exact arithmetic, staged, combined in a fixed order) against the
-    CPU oracle's autograd, against the direct fp32-atomic form, and against itself: two launches are bit-identical when no tap left
-    its window."""
+    """The windowed backward (grad_input summed per tile in LDS, staged, combined in a fixed order; taps that leave their tile's window
+    but land within two tiles of it added by the owner-of-the-destination pass) against the CPU oracle's autograd, against the direct
+    fp32-atomic form, and against itself: two launches are bit-identical whenever no tap went FARTHER than that - in particular at
+    offsets of several pixels, which a trained offset branch produces (round 2 was only reproducible inside 2 px)."""
     from oracle.somi_ref import dcnv3 as O
     from somi_amd import ops
     from somi_amd.dcnv3 import dcnv3_backward
@@ -415,6 +419,8 @@ def test_dcnv3_backward_windowed_form(N, H, W, G, Gc, k, s, p, d, osc, spread):
     off = torch.randn(N, Ho, Wo, G * K * 2, generator=g) * spread
     if spread < 1.0:
         off.clamp_(-1.9 / osc, 1.9 / osc)                        # stay inside the window's 2 pixels of slack
+    elif spread < 8.0:
+        off.clamp_(-11.0 / osc, 11.0 / osc)                      # beyond the window, but never more than two 8-pixel tiles away
     m = torch.softmax(torch.randn(N, Ho, Wo, G, K, generator=g), -1).reshape(N, Ho, Wo, G * K)
     go = torch.randn(N, Ho, Wo, G * Gc, generator=g)
     go[0, :3] = 0                                               # an all-zero tile
@@ -429,8 +435,8 @@ def test_dcnv3_backward_windowed_form(N, H, W, G, Gc, k, s, p, d, osc, spread):
     b = dcnv3_backward(*args)
     if over is None:
         pass
-    elif spread < 1.0:
-        assert over == 0, f'{over} taps left their window at offsets ~N(0,{spread})'
+    elif spread < 8.0:
+        assert over == 0, f'{over} taps went through fp32 atomics at offsets ~N(0,{spread})'
         assert all(torch.equal(u, v) for u, v in zip(a, b)), 'two launches of the windowed backward differ'
     else:
         assert over > 0

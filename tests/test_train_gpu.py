@@ -223,17 +223,84 @@ def _train_cfg(odconv):
     return cfg
 
 
+def _conditioned_gradient_check(mine, ref32, ref64, sums, what, k_over_cpu=4.0, c_floor=64.0, rel=1e-3):
+    """The full-size gradient bar, conditioning-aware and without name patterns.
+
+    For every parameter element e:   |g - g64|_e  <=  rel * max|g64|  +  c * 2^-24 * S_e ,   S_e = sum |terms| of that gradient element
+    (measured in the fp64 oracle pass, oracle.somi_ref.testing.AbsTermSums).  The first term is BASELINE's relative bar; the second
+    is what ANY fp32 realisation of an ill-conditioned sum may be off by.  c is not free: it is calibrated on the fp32 CPU oracle run
+    on the same inputs - c_cpu = the smallest c with which the fp32 CPU path itself passes on EVERY parameter (the depth of the graph
+    amplifies each layer's fp32 rounding into the terms of the next) - and the HIP path must pass with c = max(c_floor, k * c_cpu).
+    A parameter therefore passes because its sum is ill-conditioned by a measured factor, never because of its name; an indexing or
+    layout mistake moves a gradient by O(|g|) on a well-conditioned parameter (S ~ |g|), i.e. by ~1e6 units of 2^-24 S."""
+    from oracle.somi_ref.testing import conditioned_errors
+    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+    for n, p in mine.named_parameters():
+        assert (p.grad is not None) == (n in g64), f'{what}: {n} gradient presence differs from the oracle'
+    hip = conditioned_errors([(n, p.grad) for n, p in mine.named_parameters() if p.grad is not None], g64, sums, rel=rel)
+    cpu = conditioned_errors([(n, p.grad) for n, p in ref32.named_parameters() if p.grad is not None], g64, sums, rel=rel)
+    assert len(hip) == len(g64), f'{what}: {len(g64) - len(hip)} parameters without a measured S'
+    c_cpu = max(t[1] for t in cpu)
+    c_allowed = max(c_floor, k_over_cpu * c_cpu)
+    worst = sorted(hip, key=lambda t: -t[1])[:6]
+    rm, rc = torch.tensor([t[2] for t in hip]), torch.tensor([t[2] for t in cpu])
+    print(f'{what}: c needed HIP {worst[0][1]:.1f} ({worst[0][0]}), fp32 CPU {c_cpu:.1f}; relative error HIP median {float(rm.median()):.2e} '
+          f'q90 {float(rm.quantile(0.9)):.2e}; fp32 CPU median {float(rc.median()):.2e} q90 {float(rc.quantile(0.9)):.2e}')
+    bad = [(n, round(c, 1), f'{r:.2e}', f'{cond:.1e}') for n, c, r, cond in hip if c > c_allowed]
+    assert not bad, f'{what}: beyond rel {rel} + {c_allowed:.0f} * 2^-24 * S (fp32 CPU needs c = {c_cpu:.1f}): {bad[:8]}'
+    # the population must not be systematically worse than the CPU path either (a uniformly less accurate kernel would pass the per-element bar)
+    assert rm.median() <= max(k_over_cpu * float(rc.median()), 1e-3), (float(rm.median()), float(rc.median()))
+    assert rm.quantile(0.9) <= max(k_over_cpu * float(rc.quantile(0.9)), 3e-3), (float(rm.quantile(0.9)), float(rc.quantile(0.9)))
+
+
+def test_cbam_block_backward_isolated_at_320():
+    """Layer-isolated check at the map size where the full-size attention gradients are ill-conditioned: a C2fCBAM block with
+    one 128-channel CBAM bottleneck on 2 x 320 x 320, inputs and the output gradient drawn in fp32 (so fp64 oracle and HIP see the same
+    values - no upstream fp32 noise), against the fp64 oracle.  Everything well-conditioned holds 1e-3 relative; the cancelling sums
+    (the 7x7 spatial-attention conv's bias and weights: 204 800 terms of both signs) are held to a FIXED 16 fp32 roundings of their own
+    terms - an indexing error in spatial_attn_bwd / cbam_bwd at large maps would be ~1e6 of those units."""
+    from oracle.somi_ref import blocks as OB
+    from oracle.somi_ref.testing import AbsTermSums, conditioned_errors, fill_state
+    from somi_amd import blocks as MB
+    torch.set_num_threads(16)
+    g = torch.Generator().manual_seed(5)
+    ref = fill_state(OB.C2fCBAM(256, 256, 1, True), 6)
+    OB.initialize_weights(ref)
+    mine = MB.C2fCBAM(256, 256, 1, True)
+    mine.load_state_dict(ref.state_dict())
+    for m in mine.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    x = torch.randn(2, 256, 320, 320, generator=g)
+    dy = torch.randn(2, 256, 320, 320, generator=g)
+    ref64 = ref.double().train()
+    x64 = x.double().requires_grad_(True)
+    with AbsTermSums(ref64) as cond:
+        y64 = ref64(x64)
+        y64.backward(dy.double())
+    mine = mine.cuda().train()
+    out = mine(MB.Act(nhwc(x).cuda()))
+    rel_close(out.t[..., out.coff:out.coff + out.c], nhwc(y64.detach()), what='C2fCBAM @320 forward')
+    dx = mine.backward(MB.Act(nhwc(dy).cuda()))
+    rel_close(dx.t[..., :256], nhwc(x64.grad), what='C2fCBAM @320 dx')
+    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+    res = conditioned_errors([(n, p.grad) for n, p in mine.named_parameters() if p.grad is not None], g64, cond.sums)
+    assert len(res) == len(g64)
+    print('C2fCBAM @320 isolated: ' + ', '.join(f'{n.split(".", 1)[-1]} rel {r:.1e} cond {c:.0e} c {u:.1f}' for n, u, r, c in res if 'attention' in n))
+    bad = [(n, round(u, 1), f'{r:.2e}', f'{c:.1e}') for n, u, r, c in res if u > 16.0]
+    assert not bad, f'beyond 1e-3 relative + 16 * 2^-24 * sum|terms|: {bad}'
+
+
 def test_full_width_model_train_step_gradients():
     """The real yolov5l-SOMI widths (77.5 M parameters; head convs 256->177->98 stored as 192 / 128 channels, 1024-wide SPPF,
-    per-sample ODConv weights of 512->256) through loss.backward() at 128x128, batch 2.  At this depth with batch statistics
-    over as few as 32 values the fp32 CPU oracle itself is up to 1.4e-2 away from its own fp64 run, so the yardstick is the
-    fp64 oracle (the network with these random weights is that ill-conditioned: at 256x256 the fp32 oracle's median error
-    grows to 1e-2): as a population (median, 90th percentile, maximum of the per-parameter relative errors) the HIP gradients
-    must stay within a small factor of what the fp32 CPU gradients themselves are off."""
+    per-sample ODConv weights of 512->256) through loss.backward() at 128x128, batch 2, against the fp64 oracle.  At this depth with
+    batch statistics over as few as 32 values the fp32 CPU oracle itself is up to 1.4e-2 away from its own fp64 run, so a plain
+    relative bar is meaningless; the bar is the conditioning-aware one of _conditioned_gradient_check (every parameter: 1e-3 relative
+    plus a measured multiple of one fp32 rounding of its own terms, the multiple calibrated on the fp32 CPU path)."""
     import copy
     from oracle.somi_ref import Model as OModel
     from oracle.somi_ref.loss import ComputeLoss as OLoss
-    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
+    from oracle.somi_ref.testing import SOMI_ANCHORS, AbsTermSums, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
     from somi_amd.loss import ComputeLoss
     from somi_amd.model import Model
     cfg = somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS)
@@ -246,32 +313,14 @@ def test_full_width_model_train_step_gradients():
     ref.train(), ref64.train()
     l32, _ = OLoss(ref)(ref(imgs.float() / 255), targets)
     l32.backward()
-    l64, _ = OLoss(ref64)(ref64(imgs.double() / 255), targets.double())
-    l64.backward()
+    with AbsTermSums(ref64) as cond:
+        l64, _ = OLoss(ref64)(ref64(imgs.double() / 255), targets.double())
+        l64.backward()
     mine = mine.cuda().train()
     lm, _ = ComputeLoss(mine)(mine(imgs.cuda()), targets.cuda())
     rel_close(lm, l64.detach().float(), rel=1e-4, what='loss')
     lm.backward()
-    rel_mine, rel_o32, bad = [], [], []
-    for (n, p), (_, q32), (_, q64) in zip(mine.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
-        if q64.grad is None:
-            continue
-        assert p.grad is not None, n
-        g64 = q64.grad
-        scale = g64.abs().max().item() + 1e-12
-        if scale < 1e-4:                                          # gradients that are zero up to rounding (exact cancellations)
-            continue
-        rel_mine.append((p.grad.cpu().double() - g64).abs().max().item() / scale)
-        rel_o32.append((q32.grad.double() - g64).abs().max().item() / scale)
-        if rel_mine[-1] > 0.5:                                    # a layout / indexing mistake is O(1) on the parameter it touches
-            bad.append((n, rel_mine[-1], rel_o32[-1]))
-    assert not bad, bad[:8]
-    rm, ro = torch.tensor(rel_mine), torch.tensor(rel_o32)
-    # The error is noise, not bias: over three input seeds the medians were HIP 3.6e-3 / 3.0e-2 / 3.2e-3 against fp32-CPU
-    # 9.0e-4 / 6.3e-2 / 2.3e-3 (the CPU's own error moves 70x with the seed).  Tight bars live in the block-level tests; this one
-    # guards the full-width code paths: nothing O(1) on any parameter, and the population within reach of the CPU's own noise.
-    assert rm.median() <= max(4 * float(ro.median()), 1e-2), (float(rm.median()), float(ro.median()))
-    assert rm.quantile(0.9) <= max(4 * float(ro.quantile(0.9)), 3e-2), (float(rm.quantile(0.9)), float(ro.quantile(0.9)))
+    _conditioned_gradient_check(mine, ref, ref64, cond.sums, 'full width @128')
 
 
 @pytest.mark.parametrize('odconv', [False, True])
@@ -684,12 +733,13 @@ def test_training_step_is_bit_reproducible(graph):
                      'somi_dcn_w025': (somi_cfg(0.25, 0.33, anchors=SOMI_ANCHORS, dcn=True), 4, 128, 10)}[graph]
     model = fill_state(Model(cfg), 5)
     if graph == 'somi_dcn_w025':
-        # the DCNv3 backward is bit-reproducible while every sampling tap stays inside its tile's window (2 pixels of slack around the
-        # kernel footprint; taps beyond go through fp32 atomics like the reference's kernel): keep the learned offsets small
+        # fill_state's offset branch already throws taps beyond the 2-pixel window slack; scale it up further (x3: offsets of several
+        # pixels, more than the 300-step soak run reached) - the near pass of the DCNv3 backward adds those in a fixed order, so the step
+        # stays bit-reproducible.  The assertion on the far-tap counter below proves that no float atomic ran.
         with torch.no_grad():
             for m_ in model.modules():
                 if type(m_).__name__ == 'DCNv3':
-                    m_.offset.weight.mul_(0.2), m_.offset.bias.mul_(0.2)
+                    m_.offset.weight.mul_(3.0), m_.offset.bias.mul_(3.0)
     model = model.cuda()
     tr = TrainStep(model, dict(HYP_VISDRONE), B)
     imgs, targets = synthetic_batch(B, S, nc=nc, seed=8)
@@ -721,7 +771,7 @@ def test_training_step_is_bit_reproducible(graph):
     a, b = runs
     if graph == 'somi_dcn_w025':
         from somi_amd import ops
-        assert ops.dcn_overflow_taps() == 0, 'sampling taps left their window: this run exercises the atomic fallback, not the claim'
+        assert ops.dcn_overflow_taps() == 0, 'sampling taps went farther than the near pass reaches: this run exercises the atomic fallback, not the claim'
 
     def first_difference(x, y, st):
         idx = int((x != y).nonzero()[0])
@@ -738,19 +788,20 @@ def test_training_step_is_bit_reproducible(graph):
 
 
 def test_uavdt_1280_nc3_training_step_gradients():
-    """BASELINE configs[3] per-GPU shape: full-width SOMI, nc=3 (UAVDT), 1280x1280 - grids 320/160/80/40 - one training step at batch 2
-    (the squeeze BN of ODConv needs more than one sample): loss against the fp64 CPU oracle at 1e-4, train-mode outputs within 4x of
-    the fp32 CPU oracle's own distance from fp64 (36 layers deep, both fp32 paths sit 1e-3 ... 3e-3 of the output range from fp64),
-    and every parameter gradient judged as in test_full_width_model_train_step_gradients: nothing O(1) anywhere, and the population of
-    relative errors (against fp64) within a small factor of what the fp32 CPU oracle itself is off."""
+    """BASELINE configs[3] per-GPU shape: full-width SOMI WITH its DCNv3 sites (160^2 and 320^2 here), nc=3 (UAVDT), 1280x1280 - grids
+    320/160/80/40 - one training step at batch 2 (the squeeze BN of ODConv needs more than one sample): loss against the fp64 CPU oracle
+    at 1e-4, train-mode outputs within 4x of the fp32 CPU oracle's own distance from fp64 (38 layers deep, both fp32 paths sit 1e-3 ...
+    3e-3 of the output range from fp64), and every parameter gradient under the conditioning-aware bar of _conditioned_gradient_check -
+    no parameter is exempt by name: the CBAM attention gradients that are sums of 10^5 cancelling terms pass because their measured
+    sum |terms| is 10^3 ... 10^5 times the gradient, or they fail."""
     import copy
     from oracle.somi_ref import Model as OModel
     from oracle.somi_ref.loss import ComputeLoss as OLoss
-    from oracle.somi_ref.testing import SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
+    from oracle.somi_ref.testing import SOMI_ANCHORS, AbsTermSums, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
     from somi_amd.loss import ComputeLoss
     from somi_amd.model import Model
     torch.set_num_threads(16)
-    cfg = somi_cfg(1.0, 1.0, nc=3, anchors=SOMI_ANCHORS)
+    cfg = somi_cfg(1.0, 1.0, nc=3, anchors=SOMI_ANCHORS, dcn=True)
     ref = fill_state(OModel(cfg), 6)
     mine = Model(cfg)
     mine.load_state_dict(ref.state_dict())
@@ -764,9 +815,10 @@ def test_uavdt_1280_nc3_training_step_gradients():
     torch.cuda.synchronize()
     assert [tuple(p.shape) for p in pm] == [(2, 4, g, g, 8) for g in (320, 160, 80, 40)]
     ref64.train()
-    p64 = ref64(imgs.double() / 255)
-    l64, _ = OLoss(ref64)(p64, targets.double())
-    l64.backward()
+    with AbsTermSums(ref64) as cond:
+        p64 = ref64(imgs.double() / 255)
+        l64, _ = OLoss(ref64)(p64, targets.double())
+        l64.backward()
     rel_close(lm, l64.detach().float(), rel=1e-4, what='loss @1280 nc=3')
     ref.train()
     p32 = ref(imgs.float() / 255)
@@ -779,35 +831,4 @@ def test_uavdt_1280_nc3_training_step_gradients():
         e_o32 = (b32.detach().double() - b64).abs().max().item() / scale
         assert e_mine <= max(4 * e_o32, 1e-3), f'train outputs @1280: HIP {e_mine:.2e} vs fp32 CPU {e_o32:.2e} (relative to fp64)'
     del p64, p32
-    rel_mine, rel_o32, bad = [], [], []
-    for (n, p), (_, q32), (_, q64) in zip(mine.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
-        if q64.grad is None:
-            continue
-        assert p.grad is not None, n
-        g64 = q64.grad
-        scale = g64.abs().max().item() + 1e-12
-        if scale < 1e-4:
-            continue
-        rel_mine.append((p.grad.cpu().double() - g64).abs().max().item() / scale)
-        rel_o32.append((q32.grad.double() - g64).abs().max().item() / scale)
-        # a layout / indexing mistake is O(1) on a parameter the fp32 CPU path gets right; a few attention parameters are sums of
-        # cancelling terms over 10^5 pixels where the fp32 CPU path is itself 0.2 ... 0.7 of the scale away from fp64
-        if rel_mine[-1] > max(0.5, 4 * rel_o32[-1]):
-            bad.append((n, rel_mine[-1], rel_o32[-1]))
-    # ... with one family of exceptions, the parameters inside the CBAM attention blocks on which the fp32 CPU path is ITSELF more than 5 % of
-    # the scale away from fp64 (it is 8 ... 80 % off on the ones that show up here):
-    #  * the first layer of the channel-attention MLPs sits behind a ReLU fed by pooled values; a hidden unit whose pre-activation is within
-    #    rounding of zero has its gate open in one arithmetic and shut in the other, which moves its whole weight row - and, through the
-    #    channel weights, the statistics the spatial attention of the same block sees;
-    #  * the 7x7 spatial-attention conv: its bias gradient is the plain sum of the logit gradients over every pixel of the batch (2 x 320 x 320
-    #    at layer 2), terms of both signs that cancel to a few ulps of their size, and its weight gradients are that same sum weighted by
-    #    the (mostly positive) channel mean / max maps (test_whole_model_train_step_gradients carries an absolute floor for the bias).
-    # The values are stable from run to run and under changes of the accumulation precision of those sums (tried: double), i.e. they are
-    # a different, equally valid, fp32 realisation - not noise of this implementation.
-    gated = [b for b in bad if ('.channel_attention.' in b[0] or '.spatial_attention.' in b[0]) and b[2] > 0.05]
-    assert len(gated) == len(bad) and len(bad) <= max(6, len(rel_mine) // 100), [b for b in bad if b not in gated][:8] or bad[:8]
-    rm, ro = torch.tensor(rel_mine), torch.tensor(rel_o32)
-    print(f'1280 nc=3: HIP median {float(rm.median()):.2e} q90 {float(rm.quantile(0.9)):.2e} max {float(rm.max()):.2e}; '
-          f'fp32 CPU median {float(ro.median()):.2e} q90 {float(ro.quantile(0.9)):.2e} max {float(ro.max()):.2e}')
-    assert rm.median() <= max(4 * float(ro.median()), 1e-2), (float(rm.median()), float(ro.median()))
-    assert rm.quantile(0.9) <= max(4 * float(ro.quantile(0.9)), 3e-2), (float(rm.quantile(0.9)), float(ro.quantile(0.9)))
+    _conditioned_gradient_check(mine, ref, ref64, cond.sums, '1280 nc=3 with DCNv3 sites')

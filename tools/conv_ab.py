@@ -18,6 +18,9 @@ SHAPES = [(32, 160, 128, 128, 3, 1, 6), (32, 80, 256, 256, 3, 1, 12), (32, 40, 5
           (32, 160, 128, 128, 1, 1, 4), (32, 80, 256, 256, 1, 1, 8), (32, 80, 640, 256, 1, 1, 2), (32, 40, 512, 512, 1, 1, 8),
           (32, 160, 64, 128, 3, 2, 1), (32, 80, 256, 512, 3, 2, 2), (32, 320, 64, 64, 3, 1, 2)]
 d = torch.device('cuda')
+if os.environ.get('CONV_AB_N'):                                  # first N shapes only (kernel experiments)
+    SHAPES = SHAPES[:int(os.environ['CONV_AB_N'])]
+KINDS = os.environ.get('CONV_AB_KINDS', 'fwd,dgrad,wgrad').split(',')
 
 
 def t(fn, reps=6):
@@ -44,11 +47,13 @@ for B, H, Cin, Cout, k, s, n in SHAPES:
     for kind, fn in (('fwd', lambda: ops.conv2d_nhwc(x, w, None, kh=k, kw=k, stride=s, pad=p, act='silu')),
                      ('dgrad', lambda: ops.conv2d_dgrad_nhwc(dy, wt, B=B, H=H, W=H, cin=Cin, kh=k, kw=k, stride=s, pad=p)),
                      ('wgrad', lambda: ops.conv2d_wgrad_nhwc(x, dy, kh=k, kw=k, stride=s, pad=p))):
+        if kind not in KINDS:
+            continue
         dt = t(fn)
         tot[kind][0] += fl * n
         tot[kind][1] += dt * n
         print(json.dumps({'lib': tag, 'kind': kind, 'shape': f'B{B} {H}x{H} {Cin}->{Cout} k{k}s{s}', 'us': round(dt * 1e6, 1),
                           'TFLOPs': round(fl / dt / 1e12, 1)}), flush=True)
     del x, w, wt, y, dy
-print(json.dumps({'lib': tag, 'summary_TFLOPs': {k: round(v[0] / v[1] / 1e12, 1) for k, v in tot.items()},
+print(json.dumps({'lib': tag, 'summary_TFLOPs': {k: round(v[0] / v[1] / 1e12, 1) for k, v in tot.items() if v[1]},
                   'all': round(sum(v[0] for v in tot.values()) / sum(v[1] for v in tot.values()) / 1e12, 1)}), flush=True)

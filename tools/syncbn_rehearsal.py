@@ -51,6 +51,11 @@ def conv_chain(rank, world, dev):
             m.eps, m.momentum = 1e-3, 0.03
     mine = mine.to(dev).train()
     ref.train()
+    # the ranks' running means (the pivots their partial sums are taken around) have drifted apart, as they do after the first steps of a
+    # real run: the exchanged records are pivot-free, so the statistics over all ranks must not care (rank 0 keeps the oracle's buffers)
+    with torch.no_grad():
+        for m in mine:
+            m.bn.running_mean += 0.37 * rank
     per = 2
     x = torch.randn(per * world, 16, 14, 10, generator=g, requires_grad=True)
     y = ref(x)
@@ -69,7 +74,8 @@ def conv_chain(rank, world, dev):
         ops.SYNC_BN = None
     close(a.t[..., :20], nhwc(y[lo:hi]), 'sync forward (own slice of the whole batch)')
     for m, r in zip(mine, ref):
-        close(m.bn.running_mean, r.bn.running_mean, 'running_mean over all ranks')
+        if rank == 0:
+            close(m.bn.running_mean, r.bn.running_mean, 'running_mean over all ranks')
         close(m.bn.running_var, r.bn.running_var, 'running_var over all ranks (unbiased over the global count)')
     close(d.t, nhwc(x.grad[lo:hi]), 'sync dx (own slice)')
     for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):

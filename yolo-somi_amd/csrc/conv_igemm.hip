@@ -11,9 +11,11 @@
 //    to an out-of-range offset so the hardware range check returns zeros - no branches, ~40 VALU per K-tile instead
 //    of ~200 with pointer arithmetic (PMC: 4.1 VALU per MFMA before, which phase-locked the two waves of a SIMD into
 //    issuing addresses together while the matrix pipe idled);
-//  * LDS image [row][36] floats (32 k + 4 pad: 16 B-aligned rows, conflict-free ds_write_b128 / ds_read_b128,
-//    SQ_LDS_BANK_CONFLICT = 0), DOUBLE buffered: tile t+1 is fetched to registers after the first quarter of tile t's
-//    MFMAs and written to the other buffer before the last quarter - one barrier per K-tile;
+//  * LDS image [row][32] floats, the eight 16 B chunks of a row XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128 for the
+//    32x32 fragment pattern without padding), DOUBLE buffered, one barrier per K-tile.  The image is lane-linear per wave instruction
+//    (8 rows x 128 B), so the plain FAST path fills it by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR staging, no ds_write pass -
+//    measured round 3: the register-staged write pass cost 5 % of the kernel) with the swizzle on the SOURCE address; the modulated and
+//    generic paths stage through registers into the same image;
 //  * each lane reads 4 consecutive k of one row per ds_read_b128 and feeds them to 4 consecutive MFMA k-steps (the k
 //    order inside a K-tile is permuted identically for both operands: lane half h of k-step t takes k = 8j+4h+t);
 //  * the weights are the MFMA A operand and the activations the B operand, so the accumulator holds D[n][m] with
@@ -38,10 +40,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;                    // K-tile (floats)
-constexpr int LDS_LD = BK + 4;            // LDS row stride in floats (144 B)
+constexpr int LDS_LD = BK + 4;            // sizes the LDS array (the epilogue stages D tiles with this row stride)
+constexpr int OP_LD = BK;                 // operand image row stride in floats (128 B, chunks XOR-swizzled)
 constexpr unsigned OOB = 0xFFFFFFE0u;     // byte offset beyond every descriptor: the load returns 0
 constexpr unsigned OOB_BASE = 0xF0000000u;  // + any K offset (< 2^27) still beyond every descriptor
 constexpr unsigned MAX_BUF_BYTES = 0xE0000000u;
+
+// LDS-DMA: 16 B per lane from a buffer descriptor straight into LDS at `lds_base` (wave-uniform) + 16 * lane; completion is tracked by
+// the vector-memory counter.  The builtin and the wait only exist in the device pass (the host pass just needs the kernel's stub).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, float *lds_base, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_base, 16, voff, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void lds_dma_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 
 __device__ __forceinline__ float fast_silu(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
 
@@ -182,10 +198,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
     constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
     constexpr int NT = WAVES_M * WAVES_N * 64, RPP = NT / 8;   // threads; rows fetched per pass (8 threads x 16 B cover a row's K-tile)
     constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;   // 16 B loads per thread per K-tile (activations / weights)
-    constexpr int TILE = (BM + BN) * LDS_LD;
+    constexpr int TILE = (BM + BN) * OP_LD;               // one operand buffer
+    // operands go global -> LDS directly (the DMA's LDS base travels in M0[15:0]: both buffers must lie below 64 KB)
+    constexpr bool DMA = FAST && !MODULATE && 2 * TILE * sizeof(float) <= 65536;
     static_assert((WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8) && TM >= 1 && TN >= 1 && A_ROWS >= 1 && B_ROWS >= 1, "bad tiling");
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
 
     const somi_conv_desc &d = a.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -223,10 +241,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
     long u = sk ? sk_lo(wg, U, gridDim.x) : (long)xcd_remap(blockIdx.x, ntile) * (nkt > 0 ? nkt : 1);
     const long u_lo = u, u_hi = sk ? sk_lo(wg + 1, U, gridDim.x) : u + (nkt > 0 ? nkt : 1);
 
-    const int kc = (tid & 7) * 4, row0 = tid >> 3;                    // per-thread fetch column / first row
-    const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
-    const int aw_off = (wm * WM) * LDS_LD + frag_off;                 // activation rows of this wave
-    const int bw_off = (BM + wn * WN) * LDS_LD + frag_off;            // weight rows of this wave
+    // A thread owns LDS chunk slot (tid & 7) of rows row0 + RPP*i; the slot holds k-chunk slot ^ ((row >> 1) & 7), and (row >> 1) & 7 is
+    // the same for all of a thread's rows (RPP, BM are multiples of 16), so the swizzle is one XOR on the thread's fetch column.
+    const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 4, row0 = tid >> 3;   // per-thread fetch column (floats) / first row
+    const int lds_col = (tid & 7) * 4;                                // ... and where it lands in the row's image
+    const int aw_off = (wm * WM + (lane & 31)) * OP_LD;               // activation rows of this wave (fragment row = lane & 31)
+    const int bw_off = (BM + wn * WN + (lane & 31)) * OP_LD;          // weight rows of this wave
+    int fo[4];                                                        // float offset of k-chunk 2j + (lane >> 5) inside the lane's row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fo[j] = ((2 * j + (lane >> 5)) ^ ((lane >> 1) & 7)) << 2;
 
     while (u < u_hi) {
         const int tile = (int)(u / (nkt > 0 ? nkt : 1));
@@ -362,10 +385,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
         auto store_tile = [&](float *buf) {
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i)
-                *reinterpret_cast<f32x4 *>(&buf[(row0 + RPP * i) * LDS_LD + kc]) = ra[i];
+                *reinterpret_cast<f32x4 *>(&buf[(row0 + RPP * i) * OP_LD + lds_col]) = ra[i];
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i)
-                *reinterpret_cast<f32x4 *>(&buf[(BM + row0 + RPP * i) * LDS_LD + kc]) = rb[i];
+                *reinterpret_cast<f32x4 *>(&buf[(BM + row0 + RPP * i) * OP_LD + lds_col]) = rb[i];
+        };
+        // the same fetch as LDS-DMA: each wave instruction lands 8 rows x 128 B at a wave-uniform LDS base + 16 B x lane
+        auto dma_tile = [&](float *buf) {
+            if constexpr (DMA) {
+                const int dpix = cls ? -(r_u * d.W + q_u) : (r_u * d.W + q_u) * d.dil;
+                const unsigned sd = (unsigned)(dpix * d.x_cs + c0_u) * 4u, bit = 1u << tp_u;
+                float *wrow = buf + wave * 8 * OP_LD;
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i)
+                    lds_dma16(rx, wrow + RPP * i * OP_LD, (a_mask[i] & bit) ? a_offb[i] + sd : OOB);
+                const unsigned ko = cls ? (unsigned)(((ph + cstep * r_u) * d.kw + pw + cstep * q_u) * d.Cin + c0_u) * 4u
+                                        : (unsigned)(tp_u * d.Cin + c0_u) * 4u;
+#pragma unroll
+                for (int i = 0; i < B_ROWS; ++i)
+                    lds_dma16(rw, wrow + (BM + RPP * i) * OP_LD, b_off[i] + ko);
+            }
         };
 
         f32x16 acc[TN][TM];
@@ -381,9 +420,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
         // exposed LDS latencies per K-tile per wave, and the two waves a workgroup puts on a SIMD hit them together).
         auto load_frag = [&](const float *buf, int j, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(buf + aw_off + i * 32 * LDS_LD + j * 8);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(buf + aw_off + i * 32 * OP_LD + fo[j]);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const f32x4 *>(buf + bw_off + i * 32 * LDS_LD + j * 8);
+            for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const f32x4 *>(buf + bw_off + i * 32 * OP_LD + fo[j]);
         };
         auto mma_steps = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], int t_lo, int t_hi) {
 #pragma unroll
@@ -396,8 +435,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
         };
 
         if (kt1 > kt0) {
-            fetch_tile(kt0);
-            store_tile(lds);
+            if constexpr (DMA) {
+                dma_tile(lds);
+                lds_dma_wait();       // the DMA's LDS writes are tracked by the vector-memory counter
+            } else {
+                fetch_tile(kt0);
+                store_tile(lds);
+            }
         }
         __syncthreads();
         f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
@@ -411,7 +455,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
             mma_steps(fa0, fb0, 0, 4);
             if (more) {
                 advance_k();
-                fetch_tile(kt + 1);    // in flight behind the next two MFMA groups
+                if constexpr (DMA) dma_tile(nxt);   // lands in the other buffer (last read before the previous barrier) behind the whole K-tile
+                else fetch_tile(kt + 1);            // in flight behind the next two MFMA groups
             }
             __builtin_amdgcn_sched_barrier(0);
             load_frag(cur, 2, fa0, fb0);
@@ -421,10 +466,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
             load_frag(cur, 3, fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
             mma_steps(fa0, fb0, 0, 4);
-            if (more) store_tile(nxt); // the other buffer: nobody reads it during this K-tile
+            if constexpr (!DMA) {
+                if (more) store_tile(nxt); // the other buffer: nobody reads it during this K-tile
+            }
             __builtin_amdgcn_sched_barrier(0);
             mma_steps(fa1, fb1, 0, 1);
-            __syncthreads();           // every wave has read `cur` for the last time and stored its part of `nxt`
+            if constexpr (DMA) lds_dma_wait();
+            __syncthreads();           // every wave has read `cur` for the last time and its part of `nxt` has landed
             if (more) load_frag(nxt, 0, fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
             mma_steps(fa1, fb1, 1, 4);

@@ -7,7 +7,8 @@
 // tiles.  Every 32-pixel K-tile it stages dy[32][BM] and the tap-shifted x[32][BN] rows (16 B buffer loads, padding by the
 // hardware range check) into a double-buffered LDS image
 // [pixel][channel] and feeds v_mfma_f32_32x32x2_f32 with one ds_read_b32 per operand value (lanes = consecutive channels,
-// conflict-free).  Partial tiles of the splits go to a workspace and are summed in a fixed order (deterministic), optionally
+// conflict-free).  The image is lane-linear (thread t owns floats [4t, 4t+4) of every pass), so it is filled by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`): no VGPR staging and no ds_write pass.  Partial tiles of the splits go to a workspace and are summed in a fixed order (deterministic), optionally
 // on top of an existing gradient.
 #include <stdlib.h>
 #include "common.h"
@@ -35,6 +36,19 @@ struct WgradArgs {
 
 __device__ __forceinline__ f32x4 wbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// LDS-DMA: 16 B per lane from a buffer descriptor straight into LDS at `lds_base` (wave-uniform) + 16 * lane; completion is tracked by
+// the vector-memory counter.  The builtin and the wait only exist in the device pass (the host pass just needs the kernel's stub).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, float *lds_base, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_base, 16, voff, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void lds_dma_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 template <int BM, int BN, int NW = 4>   // co rows x k columns per tile: 128 x {128,64,32} or 64 x {128,64}; NW waves (8: 128 x 128 only)
@@ -87,28 +101,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
         bho[i] = rem / a.Wo;
         bwo[i] = rem % a.Wo;
     }
-    f32x4 ra[A_N], rb[B_N];
     // all offsets are 32-bit: both tensors fit their 4 GiB buffer descriptors (checked by the launcher)
     const unsigned set_p0 = (unsigned)(set_pix0 + p_lo);                  // first pixel of this split in the flattened order
     const unsigned a_col = (unsigned)(a.dy_coff + co0 + a_quad * 4), b_colo = (unsigned)(a.x_coff + b_ci);
     const int npl = p_hi - p_lo;
-    auto fetch = [&](int pt) {                                            // pt = first pixel (inside the split) of the K-tile
-#pragma unroll
-        for (int i = 0; i < A_N; ++i) {
-            const int pl = pt + a_row0 + i * A_ROWS_PER_PASS;
-            const bool ok = a_col_ok && pl < npl;
-            const unsigned off = ((set_p0 + (unsigned)pl) * (unsigned)a.dy_cs + a_col) * 4u;
-            ra[i] = wbuf_load4(rdy, ok ? off : W_OOB);
-        }
-#pragma unroll
-        for (int i = 0; i < B_N; ++i) {
-            const int pl = pt + b_row0 + i * B_ROWS_PER_PASS;
-            const int hi = bho[i] * a.stride - a.pad + r, wi = bwo[i] * a.stride - a.pad + q;
-            const bool ok = b_col_ok && pl < npl && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const unsigned off = ((unsigned)((bb[i] * a.H + hi) * a.W + wi) * (unsigned)a.x_cs + b_colo) * 4u;
-            rb[i] = wbuf_load4(rx, ok ? off : W_OOB);
-        }
-    };
     auto advance = [&]() {
 #pragma unroll
         for (int i = 0; i < B_N; ++i) {
@@ -119,13 +115,24 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
             }
         }
     };
-    auto store = [&](float *buf) {
+    // LDS-DMA: thread t's 16 B of pass i land at float 4t of that pass - one wave instruction = 1 KiB at a wave-uniform base
+    auto dma = [&](float *buf, int pt) {
+        float *wbase = buf + wave * 256;
 #pragma unroll
-        for (int i = 0; i < A_N; ++i)
-            *reinterpret_cast<f32x4 *>(&buf[(a_row0 + i * A_ROWS_PER_PASS) * A_LD + a_quad * 4]) = ra[i];
+        for (int i = 0; i < A_N; ++i) {
+            const int pl = pt + a_row0 + i * A_ROWS_PER_PASS;
+            const bool ok = a_col_ok && pl < npl;
+            const unsigned off = ((set_p0 + (unsigned)pl) * (unsigned)a.dy_cs + a_col) * 4u;
+            lds_dma16(rdy, wbase + i * A_ROWS_PER_PASS * A_LD, ok ? off : W_OOB);
+        }
 #pragma unroll
-        for (int i = 0; i < B_N; ++i)
-            *reinterpret_cast<f32x4 *>(&buf[WG_PIX * A_LD + (b_row0 + i * B_ROWS_PER_PASS) * B_LD + b_quad * 4]) = rb[i];
+        for (int i = 0; i < B_N; ++i) {
+            const int pl = pt + b_row0 + i * B_ROWS_PER_PASS;
+            const int hi = bho[i] * a.stride - a.pad + r, wi = bwo[i] * a.stride - a.pad + q;
+            const bool ok = b_col_ok && pl < npl && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const unsigned off = ((unsigned)((bb[i] * a.H + hi) * a.W + wi) * (unsigned)a.x_cs + b_colo) * 4u;
+            lds_dma16(rx, wbase + WG_PIX * A_LD + i * B_ROWS_PER_PASS * B_LD, ok ? off : W_OOB);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
     };
 
     if (nkt > 0) {
-        fetch(0);
-        store(lds);
+        dma(lds, 0);
+        lds_dma_wait();               // the DMA's LDS writes are tracked by the vector-memory counter
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -166,12 +173,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
         mma_quarter(cur, 0);
         if (more) {
             advance();
-            fetch((kt + 1) * WG_PIX);
+            dma(nxt, (kt + 1) * WG_PIX);                               // lands behind the rest of this K-tile's MFMAs
         }
         mma_quarter(cur, 1);
         mma_quarter(cur, 2);
-        if (more) store(nxt);
         mma_quarter(cur, 3);
+        lds_dma_wait();
         __syncthreads();
     }
 

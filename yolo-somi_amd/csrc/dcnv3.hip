@@ -32,8 +32,17 @@
 //          |grad_output|, so the sum does not depend on list order): 1.0 ms.  (Tried: LDS double atomics, 35 cycles per wave
 //          instruction, 1.7 ms; lists sorted by tap id + fp32 sums in that order, 1.4 ms - the rank scans are dependent LDS reads.)
 //     C  dcnv3_bwd_combine_kernel: every input pixel adds the (at most 2x2) windows that cover it in ascending tile order.
-//     grad_input is therefore run-to-run bit-identical whenever every tap stays within R pixels of the kernel footprint; taps
-//     beyond the window (the reference test's offsets of +-20 pixels) go to grad_input as fp32 atomics like the reference's own.
+//     D  dcnv3_bwd_near_kernel: taps that leave their tile's window but land within two 8x8 input tiles of it ("near": offsets up to
+//        ~10 px beyond the kernel footprint - everything a training run produces) are NOT scattered.  B only records, per (image, group,
+//        tile), a 25-bit mask of the neighbouring destination tiles that receive such taps; D runs one workgroup per DESTINATION tile,
+//        re-derives the sampling records of the flagged source tiles around it (same arithmetic as B), keeps the taps that left their
+//        window and land in its own tile, and adds them in a fixed order (source tile ascending, record, corner) - plain
+//        read-modify-write on pixels it alone owns.  No float atomics: grad_input is run-to-run bit-identical.
+//     Only taps even farther out (the reference test's offsets of +-20 pixels; stride != 1) go to grad_input as fp32 atomics like the
+//     reference's own; they are counted in the workspace's overflow word (0 <=> the launch was bit-reproducible).
+//     B / C / D run over the batch in chunks of images whose staging slab stays below ~128 MB (SOMI_DCN_SLAB_MB): the slab is rewritten
+//     chunk after chunk while it is still resident in the 256 MB Infinity Cache, so most of its write + read traffic never reaches HBM
+//     (round 2 staged the whole batch: 2.95 GB at N32 160x160, 8.9 GB of HBM traffic for 3.0 GB of algorithmic bytes).
 //   direct (no workspace, other group widths): one kernel, fp32 atomics into grad_input exactly as the reference does.
 #include "common.h"
 
@@ -351,8 +360,17 @@ struct GinGeo {
     int lo_h, lo_w;              // window origin = tile origin * stride + lo
     unsigned rkw, rWW;           // floor(65536/d) + 1 for d = kernel_w, WW: x / d == (x * r) >> 16 while x < 65536 / d (win_plan checks)
     float *staging;              // [N][G][tiles][WH*WW][Gc]
-    unsigned *overflow;          // taps that fell outside their tile's window (added with fp32 atomics): 0 <=> bit-reproducible
+    unsigned *overflow;          // FAR taps (added with fp32 atomics): 0 <=> bit-reproducible
+    unsigned *near;              // [N][G][tiles] masks of the destination tiles that receive a tile's NEAR taps; nullptr: no near pass (stride != 1)
 };
+
+// A tap at input pixel (h, w) that fell outside its tile's window: its destination tile relative to the tile under the window's centre.
+// Within +-2 tiles both ways -> `bit` in the tile's 5x5 mask and true (the near pass D adds it); else false (far: atomics).
+__device__ __forceinline__ bool near_bit(const GinGeo &q, int h, int w, int win_h0, int win_w0, int &bit) {
+    const int dth = (h >> 3) - ((win_h0 + (q.WH >> 1)) >> 3), dtw = (w >> 3) - ((win_w0 + (q.WW >> 1)) >> 3);
+    bit = (dth + 2) * 5 + dtw + 2;
+    return q.near != nullptr && (unsigned)(dth + 2) <= 4u && (unsigned)(dtw + 2) <= 4u;
+}
 struct RecG {                    // one sampling point of one output pixel: floor position and the four tap coefficients x mask
     int h0, w0;
     float cf[4];                 // 0 for a tap outside the image / an unused point
@@ -379,11 +397,12 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
     __shared__ float red[4];
     __shared__ int wsum[4];
     __shared__ int novf;
+    __shared__ unsigned nearmask;
     const int tile = blockIdx.x, n = blockIdx.y, g = blockIdx.z;
     const int th0 = (tile / q.tiles_w) * GIN_TH, tw0 = (tile % q.tiles_w) * GIN_TW;
     const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
     for (int i = threadIdx.x; i <= ncell; i += 256) { cnt[i] = 0; cur[i] = 0; }
-    if (threadIdx.x == 0) novf = 0;
+    if (threadIdx.x == 0) { novf = 0; nearmask = 0u; }
     // the tile's grad_output for this group, and its largest magnitude
     constexpr int SLOTS = 256 / GC, NPX = GIN_TP / SLOTS;
     const int c = threadIdx.x % GC, slot = threadIdx.x / GC;
@@ -466,6 +485,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
                 const int at = start[cell] + atomicAdd(&cur[cell], 1);
                 ent_cf[at] = r.cf[tp];
                 ent_px[at] = (uint8_t)pl;
+            } else if (int nb; near_bit(q, h, w, win_h0, win_w0, nb)) {
+                atomicOr(&nearmask, 1u << nb);                     // left for the near pass (dcnv3_bwd_near_kernel)
             } else {
                 const int at = atomicAdd(&novf, 1);
                 if (at < GIN_OVF_CAP) {
@@ -516,7 +537,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
             *reinterpret_cast<f32x4 *>(dst + cell * GC + c4) = r;
         }
     }
-    // 5. taps beyond the window: fp32 atomics into grad_input like the reference's own kernel (128 contiguous bytes per tap)
+    if (threadIdx.x == 0 && q.near) q.near[((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile] = nearmask;
+    // 5. FAR taps: fp32 atomics into grad_input like the reference's own kernel (128 contiguous bytes per tap)
     if (novf) {
         float *gin = a.grad_input + (long)n * a.H * a.W * a.C + g * GC + c;
         const int nlist = novf < GIN_OVF_CAP ? novf : GIN_OVF_CAP;
@@ -560,6 +582,7 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
     const size_t mid = (size_t)nrec * sizeof(RecM) > (size_t)GC * GMM_LD * 4 ? (size_t)nrec * sizeof(RecM) : (size_t)GC * GMM_LD * 4;
     OvfG *ovf = reinterpret_cast<OvfG *>(reinterpret_cast<char *>(recs) + (mid + 15) / 16 * 16);
     __shared__ int novf;
+    __shared__ unsigned nearmask;
     const int tile = blockIdx.x, n = blockIdx.y, g = blockIdx.z;
     const int th0 = (tile / q.tiles_w) * GIN_TH, tw0 = (tile % q.tiles_w) * GIN_TW;
     const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
@@ -597,7 +620,7 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
         }
     }
     for (int i = tid; i < ncell * GMM_LD / 4; i += NT) reinterpret_cast<f32x4 *>(S)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid == 0) novf = 0;
+    if (tid == 0) { novf = 0; nearmask = 0u; }
     // 1. records
     for (int i = tid, j = 0; i < nrec; i += NT, ++j) {
         const int pl = i / a.K, k = i % a.K;
@@ -647,10 +670,15 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
             const int wh = wh0 + dy, ww = ww0 + dx;
             if ((unsigned)wh < (unsigned)q.WH && (unsigned)ww < (unsigned)q.WW) {
                 S[(wh * q.WW + ww) * GMM_LD + pl] += cf;                      // plain read-add-write: see the note on column writers above
+            } else if (int nb; near_bit(q, wh + win_h0, ww + win_w0, win_h0, win_w0, nb)) {
+                atomicOr(&nearmask, 1u << nb);                                // left for the near pass (dcnv3_bwd_near_kernel)
             } else {
                 const int at = atomicAdd(&novf, 1);
                 if (at < GMM_OVF_CAP) ovf[at] = OvfG{(wh + win_h0) * a.W + ww + win_w0, pl, cf};   // a longer list: all of them again in step 5
             }
+            // the four corner lanes of a pixel are neighbours in one wave and an LDS read-add-write pair of one put() must not be
+            // interleaved with the next put()'s by the compiler: the wave's LDS instructions then execute in program order
+            __builtin_amdgcn_wave_barrier();
         };
         int k = 0;
         for (; k + 3 <= a.K; k += 3) {
@@ -712,7 +740,8 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
                 }
         }
     }
-    // 5. taps beyond the window: fp32 atomics into grad_input like the reference's own kernel (one channel per lane)
+    if (tid == 0 && q.near) q.near[((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile] = nearmask;
+    // 5. FAR taps: fp32 atomics into grad_input like the reference's own kernel (one channel per lane)
     if (novf) {
         constexpr int SLOTS = NT / GC;
         const int c = tid % GC, slot = tid / GC;
@@ -740,6 +769,7 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
                     if (!((bits >> t) & 1)) continue;
                     const int hwp = r.off[t] / a.C, h = hwp / a.W, w = hwp % a.W;
                     if ((unsigned)(h - win_h0) < (unsigned)q.WH && (unsigned)(w - win_w0) < (unsigned)q.WW) continue;   // went through S
+                    if (int nb; near_bit(q, h, w, win_h0, win_w0, nb)) continue;                                          // the near pass adds it
                     atomicAdd(gin + (long)hwp * a.C, tv * cf4[t]);
                 }
             }
@@ -776,6 +806,111 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_combine_kernel(const DcnArgs a,
                 acc += *reinterpret_cast<const f32x4 *>(q.staging + ((n * a.G + g) * ntile + th * q.tiles_w + tw) * ncell * a.Gc + cell * a.Gc + cg);
             }
         *reinterpret_cast<f32x4 *>(o) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward D: the near taps
+// One workgroup per (destination tile of 8x8 input pixels, image, group).  For every source tile within +-2 tiles whose mask names
+// this destination: rebuild the source tile's sampling records (the arithmetic of backward B, so the same floor positions and
+// coefficients), keep the corners that left the source's window and land in this tile, compact them in a fixed order
+// (round j of records, thread, corner) and add grad_output[source pixel][c] * coefficient into an LDS image of the tile, one entry
+// after the other (a cell row is only ever touched by the one thread group that owns its residue).  Finally the image is added to
+// grad_input - pixels this workgroup alone owns at this point of the stream.  Stride 1 only (the launcher enables q.near for it).
+constexpr int NEAR_CAP = 1024;                                        // candidates of one round: 256 threads x 4 corners
+template <int GC>
+__global__ __launch_bounds__(256) void dcnv3_bwd_near_kernel(const DcnArgs a, const GinGeo q) {
+    __shared__ float accL[GIN_TP * GC];
+    __shared__ int ent_key[NEAR_CAP];                                 // cell << 8 | source pixel of the tile
+    __shared__ float ent_cf[NEAR_CAP];
+    __shared__ int wsum[4];
+    constexpr int NG = 256 / GC;                                      // thread groups; group j owns the cells with cell % NG == j
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid % GC, grp = tid / GC;
+    const int dt_w = (a.W + 7) >> 3;
+    const int ty = blockIdx.x / dt_w, tx = blockIdx.x % dt_w, n = blockIdx.y, g = blockIdx.z;
+    const int ntile = q.tiles_h * q.tiles_w;
+    const int cb_h = (q.lo_h + (q.WH >> 1)) >> 3, cb_w = (q.lo_w + (q.WW >> 1)) >> 3;    // source tile t sits in destination tile t + cb
+    const unsigned *masks = q.near + ((long)n * a.G + g) * ntile;
+    // which of the 25 neighbours are flagged for this destination (uniform)
+    unsigned todo = 0;
+    for (int s = 0; s < 25; ++s) {
+        const int th = ty + s / 5 - 2 - cb_h, tw = tx + s % 5 - 2 - cb_w;
+        if ((unsigned)th >= (unsigned)q.tiles_h || (unsigned)tw >= (unsigned)q.tiles_w) continue;
+        const int bit = (ty - (th + cb_h) + 2) * 5 + (tx - (tw + cb_w) + 2);
+        if ((masks[th * q.tiles_w + tw] >> bit) & 1u) todo |= 1u << s;
+    }
+    if (!todo) return;
+    for (int i = tid; i < GIN_TP * GC; i += 256) accL[i] = 0.f;
+    const int nrec = GIN_TP * a.K;
+    const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
+    for (int s = 0; s < 25; ++s) {                                    // ascending (th, tw): the fixed order of the sums
+        if (!((todo >> s) & 1u)) continue;
+        const int th = ty + s / 5 - 2 - cb_h, tw = tx + s % 5 - 2 - cb_w;
+        const int th0 = th * GIN_TH, tw0 = tw * GIN_TW;
+        const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
+        for (int i0 = 0; i0 < nrec; i0 += 256) {
+            const int i = i0 + tid;
+            int key[4];
+            float cf[4];
+            int cnt = 0;
+            if (i < nrec) {
+                const int pl = i / a.K, k = i % a.K;
+                const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+                if (ho < a.Ho && wo < a.Wo) {
+                    const long sidx = ((((long)n * a.Ho + ho) * a.Wo + wo) * a.G + g) * a.K + k;
+                    const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + sidx * 2);
+                    const float m = a.mask[sidx];
+                    const int ii = k / a.kh, jj = k % a.kh;
+                    const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
+                    const float p0h = (float)(half_h - a.ph + ho * a.sh) - (float)half_h * a.offset_scale;
+                    const float loc_w = p0w + ((float)(ii * a.dw) + ofs.x) * a.offset_scale;
+                    const float loc_h = p0h + ((float)(jj * a.dh) + ofs.y) * a.offset_scale;
+                    if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)a.H && loc_w < (float)a.W) {
+                        const float fh = floorf(loc_h), fw = floorf(loc_w);
+                        const int h0 = (int)fh, w0 = (int)fw;
+                        const float lh = loc_h - fh, lw = loc_w - fw, hh = 1.f - lh, hw = 1.f - lw;
+                        const bool h0ok = h0 >= 0, h1ok = h0 + 1 <= a.H - 1, w0ok = w0 >= 0, w1ok = w0 + 1 <= a.W - 1;
+                        const float c4[4] = {(h0ok && w0ok) ? hh * hw * m : 0.f, (h0ok && w1ok) ? hh * lw * m : 0.f,
+                                             (h1ok && w0ok) ? lh * hw * m : 0.f, (h1ok && w1ok) ? lh * lw * m : 0.f};
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) {
+                            const int h = h0 + (tp >> 1), w = w0 + (tp & 1);
+                            const bool in_win = (unsigned)(h - win_h0) < (unsigned)q.WH && (unsigned)(w - win_w0) < (unsigned)q.WW;
+                            if (c4[tp] != 0.f && !in_win && (h >> 3) == ty && (w >> 3) == tx) {
+                                key[cnt] = (((h & 7) * 8 + (w & 7)) << 8) | pl;
+                                cf[cnt] = c4[tp];
+                                ++cnt;
+                            }
+                        }
+                    }
+                }
+            }
+            // exclusive scan of cnt over the block -> slots in (thread, corner) order
+            int inc = cnt;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+            __syncthreads();                                          // the previous round's entries have been consumed
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            int base = inc - cnt;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            for (int e = 0; e < cnt; ++e) { ent_key[base + e] = key[e]; ent_cf[base + e] = cf[e]; }
+            __syncthreads();
+            for (int e = 0; e < total; ++e) {                         // one entry after the other: the order of the adds is the list's
+                const int ky = ent_key[e], cell = ky >> 8, pl = ky & 255;
+                if (cell % NG != grp) continue;
+                const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+                accL[cell * GC + c] += a.grad_output[(((long)n * a.Ho + ho) * a.Wo + wo) * a.C + g * GC + c] * ent_cf[e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int cell = grp; cell < GIN_TP; cell += NG) {
+        const int h = ty * 8 + (cell >> 3), w = tx * 8 + (cell & 7);
+        if (h < a.H && w < a.W) {
+            float *o = a.grad_input + (((long)n * a.H + h) * a.W + w) * a.C + g * GC + c;
+            *o += accL[cell * GC + c];
+        }
     }
 }
 
@@ -1073,13 +1208,20 @@ static size_t win_plan(const DcnArgs &a, GinGeo &q) {
     return lds;
 }
 
-// backward B/C; false when it does not apply (group width, LDS budget)
-static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &staging_bytes) {
+// backward B/C/D; false when it does not apply (group width, LDS budget).  `chunk`: images per pass of B / C / D - the staging slab
+// holds one chunk and is reused by the next, sized to stay resident in the Infinity Cache between B's stores and C's loads.
+static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &workspace_bytes, int &chunk, size_t &slab_bytes) {
     if (!win_geo(a, q)) return false;
     lds = (size_t)GIN_TP * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(RecG) + 4 * sizeof(float) + 4) + GIN_OVF_CAP * sizeof(OvfG) +
           3 * ((size_t)q.WH * q.WW + 1) * sizeof(int);
     if (lds > 150 * 1024 || (long)q.tiles_h * q.tiles_w > 65535L * 32) return false;
-    staging_bytes = ((size_t)a.N * a.G * q.tiles_h * q.tiles_w * q.WH * q.WW * a.Gc * sizeof(float) + 255) / 256 * 256 + 256;   // + the overflow counter
+    static const long cap_mb = [] { const char *e = getenv("SOMI_DCN_SLAB_MB"); const long v = e ? atol(e) : 128; return v < 1 ? 1 : v; }();
+    const size_t per_img = (size_t)a.G * q.tiles_h * q.tiles_w * q.WH * q.WW * a.Gc * sizeof(float);
+    long c = (long)(((size_t)cap_mb << 20) / per_img);
+    chunk = c < 1 ? 1 : (c > a.N ? a.N : (int)c);
+    slab_bytes = ((size_t)chunk * per_img + 255) / 256 * 256;
+    const size_t near_bytes = ((size_t)chunk * a.G * q.tiles_h * q.tiles_w * sizeof(unsigned) + 255) / 256 * 256;
+    workspace_bytes = slab_bytes + near_bytes + 256;                       // slab | near masks | the overflow counter
     return true;
 }
 
@@ -1142,8 +1284,9 @@ extern "C" size_t somi_dcnv3_backward_workspace_bytes(int N, int H, int W, int G
                   sizeof(Rec) + 3 * sizeof(float)))
         return 0;
     GinGeo q{};
-    size_t lds = 0, bytes = 0;
-    return gin_plan(a, q, lds, bytes) ? bytes : 0;
+    size_t lds = 0, bytes = 0, slab = 0;
+    int chunk = 0;
+    return gin_plan(a, q, lds, bytes, chunk, slab) ? bytes : 0;
 }
 
 extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, const float *mask, const float *grad_output,
@@ -1164,27 +1307,24 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)a.TP * G * a.K * (sizeof(Rec) + 3 * sizeof(float));
     GinGeo q{};
-    size_t glds = 0, gbytes = 0;
-    const bool windowed = workspace && gin_plan(a, q, glds, gbytes) && workspace_bytes >= gbytes && aligned16(workspace) && aligned16(grad_input) &&
-                          aligned16(grad_output);
+    size_t glds = 0, gbytes = 0, slab = 0;
+    int chunk = 0;
+    const bool windowed = workspace && gin_plan(a, q, glds, gbytes, chunk, slab) && workspace_bytes >= gbytes && aligned16(workspace) &&
+                          aligned16(grad_input) && aligned16(grad_output);
     if (windowed) {
-        // A: grad_offset / grad_mask (float4 gathers, no atomics)
+        // A: grad_offset / grad_mask (float4 gathers, no atomics), the whole batch
         GinGeo qa{};
         const size_t wlds = aligned16(input) ? win_plan(a, qa) : 0;
         if (wlds) launch_win<1>(a, qa, wlds, s);
         else hipLaunchKernelGGL(dcnv3_bwd_om_kernel, dim3(a.ntile), dim3(256), (size_t)a.TP * G * a.K * sizeof(Rec), s, a);
-        // B: grad_input windows, C: combine
-        q.staging = static_cast<float *>(workspace);
-        q.overflow = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + gbytes - 256);
+        // B: grad_input windows, C: combine, D: the near taps - chunk of images after chunk through one staging slab
+        char *wsb = static_cast<char *>(workspace);
+        q.staging = reinterpret_cast<float *>(wsb);
+        q.overflow = reinterpret_cast<unsigned *>(wsb + gbytes - 256);
+        // the near pass needs stride 1 (source tile t then sits over destination tile t + const) and 8-aligned tiles of the INPUT image
+        static const bool near_on = [] { const char *e = getenv("SOMI_DCN_NEAR"); return !(e && e[0] == '0'); }();
+        q.near = (near_on && stride_h == 1 && stride_w == 1) ? reinterpret_cast<unsigned *>(wsb + slab) : nullptr;
         (void)hipMemsetAsync(q.overflow, 0, 256, s);
-        const dim3 grid(q.tiles_h * q.tiles_w, N, G);
-#define SOMI_GIN_LAUNCH(GC)                                                                                                      \
-    do {                                                                                                                         \
-        if (glds > 64 * 1024)                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)glds);                                                                               \
-        hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<GC>), grid, dim3(256), glds, s, a, q);                                         \
-    } while (0)
         // B on the matrix cores for 32-wide groups when its LDS image fits (SOMI_DCN_GIN=exact keeps the list sums for comparisons)
         const char *gsel = getenv("SOMI_DCN_GIN");
         const size_t ncell_ = (size_t)q.WH * q.WW, recb = (size_t)GIN_TP * a.K * sizeof(RecM), gotb = (size_t)Gc * GMM_LD * sizeof(float);
@@ -1194,17 +1334,46 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
     do {                                                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_mfma_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)mlds);                                                                               \
-        hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC>), grid, dim3(GMM_NT), mlds, s, a, q);                                    \
+        hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC>), grid, dim3(GMM_NT), mlds, s, c, q);                                    \
     } while (0)
-        if (mfma) SOMI_GMM_LAUNCH(32);
-        else if (Gc == 8) SOMI_GIN_LAUNCH(8);
-        else if (Gc == 16) SOMI_GIN_LAUNCH(16);
-        else if (Gc == 32) SOMI_GIN_LAUNCH(32);
-        else SOMI_GIN_LAUNCH(64);
+        const size_t in_img = (size_t)H * W * a.C, out_img = (size_t)a.Ho * a.Wo * a.C, om_img = (size_t)a.Ho * a.Wo * G * a.K;
+        for (int n0 = 0; n0 < N; n0 += chunk) {
+            DcnArgs c = a;                                         // the chunk as a batch of its own
+            c.N = N - n0 < chunk ? N - n0 : chunk;
+            c.input = a.input + n0 * in_img;
+            c.grad_input = a.grad_input + n0 * in_img;
+            c.grad_output = a.grad_output + n0 * out_img;
+            c.offset = a.offset + n0 * om_img * 2;
+            c.mask = a.mask + n0 * om_img;
+            c.npix = (long)c.N * a.Ho * a.Wo;
+            const dim3 grid(q.tiles_h * q.tiles_w, c.N, G);
+            const dim3 dgrid(((H + 7) / 8) * ((W + 7) / 8), c.N, G);
+            long blocks = ((long)c.N * H * W * (a.C / 4) + 255) / 256;
+            const dim3 cgrid((unsigned)(blocks > 16384 ? 16384 : blocks));
+            // D follows C (it adds to pixels C has just combined); the list-form macro launches B only, C and D come below
+            if (mfma) SOMI_GMM_LAUNCH(32);
+            else if (Gc == 8) hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<8>), grid, dim3(256), glds, s, c, q);
+            else if (Gc == 16) hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<16>), grid, dim3(256), glds, s, c, q);
+            else if (Gc == 32) {
+                if (glds > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+                hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<32>), grid, dim3(256), glds, s, c, q);
+            } else {
+                if (glds > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+                hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<64>), grid, dim3(256), glds, s, c, q);
+            }
+            hipLaunchKernelGGL(dcnv3_bwd_combine_kernel, cgrid, dim3(256), 0, s, c, q);
+            if (q.near) {
+                switch (Gc) {
+                case 8: hipLaunchKernelGGL((dcnv3_bwd_near_kernel<8>), dgrid, dim3(256), 0, s, c, q); break;
+                case 16: hipLaunchKernelGGL((dcnv3_bwd_near_kernel<16>), dgrid, dim3(256), 0, s, c, q); break;
+                case 32: hipLaunchKernelGGL((dcnv3_bwd_near_kernel<32>), dgrid, dim3(256), 0, s, c, q); break;
+                default: hipLaunchKernelGGL((dcnv3_bwd_near_kernel<64>), dgrid, dim3(256), 0, s, c, q); break;
+                }
+            }
+        }
 #undef SOMI_GMM_LAUNCH
-#undef SOMI_GIN_LAUNCH
-        long blocks = ((long)N * H * W * (a.C / 4) + 255) / 256;
-        hipLaunchKernelGGL(dcnv3_bwd_combine_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, s, a, q);
         return launch_status("somi_dcnv3_backward_f32 (windowed)");
     }
     // direct form.  One channel per lane: a wave's fp32 atomic covers 256 contiguous bytes of grad_input (the shape that runs at the

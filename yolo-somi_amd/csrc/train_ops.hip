@@ -144,14 +144,23 @@ __global__ __launch_bounds__(256) void rows_fold_kernel(const float *__restrict_
 // ---- SyncBatchNorm (train.py:165-167 --sync-bn): the same two reductions with the exchange between ranks in the middle.  A rank
 // folds its partial sums to doubles [2][C] + its pixel count; the caller all-gathers those records; every rank then adds the
 // records in rank order (the same order everywhere: identical statistics on every rank, bit for bit) and finishes as above.
+// central: the forward statistics leave as a PIVOT-FREE record {mean_r, M2_r = sum (x - mean_r)^2, n_r} (the partial sums were taken around
+// this rank's own pivot, its running mean: records of ranks whose pivots differ could not simply be added - ADVICE r2)
 __global__ __launch_bounds__(256) void sums_fold_f64_kernel(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C, long npix,
-                                                            double *__restrict__ sums) {
+                                                            double *__restrict__ sums, const float *__restrict__ pivot, int central) {
     int c;
     double s1, s2;
     if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * (size_t)C] = (double)npix;
     if (!stage2_sums(p1, p2, nchunk, C, c, s1, s2)) return;
-    sums[c] = s1;
-    sums[(size_t)C + c] = s2;
+    if (central) {
+        const double dm = s1 / (double)npix;
+        double m2 = s2 - s1 * dm;
+        sums[c] = (pivot ? (double)pivot[c] : 0.0) + dm;
+        sums[(size_t)C + c] = m2 < 0.0 ? 0.0 : m2;
+    } else {
+        sums[c] = s1;
+        sums[(size_t)C + c] = s2;
+    }
 }
 __global__ __launch_bounds__(256) void bn_stats_from_sums_kernel(const double *__restrict__ all, int nranks, int C, float eps, float momentum,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -159,12 +168,17 @@ __global__ __launch_bounds__(256) void bn_stats_from_sums_kernel(const double *_
                                                                  float *__restrict__ shift, float *running_mean, float *running_var) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    // records {mean_r, M2_r, n_r} combined in rank order (Chan et al.): the same doubles in the same order on every rank
     const size_t rec = 2 * (size_t)C + 1;
-    double s = 0.0, q = 0.0, cnt = 0.0;
-    for (int r = 0; r < nranks; ++r) { s += all[r * rec + c]; q += all[r * rec + C + c]; cnt += all[r * rec + 2 * (size_t)C]; }
-    const double dm = s / cnt;
-    const double m = (running_mean ? (double)running_mean[c] : 0.0) + dm;
-    double var = q / cnt - dm * dm;
+    double cnt = 0.0, msum = 0.0;
+    for (int r = 0; r < nranks; ++r) { const double nr = all[r * rec + 2 * (size_t)C]; cnt += nr; msum += nr * all[r * rec + c]; }
+    const double m = msum / cnt;
+    double m2 = 0.0;
+    for (int r = 0; r < nranks; ++r) {
+        const double nr = all[r * rec + 2 * (size_t)C], d = all[r * rec + c] - m;
+        m2 += all[r * rec + C + c] + nr * d * d;
+    }
+    double var = m2 / cnt;
     if (var < 0.0) var = 0.0;
     const float rs = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
@@ -438,7 +452,7 @@ extern "C" int somi_bn_local_sums_f64(const float *x, int x_cs, int x_coff, long
         hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, pivot, o1, o2, red_chunk(npix));
         p1 = o1; p2 = o2;
     }
-    hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums);
+    hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums, pivot, 1);
     return launch_status("somi_bn_local_sums_f64");
 }
 
@@ -462,7 +476,7 @@ extern "C" int somi_bn_act_backward_sums_f64(const float *dz, int dz_cs, int dz_
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order, npix, C,
                        p1, p2, red_chunk(npix));
-    hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums);
+    hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums, nullptr, 0);
     return launch_status("somi_bn_act_backward_sums_f64");
 }
 

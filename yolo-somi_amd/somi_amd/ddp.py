@@ -42,10 +42,13 @@ class GradBuckets:
         self.next = [0] * len(flat_grads)                        # next bucket to launch per buffer
         self.launched = []                                       # (buffer index, start, end) in launch order - for tests
         self.enabled = True                                      # False: layer_done() is a no-op (a non-stepping micro-batch)
+        self.timing = False                                      # True: HIP events around every bucket on the side stream (overlap_stats)
+        self._spans, self._bwd_end = [], None
 
     def reset(self):
         self.next = [0] * len(self.flat)
         self.handles, self.launched = [], []
+        self._spans, self._bwd_end = [], None
 
     def _launch(self, bi, start, end):
         self.launched.append((bi, start, end))
@@ -57,7 +60,13 @@ class GradBuckets:
             ev.record()                                           # gradients of this bucket are final on the compute stream
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
+                if self.timing:
+                    e1.record()
+                    self._spans.append((e0, e1))
         else:
             self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
 
@@ -75,6 +84,9 @@ class GradBuckets:
 
     def finish(self):
         """Launch whatever is left (layer 0 side) and make the compute stream wait for the exchange."""
+        if self.timing and self.use_streams:
+            self._bwd_end = torch.cuda.Event(enable_timing=True)  # device time at which the reverse walk's last kernel has run
+            self._bwd_end.record()
         for bi, cuts in enumerate(self.buckets):
             while self.next[bi] < len(cuts):
                 self._launch(bi, *cuts[self.next[bi]])
@@ -85,6 +97,20 @@ class GradBuckets:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.handles = []
 
+
+    def overlap_stats(self):
+        """After a step run with `timing = True` (and a device synchronise): (overlap_frac, exchange_ms, buckets) - the share of the
+        side stream's all-reduce time that had already elapsed when the backward pass's last kernel finished on the compute stream, i.e.
+        how much of the exchange the reverse walk actually hid (1.0 = all of it; 0.0 = the exchange ran behind the backward pass)."""
+        if not self._spans or self._bwd_end is None:
+            return None
+        total = hidden = 0.0
+        for e0, e1 in self._spans:
+            dur = e0.elapsed_time(e1)
+            before = e0.elapsed_time(self._bwd_end)              # ms from this bucket's start to the end of the backward pass
+            total += dur
+            hidden += min(max(before, 0.0), dur)
+        return (hidden / total if total > 0 else 0.0), total, len(self._spans)
 
     def measure_exchange(self, iters=5, sync=None):
         """The whole bucketed exchange on its own (nothing to overlap with), `iters` times: seconds per exchange and the bytes

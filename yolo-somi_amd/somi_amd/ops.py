@@ -125,12 +125,23 @@ def dcnv3_forward_raw(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group
 
 
 DCN_LAST_WORKSPACE = None
+_DCN_WS = {}                                                     # device -> the windowed backward's workspace (grow-only; ~130 MB: the capped staging slab)
 
 
 def dcn_overflow_taps():
-    """Sampling taps of the last windowed DCNv3 backward that fell outside their tile's LDS window (host sync; diagnostics / tests)."""
+    """FAR sampling taps of the last windowed DCNv3 backward - those that went to grad_input as fp32 atomics because they landed more than
+    two tiles from their own (0 <=> that backward was bit-reproducible).  Host sync; diagnostics / tests."""
     ws = DCN_LAST_WORKSPACE
     return None if ws is None else int(ws[-256:-252].view(torch.int32).item())
+
+
+def _dcn_workspace(nbytes, dev):
+    """The staging slab of the windowed backward is capped by the library (SOMI_DCN_SLAB_MB, 128 MB by default) and reused chunk after
+    chunk, so one buffer per device serves every call (round 2 allocated up to 2.95 GB per call and kept it alive in a global)."""
+    ws = _DCN_WS.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = _DCN_WS[dev] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return ws[:nbytes]
 
 
 def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels,
@@ -155,7 +166,7 @@ def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw,
         e0.record()
     L = _lib.lib()
     nbytes = 0 if DCN_DIRECT else L.somi_dcnv3_backward_workspace_bytes(N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw, float(offset_scale))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device) if nbytes else None      # staging slab of the windowed form
+    ws = _dcn_workspace(nbytes, input.device) if nbytes else None   # staging slab + near masks + overflow word of the windowed form
     global DCN_LAST_WORKSPACE
     DCN_LAST_WORKSPACE = ws                                      # tests read the overflow-tap counter at its end (dcn_overflow_taps)
     check(L.somi_dcnv3_backward_f32(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go),
@@ -479,13 +490,16 @@ def _npix(t):
 # --sync-bn (reference train.py:165-167, torch.nn.SyncBatchNorm): set to the torch.distributed module (train.TrainStep(sync_bn=True) does
 # it around its step) and every BatchNorm statistic below spans the batches of all ranks: one small all-gather per layer and direction.
 SYNC_BN = None
+SYNC_BN_GROUP = None     # the process group of these all-gathers.  TrainStep gives sync-BN a group of its OWN: on the default group every
+#                          blocking all-gather would queue behind the asynchronous gradient buckets (collectives of one RCCL communicator run
+#                          in issue order) and stall the backward pass until they finish - the overlap of the exchange would be lost.
 
 
 def _gather_records(rec):
     """all-gather of one [2C + 1] double record per rank -> (flat [world * (2C + 1)] tensor, world)."""
-    world = SYNC_BN.get_world_size()
+    world = SYNC_BN.get_world_size(SYNC_BN_GROUP)
     out = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
-    SYNC_BN.all_gather_into_tensor(out, rec)
+    SYNC_BN.all_gather_into_tensor(out, rec, group=SYNC_BN_GROUP)
     return out, world
 
 

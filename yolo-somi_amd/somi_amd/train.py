@@ -57,6 +57,9 @@ class TrainStep:
         self.model, self.dist = model, dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.sync_bn = dist if (sync_bn and dist is not None) else None   # like the reference: only under DDP (RANK != -1)
+        # a process group of its own for the per-layer statistics all-gathers: on the default group they would queue behind the gradient
+        # buckets already in flight (one communicator = one issue order) and stall the backward pass until those finish
+        self.sync_bn_group = dist.new_group() if self.sync_bn is not None else None
         model.hyp = hyp
         model.train()
         self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True, adam=adam)
@@ -84,13 +87,13 @@ class TrainStep:
             self.buckets.reset()
             self.buckets.enabled = stepping                       # local accumulation only on the others (DDP's no_sync)
         from . import ops
-        ops.SYNC_BN = self.sync_bn
+        ops.SYNC_BN, ops.SYNC_BN_GROUP = self.sync_bn, self.sync_bn_group
         try:
             pred = self.model(imgs)
             loss, items = self.compute_loss(pred, targets)
             loss.backward()                                       # unscaled: the SUM all-reduce supplies the WORLD_SIZE factor
         finally:
-            ops.SYNC_BN = None
+            ops.SYNC_BN = ops.SYNC_BN_GROUP = None
         if self.buckets and stepping:
             self.buckets.finish()
         self._since_step += 1
