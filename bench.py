@@ -36,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, 'yolo-somi_amd')):
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 XGMI_LINKS, XGMI_LINK_GBPS = 7, 153  # per GPU: 7 point-to-point xGMI links of ~153 GB/s each (MI355X_MICROARCH.md)
 MODELS = {'somi-dcn': 'yolov5l-SOMI (DCNv3 blocks)', 'somi': 'yolov5l-SOMI', 'yolov5s': 'yolov5s'}
@@ -209,6 +210,9 @@ def main():
     ap.add_argument('--model', choices=list(MODELS), default='somi-dcn')
     ap.add_argument('--no-dcn', action='store_true', help='same as --model somi')
     ap.add_argument('--sync-bn', action='store_true', help='N > 1: BatchNorm statistics over all ranks (train.py:165-167; off in the reference by default)')
+    ap.add_argument('--amp', choices=['bf16', 'bf16x3'], default=None,
+                    help='opt-in reduced precision of the conv products (train.py:263 autocast): bf16 operands, or bf16x3 split; fp32 accumulate, '
+                         'fp32 tensors / BN / loss / optimizer.  The default (and the headline) is exact fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-wbf', action='store_true', help='--mode infer: one model, forward + NMS only (no second model, no fusion step)')
@@ -302,7 +306,7 @@ def main():
         from somi_amd.train import TrainStep
         _, targets = synthetic_batch(args.batch, args.size, nc=nc, seed=1000 + rank)
         targets = targets.to(dev)
-        trainer = TrainStep(model, dict(HYP_VISDRONE), args.batch, dist=dist, sync_bn=args.sync_bn)
+        trainer = TrainStep(model, dict(HYP_VISDRONE), args.batch, dist=dist, sync_bn=args.sync_bn, amp=args.amp)
 
         def step():
             return trainer.step(imgs, targets)
@@ -310,6 +314,8 @@ def main():
         step = infer_step
 
     from somi_amd.dist import timed_steps, whole_job_rate
+    if args.mode == 'infer':
+        ops.CONV_PREC = ops.PREC[args.amp]                          # (training: TrainStep sets it around its forward + backward)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -347,6 +353,8 @@ def main():
         name, (cnt, flops, secs) = max(by.items(), key=lambda kv: kv[1][2])
         all_flops, all_secs = sum(v[1] for v in by.values()), sum(v[2] for v in by.values())
         achieved = flops / secs / 1e12
+        # peak of the matrix instruction the products go through, in ALGORITHMIC FLOPs: bf16x3 issues 3 MFMAs per product
+        peak_tf = {None: F32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS, 'bf16x3': round(BF16_MFMA_PEAK_TFLOPS / 3, 1)}[args.amp]
         label = MODELS[args.model]
         step_txt = (f'{label} training step: uint8 ingest + forward (batch-stat BN) + ComputeLoss + backward + '
                     f'{"gradient all-reduce + " if world > 1 else ""}Adam + EMA' if args.mode == 'train' else
@@ -375,22 +383,24 @@ def main():
                        else f'images/sec infer ({"2 models x (forward+NMS) + WBF" if ensemble else "forward+NMS"}) @{args.size}, {shaped}, {label}'),
             'value': round(whole_job_rate(args.batch, args.steps, world, dt), 2), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {None: 'f32', 'bf16': 'bf16 (conv products; fp32 accumulate, tensors, BN, loss, optimizer)',
+                      'bf16x3': 'bf16x3 (conv products as 3 bf16 MFMAs on hi/lo splits; fp32 everything else)'}[args.amp], 'data': 'synthetic',
             'config': {'workload': f'{step_txt}, {args.size}x{args.size}, batch {args.batch}/GPU ({which})',
                        'batch_per_gpu': args.batch, 'imgsz': args.size, 'params': nparams, 'classes': nc,
                        'parallelism': ((f'dp{world}' + (' sync-bn' if args.sync_bn and world > 1 else '')) if args.mode == 'train'
                                        else f'replicas x{world}')},
             'infer_images_per_s_per_gpu': None if infer_ips is None else round(infer_ips, 2),   # ONE model: forward + decode + NMS
             'latency_ms_per_image': round(dt / args.steps * 1e3 / args.batch, 4),   # device time of one step / images in it (throughput latency)
-            'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': peak_tf,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak_tf, 4), 'traffic': None,
                          'launches': cnt, 'avg_launch_us': round(secs / cnt * 1e6, 2),
                          'avg_launch_gflop': round(flops / cnt / 1e9, 3),
                          'all_conv_tflops': round(all_flops / all_secs / 1e12, 2),
                          'conv_share_of_step': round(all_secs / dt, 3)},
         }
         # the committed counter passes are of the DEFAULT command (DCN graph, training, batch 32, 640): null for any other workload
-        profiled = args.model == 'somi-dcn' and args.mode == 'train' and args.batch == 32 and args.size == 640
+        profiled = args.model == 'somi-dcn' and args.mode == 'train' and args.batch == 32 and args.size == 640 and args.amp is None
         out['roofline']['traffic'] = pmc_traffic(name) if profiled else None
         if dcn:                                                  # the DCNv3 operator kernels of the step against the HBM roofline
             kernels = {}

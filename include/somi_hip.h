@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 10
+#define SOMI_ABI_VERSION 11
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -38,6 +38,8 @@ typedef void *somi_stream_t;
 
 int somi_abi_version(void);
 const char *somi_last_error(void);
+/* sizeof of a descriptor struct as the library was compiled (0: somi_conv_desc, 1: somi_loss_desc): lets a binding check its mirror */
+size_t somi_sizeof_desc(int which);
 
 /* ------------------------------------------------------------------------------------------
  * Activations used in fused epilogues.
@@ -87,6 +89,12 @@ typedef struct somi_conv_desc {
     float *stat_sum;
     float *stat_sumsq;
     const float *stat_pivot;
+    /* Opt-in reduced precision of the products (train.py:263 `amp.autocast`; the default 0 is the exact fp32 path every parity claim is
+     * made on): 1 = operands rounded to bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate - autocast's arithmetic), 2 = "bf16x3": each
+     * operand split into two bf16 values and hi*hi + hi*lo + lo*hi accumulated in fp32 (~1e-5 relative error).  Tensors stay fp32 in
+     * HBM either way.  Honoured by the plain channel-aligned launches (Cin % 32 == 0, shared weights, no operand modulation) of
+     * somi_conv2d_nhwc_f32 / _dgrad_ / _wgrad_; every other launch computes in exact fp32. */
+    int32_t prec;
 } somi_conv_desc;
 
 int somi_conv2d_nhwc_f32(const somi_conv_desc *d, somi_stream_t stream);

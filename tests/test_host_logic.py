@@ -21,12 +21,14 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(L, name), f'{name} is declared in include/somi_hip.h but not exported'
-    assert _lib.lib().somi_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.lib().somi_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_struct_layouts_match_header():
     from somi_amd._lib import ConvDesc, LossDesc
-    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 22 * 4 + 8 + 8 + 8 + 3 * 8
+    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 22 * 4 + 8 + 8 + 8 + 3 * 8 + 4 + 4      # ... + prec + tail padding
+    from somi_amd import _lib
+    assert _lib.lib().somi_sizeof_desc(0) == ctypes.sizeof(ConvDesc) and _lib.lib().somi_sizeof_desc(1) == ctypes.sizeof(LossDesc)
     assert ctypes.sizeof(LossDesc) == 4 * 8 + 4 * 8 + 4 * 4 + 4 * 4 + 5 * 4 + 4 + 2 * 8 + 4 * 4 + 13 * 4 + 4
 
 

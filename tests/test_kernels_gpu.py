@@ -464,3 +464,41 @@ def test_conv_full_size_adjoint_identities(B, H, Cin, Cout, k, s):
     y2 = ops.conv2d_nhwc(x2, w, None, kh=k, kw=k, stride=s, pad=p)
     err = (y12 - (0.5 * y - 2.0 * y2)).abs().max().item()
     assert err <= 2e-5 * y.abs().max().item(), ('linearity', err)
+
+
+@pytest.mark.parametrize('prec,rel', [('bf16', 2e-2), ('bf16x3', 1e-4)])
+@pytest.mark.parametrize('B,H,Cin,Cout,k,s', [(2, 24, 64, 128, 3, 1),       # 128 x 128 tile
+                                              (4, 40, 128, 256, 3, 1),      # stream-K: cut tiles finish in the fp32 fix-up kernel
+                                              (3, 20, 128, 256, 3, 2),      # stride 2: the data gradient runs its parity classes
+                                              (2, 32, 256, 64, 1, 1),       # 128 x 64 tile, 1x1
+                                              (5, 17, 96, 160, 3, 1)])      # ragged M / N, Cin = 3 K-tiles per tap
+def test_conv_reduced_precision_forms(prec, rel, B, H, Cin, Cout, k, s):
+    """Opt-in `amp` forms of forward / dgrad / wgrad (somi_conv_desc.prec; train.py:263 runs the reference's GPU loop under autocast):
+    operands rounded to bf16, or split into two bf16 values with three products (bf16x3), fp32 accumulate.  Against the exact fp32 HIP
+    kernels on the same inputs.  Bars: bf16 2e-2 of the output range (the reference's own bar for half in models/ops_dcnv3/test.py:85
+    is rtol 1e-2 / atol 1e-3), bf16x3 1e-4 (16 mantissa bits per operand)."""
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    p = k // 2
+    x = torch.randn(B, H, H, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, k * k * Cin, generator=g) / math.sqrt(k * k * Cin)).to(d)
+    wt = (torch.randn(Cin, k * k * Cout, generator=g) / math.sqrt(k * k * Cout)).to(d)
+    b = torch.randn(Cout, generator=g).to(d)
+
+    def run():
+        y = ops.conv2d_nhwc(x, w, b, kh=k, kw=k, stride=s, pad=p, act='silu')
+        dy = torch.sin(torch.arange(y.numel(), device=d, dtype=torch.float32) * 0.37).view_as(y)
+        dx = ops.conv2d_dgrad_nhwc(dy, wt, B=B, H=H, W=H, cin=Cin, kh=k, kw=k, stride=s, pad=p)
+        dw = ops.conv2d_wgrad_nhwc(x, dy, kh=k, kw=k, stride=s, pad=p)
+        return y, dx, dw
+    want = run()
+    ops.CONV_PREC = ops.PREC[prec]
+    try:
+        got = run()
+    finally:
+        ops.CONV_PREC = 0
+    for a_, b_, what in zip(got, want, ('forward', 'dgrad', 'wgrad')):
+        rel_close(a_, b_, rel=rel, what=f'{prec} {what}')
+        if what != 'wgrad' or (Cout >= 128 and k * k * Cin >= 128):       # (the 64-wide wgrad tiles stay on the fp32 kernel)
+            assert not torch.equal(a_, b_), f'{prec} {what}: bit-identical to fp32 - the reduced-precision kernel did not run'

@@ -832,3 +832,50 @@ def test_uavdt_1280_nc3_training_step_gradients():
         assert e_mine <= max(4 * e_o32, 1e-3), f'train outputs @1280: HIP {e_mine:.2e} vs fp32 CPU {e_o32:.2e} (relative to fp64)'
     del p64, p32
     _conditioned_gradient_check(mine, ref, ref64, cond.sums, '1280 nc=3 with DCNv3 sites')
+
+
+@pytest.mark.parametrize('amp,loss_rel,grad_med,grad_q90', [('bf16x3', 2e-5, 2e-4, 2e-3), ('bf16', 1e-2, 3e-2, 2e-1)])
+def test_amp_training_step_stays_in_its_band(amp, loss_rel, grad_med, grad_q90):
+    """Opt-in reduced precision (TrainStep(amp=...), train.py:263 autocast): the whole small SOMI graph, one forward + loss + backward with the
+    conv family's products on the bf16 matrix instructions, against the exact fp32 path on the same weights and batch.  The bands are
+    stated here: bf16x3 (two bf16 values per operand, three products) keeps the loss to 2e-5 and the median parameter-gradient error to
+    2e-4 of the gradient's scale; plain bf16 (autocast's arithmetic) 1e-2 / 3e-2 - the same order as the reference's own bar for its
+    half-precision DCNv3 kernels (rtol 1e-2, models/ops_dcnv3/test.py:85).  Everything that is not a conv product stays fp32."""
+    from somi_amd import ops
+    from somi_amd.configs import HYP_VISDRONE, SOMI_ANCHORS, fill_state, somi_cfg, synthetic_batch
+    from somi_amd.loss import ComputeLoss
+    from somi_amd.model import Model
+    cfg = somi_cfg(0.5, 0.33, anchors=SOMI_ANCHORS, dcn=True)     # width 0.5: most layers have Cin % 32 == 0 and take the bf16 kernels
+    model = fill_state(Model(cfg), 4).cuda().train()
+    model.hyp = dict(HYP_VISDRONE)
+    imgs, targets = synthetic_batch(4, 128, seed=9)
+    imgs, targets = imgs.cuda(), targets.cuda()
+
+    def run(prec):
+        for p in model.parameters():
+            p.grad = None
+        ops.CONV_PREC = ops.PREC[prec]
+        try:
+            loss, _ = ComputeLoss(model)(model(imgs), targets)
+            loss.backward()
+        finally:
+            ops.CONV_PREC = 0
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    bufs = {n: b.clone() for n, b in model.named_buffers()}
+    l0, g0 = run(None)
+    with torch.no_grad():                                        # same BatchNorm running statistics for the second pass
+        for n, b in model.named_buffers():
+            b.copy_(bufs[n])
+    l1, g1 = run(amp)
+    assert abs(l1.item() - l0.item()) <= loss_rel * abs(l0.item()), f'{amp}: loss {l1.item()} vs fp32 {l0.item()}'
+    assert l1.item() != l0.item(), f'{amp}: loss bit-identical to fp32 - the reduced-precision kernels did not run'
+    rel = []
+    for n, g in g0.items():
+        scale = g.abs().max().item()
+        if scale > 1e-6:
+            rel.append((g1[n] - g).abs().max().item() / scale)
+    rel = torch.tensor(rel)
+    print(f'{amp}: loss rel {abs(l1.item() - l0.item()) / abs(l0.item()):.2e}; gradient error median {float(rel.median()):.2e} '
+          f'q90 {float(rel.quantile(0.9)):.2e} max {float(rel.max()):.2e}')
+    assert rel.median() <= grad_med and rel.quantile(0.9) <= grad_q90, (float(rel.median()), float(rel.quantile(0.9)))

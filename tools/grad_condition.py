@@ -65,3 +65,13 @@ import statistics  # noqa: E402
 print('relative error population: HIP median %.2e q90 %.2e max %.2e | fp32 CPU median %.2e q90 %.2e max %.2e' % (
     statistics.median(t[2] for t in ch.values()), sorted(t[2] for t in ch.values())[int(0.9 * len(ch))], max(t[2] for t in ch.values()),
     statistics.median(t[2] for t in cc.values()), sorted(t[2] for t in cc.values())[int(0.9 * len(cc))], max(t[2] for t in cc.values())))
+
+# candidate bar: e_hip(p) <= K * (u + c0 * 2^-24 * cond(p)), u = the fp32 CPU path's own error level on well-conditioned parameters
+import torch as _t  # noqa: E402
+well = sorted(t[2] for t in cc.values() if t[3] < 100)
+u50, u90, u99 = well[len(well) // 2], well[int(0.9 * len(well))], well[min(len(well) - 1, int(0.99 * len(well)))]
+print(f'fp32 CPU error on well-conditioned parameters (cond < 100, {len(well)} of them): median {u50:.2e} q90 {u90:.2e} q99 {u99:.2e} max {well[-1]:.2e}')
+for c0 in (16, 64, 256):
+    ratios = sorted(((ch[n][2] / (u90 + c0 * 2.0 ** -24 * ch[n][3]), n) for n in ch), reverse=True)
+    rc = sorted(((cc[n][2] / (u90 + c0 * 2.0 ** -24 * cc[n][3]), n) for n in cc), reverse=True)
+    print(f'c0 {c0}: worst e / (u90 + c0 eps cond): HIP', [(round(v, 2), n) for v, n in ratios[:5]], '| CPU', [(round(v, 2), n) for v, n in rc[:3]])

@@ -15,3 +15,6 @@ void set_error(const char *fmt, ...) {
 
 extern "C" int somi_abi_version(void) { return SOMI_ABI_VERSION; }
 extern "C" const char *somi_last_error(void) { return somi::g_err; }
+// sizeof of the descriptor structs as this library was compiled: a binding checks its own mirror against them (which = 0: somi_conv_desc,
+// 1: somi_loss_desc)
+extern "C" size_t somi_sizeof_desc(int which) { return which == 0 ? sizeof(somi_conv_desc) : which == 1 ? sizeof(somi_loss_desc) : 0; }

@@ -38,6 +38,8 @@ namespace somi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;                    // K-tile (floats)
 constexpr int LDS_LD = BK + 4;            // sizes the LDS array (the epilogue stages D tiles with this row stride)
@@ -71,6 +73,7 @@ struct ConvArgs {
     int cls;      // dgrad on the FAST path: grid.y = stride^2 parity classes, each walks only the taps that reach it
     int sk;       // stream-K: gridDim.x persistent workgroups share tiles_m*tiles_n*nkt units (FAST, no strided classes)
     float *ws;    // stream-K partial accumulators: [workgroup][2][BM*BN]
+    int ns;       // 0: exact fp32; 1: bf16 operands; 2: bf16x3 split (plain FAST launches of the 8-wave tiles only)
 };
 
 constexpr int SK_GRID = 512;              // 256 CUs x 2 resident workgroups
@@ -79,6 +82,17 @@ constexpr int SK_GRID = 512;              // 256 CUs x 2 resident workgroups
 struct RowMap {
     int Mrows, HoWo, Wc, cstep, h0, w0, bz;
     bool strided;
+};
+
+// LDS floats of a tile variant: the two operand buffers, or the epilogue's D staging if that is larger.  The staging is split into
+// 32-column slabs when the whole D tile would not fit the (padded) operand area.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct TileLds {
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, W = WAVES_M * WAVES_N;
+    static constexpr bool SPLIT = W * WM * (WN + 4) > 2 * (BM + BN) * LDS_LD;
+    static constexpr int SW = SPLIT ? 32 : WN;
+    static constexpr int STAGE = W * WM * (SW + 4), OPS = 2 * (BM + BN) * OP_LD;
+    static constexpr int FLOATS = STAGE > OPS ? STAGE : OPS;
 };
 
 // Epilogue.  C/D map of the 32x32 MFMA: col = lane&31 (-> m), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (-> n).
@@ -90,9 +104,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BN / WAVES_N / 32][B
                                               const RowMap &rm, int m0, int n0) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32;
     // the whole D tile staged at once when it fits the operand buffers, else one 32-column slab of every wave tile per pass
-    constexpr bool SPLIT = WAVES_M * WAVES_N * WM * (WN + 4) > 2 * (BM + BN) * LDS_LD;
-    constexpr int SW = SPLIT ? 32 : WN, NPASS = WN / SW, SLD = SW + 4;
-    static_assert(WAVES_M * WAVES_N * WM * SLD <= 2 * (BM + BN) * LDS_LD, "epilogue staging does not fit the operand buffers");
+    using TL = TileLds<BM, BN, WAVES_M, WAVES_N>;
+    constexpr int SW = TL::SW, NPASS = WN / SW, SLD = SW + 4;
+    static_assert(WAVES_M * WAVES_N * WM * SLD <= TL::FLOATS, "epilogue staging does not fit the LDS array");
     const somi_conv_desc &d = a.d;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -192,7 +206,12 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned of
 }
 // FAST: Cin % 32 == 0 (every K-tile lies inside one filter tap), kh*kw <= 32: the tap walk is wave-uniform (SALU), each
 // row's padding test is one bit of a mask built once, and a fetch costs 4 VALU per 16 B.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST>
+// NS (opt-in reduced precision, train.py:263 `amp.autocast`): 0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 1 = operands rounded to
+// bf16, fp32 accumulate (v_mfma_f32_32x32x16_bf16: autocast's arithmetic); 2 = "bf16x3": every operand split x = hi + lo into two
+// bf16 values and hi*hi + hi*lo + lo*hi accumulated in fp32 - 16 mantissa bits per operand, ~1e-5 relative error, 3 MFMAs at 16x the
+// fp32 rate.  The operands stay fp32 in HBM and are converted while they are staged into LDS ([row][32 bf16 hi | 32 bf16 lo] = the
+// fp32 image's 128-byte rows), so nothing outside this kernel changes.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST, int NS = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_M * WAVES_N / 2)) void conv_igemm_f32_kernel(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
@@ -200,10 +219,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
     constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;   // 16 B loads per thread per K-tile (activations / weights)
     constexpr int TILE = (BM + BN) * OP_LD;               // one operand buffer
     // operands go global -> LDS directly (the DMA's LDS base travels in M0[15:0]: both buffers must lie below 64 KB)
-    constexpr bool DMA = FAST && !MODULATE && 2 * TILE * sizeof(float) <= 65536;
+    constexpr bool DMA = FAST && !MODULATE && NS == 0 && 2 * TILE * sizeof(float) <= 65536;
+    static_assert(NS == 0 || (FAST && !MODULATE), "the bf16 forms exist for the plain FAST path only");
     static_assert((WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8) && TM >= 1 && TN >= 1 && A_ROWS >= 1 && B_ROWS >= 1, "bad tiling");
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[TileLds<BM, BN, WAVES_M, WAVES_N>::FLOATS];
 
     const somi_conv_desc &d = a.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -243,8 +263,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
 
     // A thread owns LDS chunk slot (tid & 7) of rows row0 + RPP*i; the slot holds k-chunk slot ^ ((row >> 1) & 7), and (row >> 1) & 7 is
     // the same for all of a thread's rows (RPP, BM are multiples of 16), so the swizzle is one XOR on the thread's fetch column.
-    const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 4, row0 = tid >> 3;   // per-thread fetch column (floats) / first row
+    // (the bf16 forms fetch their natural column and swizzle the LDS address of the converted values instead: 8-byte pieces)
+    const int kc = NS ? (tid & 7) * 4 : ((tid & 7) ^ ((tid >> 4) & 7)) * 4, row0 = tid >> 3;   // per-thread fetch column (floats) / first row
     const int lds_col = (tid & 7) * 4;                                // ... and where it lands in the row's image
+    // bf16 image: 16-byte chunk c of a row (8 bf16: hi k 8c..8c+7 for c < 4, lo for c >= 4) sits at slot c ^ f(row),
+    // f(row) = ((row >> 1) & 7) ^ ((row & 1) << 2): conflict-free ds_read_b128 fragments and ds_write_b64 pieces; lo = hi ^ 64 bytes
+    const int f_st = ((row0 >> 1) & 7) ^ ((row0 & 1) << 2);           // same for all of a thread's rows (RPP, BM multiples of 16)
+    const int st_off = ((((tid & 7) >> 1) ^ f_st) << 2) + ((tid & 1) << 1);   // float offset of this thread's 4 hi values in its row
+    const int f_rd = ((lane >> 1) & 7) ^ ((lane & 1) << 2);
+    int fo16[2];                                                      // float offset of hi chunk 2s + (lane >> 5) in the lane's row
+#pragma unroll
+    for (int st = 0; st < 2; ++st) fo16[st] = ((2 * st + (lane >> 5)) ^ f_rd) << 2;
     const int aw_off = (wm * WM + (lane & 31)) * OP_LD;               // activation rows of this wave (fragment row = lane & 31)
     const int bw_off = (BM + wn * WN + (lane & 31)) * OP_LD;          // weight rows of this wave
     int fo[4];                                                        // float offset of k-chunk 2j + (lane >> 5) inside the lane's row
@@ -382,7 +411,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) b_off[i] += (b_off[i] != OOB) ? BK * 4u : 0u;
         };
+        auto store_split = [&](float *rowp, const f32x4 &v) {           // 4 floats -> 4 bf16 hi (8 B) [+ 4 bf16 lo in the chunk slot ^ 4]
+            const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<bf16x4 *>(rowp + st_off) = bf16x4{h0, h1, h2, h3};
+            if constexpr (NS == 2) {
+                const bf16x4 lo = {(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1), (__bf16)(v[2] - (float)h2), (__bf16)(v[3] - (float)h3)};
+                *reinterpret_cast<bf16x4 *>(rowp + (st_off ^ 16)) = lo;
+            }
+        };
         auto store_tile = [&](float *buf) {
+            if constexpr (NS != 0) {
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i) store_split(&buf[(row0 + RPP * i) * OP_LD], ra[i]);
+#pragma unroll
+                for (int i = 0; i < B_ROWS; ++i) store_split(&buf[(BM + row0 + RPP * i) * OP_LD], rb[i]);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i)
                 *reinterpret_cast<f32x4 *>(&buf[(row0 + RPP * i) * OP_LD + lds_col]) = ra[i];
@@ -444,9 +489,50 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
             }
         }
         __syncthreads();
+        if constexpr (NS != 0) {
+            // bf16 forms: two 16-deep MFMA steps per K-tile; the next tile's global loads fly behind step 0, its conversion and LDS
+            // stores follow step 1
+            for (int kt = kt0; kt < kt1; ++kt) {
+                const float *cur = lds + ((kt - kt0) & 1) * TILE;
+                float *nxt = lds + ((kt - kt0 + 1) & 1) * TILE;
+                const bool more = kt + 1 < kt1;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float *p = cur + aw_off + i * 32 * OP_LD;
+                        ah[i] = *reinterpret_cast<const bf16x8 *>(p + fo16[st]);
+                        if constexpr (NS == 2) al[i] = *reinterpret_cast<const bf16x8 *>(p + (fo16[st] ^ 16));
+                    }
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) {
+                        const float *p = cur + bw_off + i * 32 * OP_LD;
+                        bh[i] = *reinterpret_cast<const bf16x8 *>(p + fo16[st]);
+                        if constexpr (NS == 2) bl[i] = *reinterpret_cast<const bf16x8 *>(p + (fo16[st] ^ 16));
+                    }
+                    if (st == 0 && more) {
+                        advance_k();
+                        fetch_tile(kt + 1);
+                    }
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            if constexpr (NS == 2) {                  // the small cross terms first
+                                acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[jn], ah[i], acc[jn][i], 0, 0, 0);
+                                acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[jn], al[i], acc[jn][i], 0, 0, 0);
+                            }
+                            acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[jn], ah[i], acc[jn][i], 0, 0, 0);
+                        }
+                }
+                if (more) store_tile(nxt);
+                __syncthreads();
+            }
+        }
         f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-        if (kt1 > kt0) load_frag(lds, 0, fa0, fb0);
-        for (int kt = kt0; kt < kt1; ++kt) {
+        if (NS == 0 && kt1 > kt0) load_frag(lds, 0, fa0, fb0);
+        for (int kt = kt0; NS == 0 && kt < kt1; ++kt) {
             const float *cur = lds + ((kt - kt0) & 1) * TILE;
             float *nxt = lds + ((kt - kt0 + 1) & 1) * TILE;
             const bool more = kt + 1 < kt1;
@@ -501,7 +587,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_M * WAVES_N / 2)) void conv_streamk_fixup_kernel(const ConvArgs a, int G) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32, NT = WAVES_M * WAVES_N * 64;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[TileLds<BM, BN, WAVES_M, WAVES_N>::FLOATS];
     const int nkt = a.K / BK, ntile = a.tiles_m * a.tiles_n;
     const long U = (long)ntile * nkt;
     const int g = blockIdx.x + 1;
@@ -562,10 +648,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
 }
 
 struct TilePlan {
-    int variant;   // 0: 128x128, 1: 64x128, 2: 128x64, 3: 128x32, 4: 128x128 with 8 waves (2 per SIMD and workgroup)
+    int variant;   // 0: 128x128, 1: 64x128, 2: 128x64, 3: 128x32, 4: 128x128 with 8 waves (2 per SIMD and workgroup), 5: 128x64 8 waves,
+                   // 6: 256x128 (experiment), 7: 256x64 with 8 waves of 32x64 (64-channel layers on large maps)
     bool sk;       // stream-K schedule
 };
-static const int kTileBM[7] = {128, 64, 128, 128, 128, 128, 256}, kTileBN[7] = {128, 128, 64, 32, 128, 64, 128};
+static const int kTileBM[8] = {128, 64, 128, 128, 128, 128, 256, 256}, kTileBN[8] = {128, 128, 64, 32, 128, 64, 128, 64};
 static inline int sk_slots(int variant) { return variant == 6 ? SK_GRID / 2 : SK_GRID; }   // resident workgroups chip-wide
 
 static bool fast_path(const somi_conv_desc &d) {
@@ -589,6 +676,12 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
     static const int eight = getenv("SOMI_CONV_8WAVE") ? atoi(getenv("SOMI_CONV_8WAVE")) : 2;
     if (eight && p.variant == 0) p.variant = 4;
     if (eight > 1 && p.variant == 2) p.variant = 5;
+    // 64 output channels on a large map: a 256 x 64 tile of 8 waves x (32 x 64) issues as many MFMAs per barrier as the 128 x 128 form
+    // (the 128 x 64 tile half of them) at 1.25x its operand bytes per FLOP; 80 KB of LDS, two per CU.  Measured round 3: no gain - the
+    // 64 -> 64 3x3 layers at 160x160 ran 98-100 TFLOP/s with it against 101-103 with the 128 x 64 tile, so MFMAs per barrier are not what
+    // holds those layers at 100 (their K = 576 is 18 K-tiles: prologue + epilogue weigh twice what they do at K = 1152).  Off by default.
+    static const int tall = getenv("SOMI_CONV_TALL64") ? atoi(getenv("SOMI_CONV_TALL64")) : 0;
+    if (tall && p.variant == 5 && d.Cout > 32 && fast_path(d) && !d.a_chan_scale && !d.a_pix_scale && M >= 256 * 512) p.variant = 7;
     // 256 x 128 tile, 8 waves of 64 x 64 (a third fewer LDS operand bytes per MFMA than the 64 x 32 wave tile).  Measured (round 2):
     // SLOWER - 109.7 vs 118.8 TFLOP/s on 128->128 3x3 at 160x160, 109 vs 114 at 80x80.  The premise was wrong: a 32x32x2 fp32 MFMA
     // occupies the pipe for 64 cycles, so the 128 x 128 form's operand reads + tile writes are ~31 B/clk per CU, a quarter of the LDS
@@ -630,6 +723,17 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
         if (sk_grid < 2) sk_grid = 2;
     }
     const dim3 grid(sk ? sk_grid : args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
+    if constexpr (WAVES_M * WAVES_N == 8 && BM + BN <= 320) {
+        if (a.ns && fast && !mod) {                                // reduced-precision forms (opt-in): same schedule, fix-up and epilogue
+            if (a.ns == 1)
+                hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true, 1>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
+            else
+                hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true, 2>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
+            if (sk)
+                hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(sk_grid - 1), dim3(WAVES_M * WAVES_N * 64), 0, s, args, sk_grid);
+            return launch_status("somi_conv2d_nhwc_f32 (bf16)");
+        }
+    }
     if (mod && fast)
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     else if (mod)
@@ -715,6 +819,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
                                  (!d.stat_pivot || aligned16(d.stat_pivot))),
                  SOMI_EINVAL, "conv: statistics need Cout %% 4 == 0, shared weights, 16 B aligned buffers");
     a.dgrad = dgrad;
+    a.ns = (d.prec == 1 || d.prec == 2) && !d.per_sample_w ? d.prec : 0;
     a.cls = 0;
     a.sk = 0;
     a.ws = nullptr;
@@ -727,6 +832,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
         case 4: return launch<128, 128, 2, 4>(a, tp.sk, s);
         case 5: return launch<128, 64, 4, 2>(a, tp.sk, s);
         case 6: return launch<256, 128, 4, 2>(a, tp.sk, s);
+        case 7: return launch<256, 64, 8, 1>(a, tp.sk, s);
         default: return launch<128, 32, 4, 1>(a, tp.sk, s);
     }
 }
@@ -752,7 +858,7 @@ extern "C" int somi_conv2d_dgrad_nhwc_f32(const somi_conv_desc *f, const float *
     g.Ho = f->H; g.Wo = f->W; g.Cout = f->Cin; g.y_cs = dx_cs; g.y_coff = dx_coff;                  // rows = forward-input pixels
     g.kh = f->kh; g.kw = f->kw; g.stride = f->stride; g.pad = f->pad; g.dil = 1;
     g.res_cs = acc_cs; g.res_coff = acc_coff; g.act = SOMI_ACT_NONE; g.per_sample_w = f->per_sample_w;
-    g.workspace = f->workspace; g.workspace_bytes = f->workspace_bytes;
+    g.workspace = f->workspace; g.workspace_bytes = f->workspace_bytes; g.prec = f->prec;
     g.residual2 = f->residual2; g.res2_cs = f->res2_cs; g.res2_coff = f->res2_coff;
     return conv_launch(&g, stream, 1);
 }
@@ -762,7 +868,7 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
     const int M = dp->per_sample_w ? dp->Ho * dp->Wo : dp->B * dp->Ho * dp->Wo;
     const int mod = (dp->a_chan_scale || dp->a_pix_scale) ? 1 : 0;
     const int fast = (dp->Cin % somi::BK == 0 && dp->kh * dp->kw <= 32) ? 1 : 0;
-    static const char *tiles[7] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1", "128,128,2,4", "128,64,4,2", "256,128,4,2"};
+    static const char *tiles[8] = {"128,128,2,2", "64,128,1,4", "128,64,2,2", "128,32,4,1", "128,128,2,4", "128,64,4,2", "256,128,4,2", "256,64,8,1"};
     static thread_local char name[96];
     snprintf(name, sizeof(name), "conv_igemm_f32_kernel<%s,%s,%s>", tiles[somi::plan_tiles(*dp, M, 0).variant], mod ? "true" : "false",
              fast ? "true" : "false");
@@ -771,7 +877,7 @@ extern "C" const char *somi_conv2d_kernel_name(const somi_conv_desc *dp) {
 
 extern "C" int somi_conv2d_stat_rows(const somi_conv_desc *dp) {
     if (!dp || dp->Cout <= 0 || dp->Ho <= 0 || dp->Wo <= 0 || dp->B <= 0 || dp->per_sample_w) return 0;
-    static const int waves_m[7] = {2, 1, 2, 4, 2, 4, 4};
+    static const int waves_m[8] = {2, 1, 2, 4, 2, 4, 4, 8};
     const int M = dp->B * dp->Ho * dp->Wo;
     const int v = somi::plan_tiles(*dp, M, 0).variant;
     return somi::cdiv(M, somi::kTileBM[v]) * waves_m[v];

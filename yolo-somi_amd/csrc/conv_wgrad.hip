@@ -18,6 +18,10 @@ namespace somi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WG_PIX = 32;                  // pixels per K-tile
 constexpr unsigned W_OOB = 0xFFFFFFE0u;
@@ -32,6 +36,7 @@ struct WgradArgs {
     int bm, bn;                              // tile variant
     int per_sample;
     unsigned x_bytes, dy_bytes;
+    int ns;                                  // 0: exact fp32; 1: bf16; 2: bf16x3 (128 x 128 tile, shared weights)
 };
 
 __device__ __forceinline__ f32x4 wbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -51,9 +56,24 @@ __device__ __forceinline__ void lds_dma_wait() {
 #endif
 }
 
-template <int BM, int BN, int NW = 4>   // co rows x k columns per tile: 128 x {128,64,32} or 64 x {128,64}; NW waves (8: 128 x 128 only)
+// transposed LDS read (gfx950 ds_read_b64_tr_b16): per 16-lane group a block of 4 rows x 16 columns of 16-bit values, delivered
+// column-major - lane i of the group receives column i of the 4 rows.  Device pass only (the host pass just needs the kernel's stub).
+__device__ __forceinline__ i16x4 lds_read_tr16(const char *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4 *)p);
+#else
+    return i16x4{0, 0, 0, 0};
+#endif
+}
+
+// NS (opt-in reduced precision, see conv_igemm.hip): 0 = exact fp32; 1 = bf16 operands; 2 = bf16x3 split.  The bf16 forms (128 x 128 tile,
+// 8 waves) convert dy / x while they are staged into a [pixel][channel] bf16 image (256-byte rows, 16-byte chunks XOR-swizzled by
+// ((row & 3) << 2) | ((row >> 2) & 3)) and read their MFMA operands - 8 consecutive PIXELS of one channel per lane - with the hardware
+// transposing read.
+template <int BM, int BN, int NW = 4, int NS = 0>   // co rows x k columns per tile: 128 x {128,64,32} or 64 x {128,64}; NW waves (8: 128 x 128 only)
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const WgradArgs a) {
     constexpr int NT = NW * 64;
+    static_assert(NS == 0 || (BM == 128 && BN == 128 && NW == 8), "the bf16 forms exist for the 128 x 128 tile with 8 waves");
     constexpr int WAVES_N = NW == 8 ? 4 : (BM == 64 ? 2 : (BN == 128 ? 2 : 1)), WAVES_M = NW / WAVES_N;
     static_assert(BM / WAVES_M >= 32 && BN / WAVES_N >= 32, "bad wgrad tiling");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
@@ -135,6 +155,43 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
         }
     };
 
+    // bf16 forms: staging through registers (fetch -> convert -> ds_write_b64)
+    f32x4 ra[A_N], rb[B_N];
+    auto fetch = [&](int pt) {
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+            const int pl = pt + a_row0 + i * A_ROWS_PER_PASS;
+            const bool ok = a_col_ok && pl < npl;
+            const unsigned off = ((set_p0 + (unsigned)pl) * (unsigned)a.dy_cs + a_col) * 4u;
+            ra[i] = wbuf_load4(rdy, ok ? off : W_OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) {
+            const int pl = pt + b_row0 + i * B_ROWS_PER_PASS;
+            const int hi = bho[i] * a.stride - a.pad + r, wi = bwo[i] * a.stride - a.pad + q;
+            const bool ok = b_col_ok && pl < npl && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const unsigned off = ((unsigned)((bb[i] * a.H + hi) * a.W + wi) * (unsigned)a.x_cs + b_colo) * 4u;
+            rb[i] = wbuf_load4(rx, ok ? off : W_OOB);
+        }
+    };
+    // image of one buffer (bytes): dy hi [32 px][128] bf16 | dy lo | x hi | x lo, 8 KB each
+    auto split_store = [&](char *img, int row, int quad, const f32x4 &v) {
+        const int key = ((row & 3) << 2) | ((row >> 2) & 3);
+        char *p = img + 256 * row + 16 * ((quad >> 1) ^ key) + 8 * (quad & 1);
+        const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+        *reinterpret_cast<bf16x4 *>(p) = bf16x4{h0, h1, h2, h3};
+        if constexpr (NS == 2)
+            *reinterpret_cast<bf16x4 *>(p + 8192) = bf16x4{(__bf16)(v[0] - (float)h0), (__bf16)(v[1] - (float)h1), (__bf16)(v[2] - (float)h2),
+                                                           (__bf16)(v[3] - (float)h3)};
+    };
+    auto store_bf16 = [&](float *buf) {
+        char *img = reinterpret_cast<char *>(buf);
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) split_store(img, a_row0 + i * A_ROWS_PER_PASS, a_quad, ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) split_store(img + 16384, b_row0 + i * B_ROWS_PER_PASS, b_quad, rb[i]);
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -161,12 +218,71 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
         }
     };
 
-    if (nkt > 0) {
+    if constexpr (NS != 0) {
+        // lane geometry of the transposed reads: group half cg = channels +16, q = pixel row of the 4-row block, p = 8-byte piece
+        const int h = lane >> 5, cg = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+        int lpart[2];                                                 // per 4-pixel block jj: row bytes + the low chunk bits + the piece
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int keylo = (2 * h + jj) & 3;                       // (row >> 2) & 3 of row 16 st + 8 h + 4 jj + q
+            lpart[jj] = 256 * (8 * h + 4 * jj + q4) + 16 * ((2 * cg + (p4 >> 1)) ^ keylo) + 8 * (p4 & 1);
+        }
+        int ta[TM], tb[TN];                                           // the high chunk bits of a 32-channel tile, swizzled by (row & 3) << 2 = q << 2
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ta[i] = 16 * ((((wm * WM + i * 32) >> 3)) ^ (q4 << 2));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tb[j] = 16384 + 16 * ((((wn * WN + j * 32) >> 3)) ^ (q4 << 2));
+        auto frag = [&](const char *img, int off) -> bf16x8 {
+            const i16x4 lo4 = lds_read_tr16(img + off + lpart[0]), hi4 = lds_read_tr16(img + off + lpart[1]);
+            return __builtin_bit_cast(bf16x8, i16x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]});
+        };
+        if (nkt > 0) {
+            fetch(0);
+            store_bf16(lds);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char *cur = reinterpret_cast<const char *>(lds + (kt & 1) * TILE);
+            float *nxt = lds + ((kt + 1) & 1) * TILE;
+            const bool more = kt + 1 < nkt;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = frag(cur, 4096 * st + ta[i]);
+                    if constexpr (NS == 2) al[i] = frag(cur, 8192 + 4096 * st + ta[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = frag(cur, 4096 * st + tb[j]);
+                    if constexpr (NS == 2) bl[j] = frag(cur, 8192 + 4096 * st + tb[j]);
+                }
+                if (st == 0 && more) {
+                    advance();
+                    fetch((kt + 1) * WG_PIX);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (NS == 2) {                      // the small cross terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (more) store_bf16(nxt);
+            __syncthreads();
+        }
+    }
+    if (NS == 0 && nkt > 0) {
         dma(lds, 0);
         lds_dma_wait();               // the DMA's LDS writes are tracked by the vector-memory counter
     }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; NS == 0 && kt < nkt; ++kt) {
         const float *cur = lds + (kt & 1) * TILE;
         float *nxt = lds + ((kt + 1) & 1) * TILE;
         const bool more = kt + 1 < nkt;
@@ -306,7 +422,10 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid(a.tiles_co * a.tiles_k * a.splits, 1, sets);
     static const int eight = getenv("SOMI_WGRAD_8WAVE") ? atoi(getenv("SOMI_WGRAD_8WAVE")) : 2;
-    if (a.bm == 128 && a.bn == 128 && eight) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8>), grid, dim3(512), 0, s, a);
+    a.ns = (fwd->prec == 1 || fwd->prec == 2) && !a.per_sample && a.bm == 128 && a.bn == 128 ? fwd->prec : 0;
+    if (a.ns == 1) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8, 1>), grid, dim3(512), 0, s, a);
+    else if (a.ns == 2) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8, 2>), grid, dim3(512), 0, s, a);
+    else if (a.bm == 128 && a.bn == 128 && eight) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8>), grid, dim3(512), 0, s, a);
     else if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128 && a.bn == 64) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, s, a);

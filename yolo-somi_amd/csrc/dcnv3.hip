@@ -362,6 +362,7 @@ struct GinGeo {
     float *staging;              // [N][G][tiles][WH*WW][Gc]
     unsigned *overflow;          // FAR taps (added with fp32 atomics): 0 <=> bit-reproducible
     unsigned *near;              // [N][G][tiles] masks of the destination tiles that receive a tile's NEAR taps; nullptr: no near pass (stride != 1)
+    unsigned *near_any;          // one word per chunk of images: != 0 iff any tile of the chunk has near taps (the near pass exits on 0)
 };
 
 // A tap at input pixel (h, w) that fell outside its tile's window: its destination tile relative to the tile under the window's centre.
@@ -537,7 +538,10 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
             *reinterpret_cast<f32x4 *>(dst + cell * GC + c4) = r;
         }
     }
-    if (threadIdx.x == 0 && q.near) q.near[((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile] = nearmask;
+    if (threadIdx.x == 0 && q.near) {
+        q.near[((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile] = nearmask;
+        if (nearmask) atomicOr(q.near_any, 1u);
+    }
     // 5. FAR taps: fp32 atomics into grad_input like the reference's own kernel (128 contiguous bytes per tap)
     if (novf) {
         float *gin = a.grad_input + (long)n * a.H * a.W * a.C + g * GC + c;
@@ -740,7 +744,10 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
                 }
         }
     }
-    if (tid == 0 && q.near) q.near[((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile] = nearmask;
+    if (tid == 0 && q.near) {
+        q.near[((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile] = nearmask;
+        if (nearmask) atomicOr(q.near_any, 1u);
+    }
     // 5. FAR taps: fp32 atomics into grad_input like the reference's own kernel (one channel per lane)
     if (novf) {
         constexpr int SLOTS = NT / GC;
@@ -826,10 +833,15 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_near_kernel(const DcnArgs a, co
     constexpr int NG = 256 / GC;                                      // thread groups; group j owns the cells with cell % NG == j
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = tid % GC, grp = tid / GC;
-    const int dt_w = (a.W + 7) >> 3;
-    const int ty = blockIdx.x / dt_w, tx = blockIdx.x % dt_w, n = blockIdx.y, g = blockIdx.z;
+    if (*q.near_any == 0u) return;                                    // the usual case: no tile of this chunk has a near tap
+    const int dt_w = (a.W + 7) >> 3, dt_n = ((a.H + 7) >> 3) * dt_w;
     const int ntile = q.tiles_h * q.tiles_w;
     const int cb_h = (q.lo_h + (q.WH >> 1)) >> 3, cb_w = (q.lo_w + (q.WW >> 1)) >> 3;    // source tile t sits in destination tile t + cb
+    const int nrec = GIN_TP * a.K;
+    const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
+    for (long item = blockIdx.x; item < (long)dt_n * a.N * a.G; item += gridDim.x) {    // (destination tile, image, group)
+    const int dtile = (int)(item % dt_n), n = (int)((item / dt_n) % a.N), g = (int)(item / ((long)dt_n * a.N));
+    const int ty = dtile / dt_w, tx = dtile % dt_w;
     const unsigned *masks = q.near + ((long)n * a.G + g) * ntile;
     // which of the 25 neighbours are flagged for this destination (uniform)
     unsigned todo = 0;
@@ -839,10 +851,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_near_kernel(const DcnArgs a, co
         const int bit = (ty - (th + cb_h) + 2) * 5 + (tx - (tw + cb_w) + 2);
         if ((masks[th * q.tiles_w + tw] >> bit) & 1u) todo |= 1u << s;
     }
-    if (!todo) return;
+    if (!todo) continue;
+    __syncthreads();                                                  // the previous item's image has been flushed
     for (int i = tid; i < GIN_TP * GC; i += 256) accL[i] = 0.f;
-    const int nrec = GIN_TP * a.K;
-    const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
     for (int s = 0; s < 25; ++s) {                                    // ascending (th, tw): the fixed order of the sums
         if (!((todo >> s) & 1u)) continue;
         const int th = ty + s / 5 - 2 - cb_h, tw = tx + s % 5 - 2 - cb_w;
@@ -911,6 +922,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_near_kernel(const DcnArgs a, co
             float *o = a.grad_input + (((long)n * a.H + h) * a.W + w) * a.C + g * GC + c;
             *o += accL[cell * GC + c];
         }
+    }
     }
 }
 
@@ -1215,7 +1227,7 @@ static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &workspace
     lds = (size_t)GIN_TP * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(RecG) + 4 * sizeof(float) + 4) + GIN_OVF_CAP * sizeof(OvfG) +
           3 * ((size_t)q.WH * q.WW + 1) * sizeof(int);
     if (lds > 150 * 1024 || (long)q.tiles_h * q.tiles_w > 65535L * 32) return false;
-    static const long cap_mb = [] { const char *e = getenv("SOMI_DCN_SLAB_MB"); const long v = e ? atol(e) : 128; return v < 1 ? 1 : v; }();
+    static const long cap_mb = [] { const char *e = getenv("SOMI_DCN_SLAB_MB"); const long v = e ? atol(e) : 1024; return v < 1 ? 1 : v; }();
     const size_t per_img = (size_t)a.G * q.tiles_h * q.tiles_w * q.WH * q.WW * a.Gc * sizeof(float);
     long c = (long)(((size_t)cap_mb << 20) / per_img);
     chunk = c < 1 ? 1 : (c > a.N ? a.N : (int)c);
@@ -1324,7 +1336,7 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
         // the near pass needs stride 1 (source tile t then sits over destination tile t + const) and 8-aligned tiles of the INPUT image
         static const bool near_on = [] { const char *e = getenv("SOMI_DCN_NEAR"); return !(e && e[0] == '0'); }();
         q.near = (near_on && stride_h == 1 && stride_w == 1) ? reinterpret_cast<unsigned *>(wsb + slab) : nullptr;
-        (void)hipMemsetAsync(q.overflow, 0, 256, s);
+        (void)hipMemsetAsync(q.overflow, 0, 256, s);                  // the far-tap counter and the per-chunk near_any words behind it
         // B on the matrix cores for 32-wide groups when its LDS image fits (SOMI_DCN_GIN=exact keeps the list sums for comparisons)
         const char *gsel = getenv("SOMI_DCN_GIN");
         const size_t ncell_ = (size_t)q.WH * q.WW, recb = (size_t)GIN_TP * a.K * sizeof(RecM), gotb = (size_t)Gc * GMM_LD * sizeof(float);
@@ -1347,7 +1359,10 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
             c.mask = a.mask + n0 * om_img;
             c.npix = (long)c.N * a.Ho * a.Wo;
             const dim3 grid(q.tiles_h * q.tiles_w, c.N, G);
-            const dim3 dgrid(((H + 7) / 8) * ((W + 7) / 8), c.N, G);
+            long ditems = (long)((H + 7) / 8) * ((W + 7) / 8) * c.N * G;
+            const dim3 dgrid((unsigned)(ditems > 4096 ? 4096 : ditems));   // persistent: exits at once unless a tile of the chunk flagged near taps
+            SOMI_REQUIRE(n0 / chunk < 60, SOMI_EINVAL, "dcnv3 backward: more than 60 chunks of images (raise SOMI_DCN_SLAB_MB)");
+            q.near_any = q.overflow + 1 + n0 / chunk;
             long blocks = ((long)c.N * H * W * (a.C / 4) + 255) / 256;
             const dim3 cgrid((unsigned)(blocks > 16384 ? 16384 : blocks));
             // D follows C (it adds to pixels C has just combined); the list-form macro launches B only, C and D come below

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SOMI_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 10         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
+ABI_VERSION = 11         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
 
@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ('B', 'H', 'W', 'Cin', 'x_cs', 'x_coff', 'Ho', 'Wo', 'Cout', 'y_cs', 'y_coff',
                                          'kh', 'kw', 'stride', 'pad', 'dil', 'res_cs', 'res_coff', 'act', 'per_sample_w')] + \
                [('res2_cs', C.c_int32), ('res2_coff', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_uint64),
-                ('residual2', C.c_void_p), ('stat_sum', C.c_void_p), ('stat_sumsq', C.c_void_p), ('stat_pivot', C.c_void_p)]
+                ('residual2', C.c_void_p), ('stat_sum', C.c_void_p), ('stat_sumsq', C.c_void_p), ('stat_pivot', C.c_void_p), ('prec', C.c_int32)]
 
 
 class LossDesc(C.Structure):
@@ -60,6 +60,7 @@ I, F, P, S, Z, U64 = C.c_int, C.c_float, C.c_void_p, c_stream, C.c_size_t, C.c_u
 SIGNATURES = {
     'somi_abi_version': (I, []),
     'somi_last_error': (C.c_char_p, []),
+    'somi_sizeof_desc': (Z, [I]),
     'somi_conv2d_nhwc_f32': (I, [C.POINTER(ConvDesc), S]),
     'somi_conv2d_workspace_bytes': (Z, []),
     'somi_conv2d_stat_rows': (I, [C.POINTER(ConvDesc)]),
@@ -171,6 +172,8 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.somi_abi_version() != ABI_VERSION and not lax:
             raise RuntimeError('libsomi_hip.so ABI version mismatch')
+        if not lax and (L.somi_sizeof_desc(0) != C.sizeof(ConvDesc) or L.somi_sizeof_desc(1) != C.sizeof(LossDesc)):
+            raise RuntimeError('libsomi_hip.so descriptor layout differs from this binding')
         _lib = L
     return _lib
 

@@ -20,6 +20,10 @@ ACT = {'none': 0, None: 0, 'silu': 1, 'gelu': 2, 'relu': 3, 'sigmoid': 4, 'softm
 
 
 _CONV_WS = {}
+# Opt-in reduced precision of the conv family's products (train.py:263 `amp.autocast`): 0 exact fp32 (the default, what every parity
+# claim is made on), 1 bf16 operands, 2 bf16x3 split (somi_conv_desc.prec).  train.TrainStep(amp=...) / bench.py --amp set it.
+CONV_PREC = 0
+PREC = {None: 0, 'f32': 0, 'bf16': 1, 'bf16x3': 2}
 
 
 def _conv_workspace(d, dev):
@@ -67,6 +71,7 @@ def conv2d_nhwc(x, w, bias=None, *, kh, kw, stride=1, pad=0, dil=1, act='none', 
     if out is None:
         out = torch.empty(B, Ho, Wo, cout, device=x.device, dtype=torch.float32)
     d = ConvDesc()
+    d.prec = CONV_PREC
     d.x, d.w, d.bias, d.y = _ptr(_f32c(x, 'input')), _ptr(_f32c(w, 'weight')), _ptr(bias), _ptr(_f32c(out, 'output'))
     d.post_scale, d.post_shift, d.residual = _ptr(post_scale), _ptr(post_shift), _ptr(residual)
     d.a_chan_scale, d.a_pix_scale = _ptr(a_chan_scale), _ptr(a_pix_scale)
@@ -421,6 +426,7 @@ def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cou
     if out is None:
         out = torch.empty(B, H, W, cin, device=dy.device, dtype=torch.float32)
     d = ConvDesc()
+    d.prec = CONV_PREC
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, cin, Ho, Wo, cout
     d.kh, d.kw, d.stride, d.pad, d.dil, d.per_sample_w = kh, kw, stride, pad, 1, int(per_sample_w)
     _conv_workspace(d, dy.device)
@@ -456,6 +462,7 @@ def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cou
     cin = x_cs - x_coff if cin is None else cin
     cout = dy_cs - dy_coff if cout is None else cout
     d = ConvDesc()
+    d.prec = CONV_PREC
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, cin, Ho, Wo, cout
     d.kh, d.kw, d.stride, d.pad, d.dil, d.per_sample_w = kh, kw, stride, pad, 1, int(per_sample_w)
     shape = ((B,) if per_sample_w else ()) + (cout, kh * kw * cin)

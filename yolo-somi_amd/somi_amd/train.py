@@ -47,11 +47,15 @@ def scheduler_step(optimizer, epoch, lf):
 
 
 class TrainStep:
-    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True, sync_bn=False):
+    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True, sync_bn=False, amp=None):
         """accumulate: optimizer step every `accumulate` batches (train.py:121,252,272: max(round(nbs / total_batch), 1) in the
         reference loop; gradients simply keep accumulating in the flat buffers in between).  Default 1: every batch.
         sync_bn: --sync-bn (train.py:165-167, SyncBatchNorm.convert_sync_batchnorm): every BatchNorm layer takes its training
-        statistics - forward mean / variance, backward sums - over the batches of all ranks (ops.SYNC_BN)."""
+        statistics - forward mean / variance, backward sums - over the batches of all ranks (ops.SYNC_BN).
+        amp: None / 'f32' (default: exact fp32 products, the path every parity claim is made on), 'bf16' or 'bf16x3' - the reference's GPU
+        loop runs forward under amp.autocast (train.py:263): the conv family's products (forward, data and weight gradients) then go
+        through the bf16 matrix instructions with fp32 accumulation (ops.CONV_PREC).  Tensors, BatchNorm statistics, the loss, the
+        optimizer and the EMA stay fp32, so no GradScaler is needed (bf16 has fp32's exponent range)."""
         if not next(model.parameters()).is_cuda:
             raise RuntimeError('TrainStep runs on the MI355X only (no CPU fallback)')
         self.model, self.dist = model, dist
@@ -60,6 +64,10 @@ class TrainStep:
         # a process group of its own for the per-layer statistics all-gathers: on the default group they would queue behind the gradient
         # buckets already in flight (one communicator = one issue order) and stall the backward pass until those finish
         self.sync_bn_group = dist.new_group() if self.sync_bn is not None else None
+        from . import ops as _ops
+        if amp not in _ops.PREC:
+            raise ValueError(f'amp must be one of {sorted(k for k in _ops.PREC if k)} or None, got {amp!r}')
+        self.amp = _ops.PREC[amp]
         model.hyp = hyp
         model.train()
         self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True, adam=adam)
@@ -88,12 +96,14 @@ class TrainStep:
             self.buckets.enabled = stepping                       # local accumulation only on the others (DDP's no_sync)
         from . import ops
         ops.SYNC_BN, ops.SYNC_BN_GROUP = self.sync_bn, self.sync_bn_group
+        ops.CONV_PREC = self.amp
         try:
             pred = self.model(imgs)
             loss, items = self.compute_loss(pred, targets)
             loss.backward()                                       # unscaled: the SUM all-reduce supplies the WORLD_SIZE factor
         finally:
             ops.SYNC_BN = ops.SYNC_BN_GROUP = None
+            ops.CONV_PREC = 0
         if self.buckets and stepping:
             self.buckets.finish()
         self._since_step += 1
