@@ -180,14 +180,24 @@ class AbsTermSums:
     """
 
     def __init__(self, model):
-        self.model, self.sums, self._handles = model, {}, []
+        self.model, self.sums, self.sq, self._handles = model, {}, {}, []
         self._names = {id(p): n for n, p in model.named_parameters()}
 
-    def _add(self, p, s):
+    def _add(self, p, s, q2=None):
+        """s: sum |terms|; q2: sum terms^2 (optional) - both shaped like the parameter (or reshapeable to it)."""
         n = self._names.get(id(p))
         if n is not None:
             s = s.detach().reshape(p.shape)
             self.sums[n] = self.sums[n] + s if n in self.sums else s
+            if q2 is not None:
+                q2 = q2.detach().reshape(p.shape)
+                self.sq[n] = self.sq[n] + q2 if n in self.sq else q2
+
+    @property
+    def rss(self):
+        """{parameter name: sqrt(sum terms^2)} - the scale of what INDEPENDENT relative perturbations of the terms (the fp32 rounding of
+        everything upstream) do to the sum: between |g| (no cancellation) and S (full cancellation, all terms alike)."""
+        return {n: v.clamp_min(0).sqrt() for n, v in self.sq.items()}
 
     def __enter__(self):
         import torch.nn as nn
@@ -203,16 +213,17 @@ class AbsTermSums:
 
         def conv(m, inp, dy):
             x = inp[0]
-            self._add(m.weight, torch.nn.grad.conv2d_weight(x.abs(), m.weight.shape, dy.abs(), m.stride, m.padding, m.dilation, m.groups))
+            self._add(m.weight, torch.nn.grad.conv2d_weight(x.abs(), m.weight.shape, dy.abs(), m.stride, m.padding, m.dilation, m.groups),
+                      torch.nn.grad.conv2d_weight(x * x, m.weight.shape, dy * dy, m.stride, m.padding, m.dilation, m.groups))
             if m.bias is not None:
-                self._add(m.bias, dy.abs().sum((0, 2, 3)))
+                self._add(m.bias, dy.abs().sum((0, 2, 3)), (dy * dy).sum((0, 2, 3)))
 
         def linear(m, inp, dy):
             x = inp[0].reshape(-1, inp[0].shape[-1])
             d = dy.reshape(-1, dy.shape[-1])
-            self._add(m.weight, d.abs().t() @ x.abs())
+            self._add(m.weight, d.abs().t() @ x.abs(), (d * d).t() @ (x * x))
             if m.bias is not None:
-                self._add(m.bias, d.abs().sum(0))
+                self._add(m.bias, d.abs().sum(0), (d * d).sum(0))
 
         def bnorm(m, inp, dy):
             x = inp[0]
@@ -222,8 +233,9 @@ class AbsTermSums:
                 mean, var = m.running_mean, m.running_var
             xh = (x - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + m.eps)
             if m.weight is not None:
-                self._add(m.weight, (dy * xh).abs().sum((0, 2, 3)))
-                self._add(m.bias, dy.abs().sum((0, 2, 3)))
+                t = dy * xh
+                self._add(m.weight, t.abs().sum((0, 2, 3)), (t * t).sum((0, 2, 3)))
+                self._add(m.bias, dy.abs().sum((0, 2, 3)), (dy * dy).sum((0, 2, 3)))
 
         def lnorm(m, inp, dy):
             x = inp[0]
@@ -231,8 +243,9 @@ class AbsTermSums:
             xh = (x - x.mean(dims, keepdim=True)) / torch.sqrt(x.var(dims, unbiased=False, keepdim=True) + m.eps)
             lead = tuple(range(x.dim() - len(m.normalized_shape)))
             if m.weight is not None:
-                self._add(m.weight, (dy * xh).abs().sum(lead))
-                self._add(m.bias, dy.abs().sum(lead))
+                t = dy * xh
+                self._add(m.weight, t.abs().sum(lead), (t * t).sum(lead))
+                self._add(m.bias, dy.abs().sum(lead), (dy * dy).sum(lead))
 
         def odconv(m, inp, dy):
             # dW[k] = sum_b attn[b,k] * dW_b with dW_b the weight gradient of sample b's own convolution (blocks.ODConv2d_3rd.get_weight_bias)
@@ -249,14 +262,17 @@ class AbsTermSums:
                 if a_w is not None:
                     attn = attn * a_w.view(B, -1, 1, 1, 1, 1)
                 per = m.weight.shape[1:]
-                s = torch.zeros_like(m.weight)
+                s, s2 = torch.zeros_like(m.weight), torch.zeros_like(m.weight)
                 for b in range(B):
-                    sb = torch.nn.grad.conv2d_weight(x[b:b + 1].abs(), per, dy[b:b + 1].abs(), m.stride, m.padding, m.dilation, m.groups)
+                    xb, db = x[b:b + 1], dy[b:b + 1]
+                    sb = torch.nn.grad.conv2d_weight(xb.abs(), per, db.abs(), m.stride, m.padding, m.dilation, m.groups)
+                    qb = torch.nn.grad.conv2d_weight(xb * xb, per, db * db, m.stride, m.padding, m.dilation, m.groups)
                     s += attn[b].abs() * sb[None]
-                self._add(m.weight, s)
+                    s2 += attn[b] ** 2 * qb[None]
+                self._add(m.weight, s, s2)
                 if m.bias is not None:
                     w = a_w.abs() if a_w is not None else torch.ones(B, m.K, dtype=dy.dtype)
-                    self._add(m.bias, w.t() @ dy.abs().sum((2, 3)))
+                    self._add(m.bias, w.t() @ dy.abs().sum((2, 3)), (w * w).t() @ (dy * dy).sum((2, 3)))
 
         def bifpn(m, inp, dy):
             xs = inp[0]
@@ -264,7 +280,8 @@ class AbsTermSums:
             wgt = m.weight.detach().clone().requires_grad_(True)
             with torch.enable_grad():
                 jac = torch.autograd.functional.jacobian(lambda v: v / (m.swish(v).sum(dim=0) + m.epsilon), wgt)   # d w_i / d weight_j
-            self._add(m.weight, (jac.abs() * s[:len(xs), None]).sum(0))
+            s2 = torch.stack([((dy * x) ** 2).sum() for x in xs])
+            self._add(m.weight, (jac.abs() * s[:len(xs), None]).sum(0), (jac ** 2 * s2[:len(xs), None]).sum(0))
 
         for mod in self.model.modules():
             if isinstance(mod, ODConv2d_3rd):
@@ -305,4 +322,20 @@ def conditioned_errors(named_grads, named_ref64, sums, eps=2.0 ** -24, rel=1e-3)
         s = s.double().clamp_min(1e-300)
         c_req = ((d - rel * scale).clamp_min(0) / (eps * s)).max().item()
         out.append((n, c_req, d.max().item() / scale, s.max().item() / scale))
+    return out
+
+
+def noise_scaled_errors(named_grads, named_ref64, rss):
+    """Per parameter with a measured root-sum-square Q of its gradient's terms (AbsTermSums.rss): (name, r, rel) with
+        r   = max |g - g64| / max (|g64| + Q)     the error in units of the parameter's own noise scale,
+        rel = max |g - g64| / max |g64|           the plain relative error.
+    Independent relative perturbations of size u of the terms (what the fp32 rounding of every layer upstream amounts to) move the sum by
+    about u * Q; correlated ones by up to u * |g|: r is directly comparable to u across well- and ill-conditioned parameters."""
+    out = []
+    for n, g in named_grads:
+        g64, q = named_ref64.get(n), rss.get(n)
+        if g64 is None or q is None:
+            continue
+        d = (g.detach().cpu().double() - g64.double()).abs().max().item()
+        out.append((n, d / ((g64.double().abs() + q.double()).max().item() + 1e-300), d / (g64.abs().max().item() + 1e-300)))
     return out

@@ -21,6 +21,7 @@ d = torch.device('cuda')
 if os.environ.get('CONV_AB_N'):                                  # first N shapes only (kernel experiments)
     SHAPES = SHAPES[:int(os.environ['CONV_AB_N'])]
 KINDS = os.environ.get('CONV_AB_KINDS', 'fwd,dgrad,wgrad').split(',')
+ops.CONV_PREC = ops.PREC[os.environ.get('CONV_AB_PREC') or None]    # bf16 / bf16x3: the opt-in reduced-precision kernels
 
 
 def t(fn, reps=6):

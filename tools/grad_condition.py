@@ -17,7 +17,8 @@ import torch  # noqa: E402
 
 from oracle.somi_ref import Model as OModel  # noqa: E402
 from oracle.somi_ref.loss import ComputeLoss as OLoss  # noqa: E402
-from oracle.somi_ref.testing import SOMI_ANCHORS, AbsTermSums, conditioned_errors, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE  # noqa: E402
+from oracle.somi_ref.testing import (SOMI_ANCHORS, AbsTermSums, conditioned_errors, fill_state, noise_scaled_errors, somi_cfg,  # noqa: E402
+                                     synthetic_batch, HYP_VISDRONE)
 from somi_amd.loss import ComputeLoss  # noqa: E402
 from somi_amd.model import Model  # noqa: E402
 
@@ -75,3 +76,17 @@ for c0 in (16, 64, 256):
     ratios = sorted(((ch[n][2] / (u90 + c0 * 2.0 ** -24 * ch[n][3]), n) for n in ch), reverse=True)
     rc = sorted(((cc[n][2] / (u90 + c0 * 2.0 ** -24 * cc[n][3]), n) for n in cc), reverse=True)
     print(f'c0 {c0}: worst e / (u90 + c0 eps cond): HIP', [(round(v, 2), n) for v, n in ratios[:5]], '| CPU', [(round(v, 2), n) for v, n in rc[:3]])
+
+# noise-scaled view: r = max|dg| / max(|g| + Q), Q = root-sum-square of the gradient's terms
+rss = cond.rss
+nh = {t[0]: t for t in noise_scaled_errors([(n, p.grad) for n, p in mine.named_parameters() if p.grad is not None], g64, rss)}
+nc = {t[0]: t for t in noise_scaled_errors([(n, p.grad) for n, p in ref.named_parameters() if p.grad is not None], g64, rss)}
+rh, rc = sorted(t[1] for t in nh.values()), sorted(t[1] for t in nc.values())
+q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]  # noqa: E731
+print(f'noise-scaled error r: HIP median {q(rh, .5):.2e} q90 {q(rh, .9):.2e} q99 {q(rh, .99):.2e} max {rh[-1]:.2e} | fp32 CPU median {q(rc, .5):.2e} '
+      f'q90 {q(rc, .9):.2e} q99 {q(rc, .99):.2e} max {rc[-1]:.2e}')
+u = q(rc, .9)
+worst = sorted(((nh[n][1] / u, n, nh[n][1], nc[n][1], nh[n][2]) for n in nh), reverse=True)[:15]
+print('worst r_hip / u90(cpu):')
+for w in worst:
+    print(f'  {w[1]:58s} x{w[0]:6.2f}   r_hip {w[2]:.2e} r_cpu {w[3]:.2e} rel_hip {w[4]:.2e}')
