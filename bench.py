@@ -171,32 +171,35 @@ def pmc_traffic(kernel_name):
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     if not os.path.exists(path):
         return None
-    key = kernel_name.replace(' ', '')
+    key = kernel_name.replace(' ', '').rstrip('>')               # (rocprofv3 prints trailing default template arguments: <...,true,0>)
     for k, v in json.load(open(path)).get('kernels', {}).items():
         if key in k.replace(' ', ''):
             return v['hbm_bytes_per_launch']
     return None
 
 
-# the kernels behind the two DCNv3 operator entries that ops.PROFILE times (forward = one launch; backward = A + B + C of the windowed form)
+# the kernels behind the two DCNv3 operator entries that ops.PROFILE times.  The FIRST pattern of an entry is launched exactly once per
+# operator call (forward = that one launch; backward = A once, then B / C / D once per chunk of images through the staging slab)
 DCN_OP_KERNELS = {'dcnv3_fwd_kernel': (r'dcnv3_win_kernel<\d+,0>|dcnv3_fwd_kernel',),
-                  'dcnv3_bwd_kernel': (r'dcnv3_win_kernel<\d+,1>|dcnv3_bwd_om_kernel', r'dcnv3_bwd_gin_(mfma_)?kernel', r'dcnv3_bwd_combine_kernel')}
+                  'dcnv3_bwd_kernel': (r'dcnv3_win_kernel<\d+,1>|dcnv3_bwd_om_kernel', r'dcnv3_bwd_gin_(mfma_)?kernel', r'dcnv3_bwd_combine_kernel',
+                                       r'dcnv3_bwd_near_kernel')}
 
 
 def pmc_traffic_op(op):
-    """Sum of pmc_traffic over the kernels of one DCNv3 operator call (None when the committed profile lacks one of them)."""
+    """HBM bytes per OPERATOR CALL of one DCNv3 entry from the committed counter passes: the bytes of every launch of the entry's kernels
+    (both DCN sites, every chunk) divided by the number of operator calls - the average over the step's sites, like `avg_launch_MB`, the
+    algorithmic figure it is compared with.  None when the committed profile lacks the entry's first kernel."""
     import re
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     if not os.path.exists(path) or op not in DCN_OP_KERNELS:
         return None
-    kern = {k.replace(' ', ''): v['hbm_bytes_per_launch'] for k, v in json.load(open(path)).get('kernels', {}).items()}
-    total = 0
-    for pat in DCN_OP_KERNELS[op]:
-        hit = [v for k, v in kern.items() if re.search(pat, k)]
-        if not hit:
-            return None
-        total += hit[0]
-    return total
+    kern = {k.replace(' ', ''): v for k, v in json.load(open(path)).get('kernels', {}).items()}
+    pats = DCN_OP_KERNELS[op]
+    calls = sum(v['launches_sampled'] for k, v in kern.items() if re.search(pats[0], k))
+    if not calls:
+        return None
+    total = sum(v['hbm_bytes_per_launch'] * v['launches_sampled'] for k, v in kern.items() if any(re.search(p_, k) for p_ in pats))
+    return round(total / calls)
 
 
 def main():

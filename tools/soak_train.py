@@ -23,7 +23,7 @@ tr = TrainStep(model, hyp, 32)
 lf = one_cycle(1, hyp['lrf'], 300)
 batches = [synthetic_batch(32, 640, seed=50 + i) for i in range(4)]
 batches = [(a.to(dev), b.to(dev)) for a, b in batches]
-log, t0 = [], time.time()
+log, t0, max_far = [], time.time(), 0
 for it in range(steps):
     warmup_lr(tr.optimizer, it, max(steps, 1), 0, lf, hyp, 32)            # the reference's warm-up ramp over the whole soak
     imgs, tg = batches[it % len(batches)]
@@ -32,11 +32,15 @@ for it in range(steps):
         log.append({'step': it, 'loss': round(float(loss), 4), 'items': [round(float(v), 4) for v in items],
                     'mem_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2)})
         assert torch.isfinite(loss).all(), log[-1]
+        if dcn:
+            from somi_amd import ops as _ops
+            max_far = max(max_far, _ops.dcn_overflow_taps() or 0)
 torch.cuda.synchronize()
 finite = all(bool(torch.isfinite(b).all()) for b in tr.optimizer.flat_params)
 out = {'steps': steps, 'seconds': round(time.time() - t0, 1), 'weights_finite': finite, 'log': log}
 if dcn:
     from somi_amd import ops
     out['dcn_graph'] = True
-    out['taps_outside_window_last_backward'] = ops.dcn_overflow_taps()
+    out['far_taps_last_backward'] = ops.dcn_overflow_taps()      # taps that went through fp32 atomics (beyond the window AND the near pass): 0 <=> bit-reproducible
+    out['far_taps_max_over_run'] = max_far
 print(json.dumps(out))

@@ -843,14 +843,17 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_near_kernel(const DcnArgs a, co
     const int dtile = (int)(item % dt_n), n = (int)((item / dt_n) % a.N), g = (int)(item / ((long)dt_n * a.N));
     const int ty = dtile / dt_w, tx = dtile % dt_w;
     const unsigned *masks = q.near + ((long)n * a.G + g) * ntile;
-    // which of the 25 neighbours are flagged for this destination (uniform)
-    unsigned todo = 0;
-    for (int s = 0; s < 25; ++s) {
-        const int th = ty + s / 5 - 2 - cb_h, tw = tx + s % 5 - 2 - cb_w;
-        if ((unsigned)th >= (unsigned)q.tiles_h || (unsigned)tw >= (unsigned)q.tiles_w) continue;
-        const int bit = (ty - (th + cb_h) + 2) * 5 + (tx - (tw + cb_w) + 2);
-        if ((masks[th * q.tiles_w + tw] >> bit) & 1u) todo |= 1u << s;
+    // which of the 25 neighbours are flagged for this destination: lane s of every wave looks at neighbour s (one load latency per item
+    // instead of 25 dependent ones: the idle pass took 0.18 ms at N32 80x80 with the sequential form), the ballot is wave-uniform
+    bool mine = false;
+    if (lane < 25) {
+        const int th = ty + lane / 5 - 2 - cb_h, tw = tx + lane % 5 - 2 - cb_w;
+        if ((unsigned)th < (unsigned)q.tiles_h && (unsigned)tw < (unsigned)q.tiles_w) {
+            const int bit = (ty - (th + cb_h) + 2) * 5 + (tx - (tw + cb_w) + 2);
+            mine = (masks[th * q.tiles_w + tw] >> bit) & 1u;
+        }
     }
+    const unsigned todo = (unsigned)__ballot(mine);
     if (!todo) continue;
     __syncthreads();                                                  // the previous item's image has been flushed
     for (int i = tid; i < GIN_TP * GC; i += 256) accL[i] = 0.f;

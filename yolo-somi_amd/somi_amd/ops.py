@@ -347,6 +347,14 @@ def tta_resample(x4, ratio, gs, flip_lr, channels=3, pad=0.447):
     return y
 
 
+def resize_bilinear_nhwc4(x4, Hn, Wn, channels=3):
+    """F.interpolate(x, size=(Hn, Wn), mode='bilinear', align_corners=False) on an ingested (B,H,W,4) image (`--multi-scale`, train.py:257-262)."""
+    B, H, W, _ = x4.shape
+    y = torch.empty(B, Hn, Wn, 4, device=x4.device, dtype=torch.float32)
+    check(_lib.lib().somi_tta_resample_nhwc4_f32(_ptr(_f32c(x4)), _ptr(y), B, H, W, Hn, Wn, Hn, Wn, 0, 0.0, channels, _stream()), 'resize_bilinear')
+    return y
+
+
 def tta_descale_(z, scale, flip_lr, img_w):
     """_descale_pred (models/yolo.py:1292-1308) in place on z (B, n, no)."""
     check(_lib.lib().somi_tta_descale_f32(_ptr(_f32c(z)), z.shape[0] * z.shape[1], z.shape[2], float(scale), int(bool(flip_lr)), float(img_w),

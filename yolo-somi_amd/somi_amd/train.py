@@ -15,6 +15,8 @@ still running (ddp.GradBuckets) - DDP's semantics without the wrapper.  With gra
 the micro-batch that steps the optimizer (the sum is linear, so this equals DDP re-averaging its already-averaged buffers on every
 micro-batch, and moves 1/accumulate of the bytes).  fp32 throughout (no GradScaler: nothing to scale).
 """
+import torch
+
 from .ddp import GradBuckets, SINGLE_RANK_REHEARSAL, layer_offsets
 from .loss import ComputeLoss
 from .optim import build_optimizer
@@ -40,6 +42,19 @@ def warmup_lr(optimizer, ni, nw, epoch, lf, hyp, batch_size, nbs=64):
     return int(accumulate)
 
 
+def multi_scale_size(shape_hw, imgsz, gs, rng=None):
+    """The batch size `--multi-scale` draws (train.py:257-261): sz uniform in [0.5, 1.5] imgsz on the stride grid, the batch resized so that its
+    long side is sz, both sides rounded up to stride multiples.  -> (H, W) or None when the scale factor is 1.  rng: a random.Random."""
+    import math
+    import random
+    rng = rng or random
+    sz = rng.randrange(int(imgsz * 0.5), int(imgsz * 1.5 + gs)) // gs * gs
+    sf = sz / max(shape_hw)
+    if sf == 1:
+        return None
+    return tuple(math.ceil(x * sf / gs) * gs for x in shape_hw)
+
+
 def scheduler_step(optimizer, epoch, lf):
     """lr_scheduler.LambdaLR(optimizer, lr_lambda=lf).step() (train.py:148,284-285): lr = initial_lr * lf(epoch) for every group."""
     for x in optimizer.param_groups:
@@ -47,7 +62,7 @@ def scheduler_step(optimizer, epoch, lf):
 
 
 class TrainStep:
-    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True, sync_bn=False, amp=None):
+    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True, sync_bn=False, amp=None, multi_scale=False, imgsz=640):
         """accumulate: optimizer step every `accumulate` batches (train.py:121,252,272: max(round(nbs / total_batch), 1) in the
         reference loop; gradients simply keep accumulating in the flat buffers in between).  Default 1: every batch.
         sync_bn: --sync-bn (train.py:165-167, SyncBatchNorm.convert_sync_batchnorm): every BatchNorm layer takes its training
@@ -55,7 +70,9 @@ class TrainStep:
         amp: None / 'f32' (default: exact fp32 products, the path every parity claim is made on), 'bf16' or 'bf16x3' - the reference's GPU
         loop runs forward under amp.autocast (train.py:263): the conv family's products (forward, data and weight gradients) then go
         through the bf16 matrix instructions with fp32 accumulation (ops.CONV_PREC).  Tensors, BatchNorm statistics, the loss, the
-        optimizer and the EMA stay fp32, so no GradScaler is needed (bf16 has fp32's exponent range)."""
+        optimizer and the EMA stay fp32, so no GradScaler is needed (bf16 has fp32's exponent range).
+        multi_scale: `--multi-scale` (train.py:257-262): every batch is resized (bilinear, align_corners=False) to a random size in
+        [0.5, 1.5] imgsz on the stride grid before the forward pass (Python's `random`, as the reference draws it)."""
         if not next(model.parameters()).is_cuda:
             raise RuntimeError('TrainStep runs on the MI355X only (no CPU fallback)')
         self.model, self.dist = model, dist
@@ -68,6 +85,7 @@ class TrainStep:
         if amp not in _ops.PREC:
             raise ValueError(f'amp must be one of {sorted(k for k in _ops.PREC if k)} or None, got {amp!r}')
         self.amp = _ops.PREC[amp]
+        self.multi_scale, self.imgsz = bool(multi_scale), int(imgsz)
         model.hyp = hyp
         model.train()
         self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True, adam=adam)
@@ -88,8 +106,9 @@ class TrainStep:
             self.optimizer.reset_ema()
             model.invalidate()
 
-    def step(self, imgs, targets):
-        """imgs: (B,3,H,W) uint8 on the GPU; targets (nt,6).  Returns (loss, loss_items) like train.py:265."""
+    def step(self, imgs, targets, size=None):
+        """imgs: (B,3,H,W) uint8 on the GPU; targets (nt,6).  Returns (loss, loss_items) like train.py:265.
+        size: (H, W) to resize this batch to (what multi_scale draws by itself; tests pass it explicitly)."""
         stepping = self._since_step + 1 >= self.accumulate        # this micro-batch ends with optimizer.step()
         if self.buckets:
             self.buckets.reset()
@@ -98,7 +117,13 @@ class TrainStep:
         ops.SYNC_BN, ops.SYNC_BN_GROUP = self.sync_bn, self.sync_bn_group
         ops.CONV_PREC = self.amp
         try:
-            pred = self.model(imgs)
+            if size is None and self.multi_scale:
+                size = multi_scale_size(imgs.shape[2:], self.imgsz, int(self.model.stride.max()))
+            if size is not None and tuple(size) != tuple(imgs.shape[2:]):
+                x4 = ops.image_to_nhwc4(imgs.contiguous(), scale=1.0 / 255.0 if imgs.dtype == torch.uint8 else 1.0)
+                pred = self.model._forward_once(None, ingested=ops.resize_bilinear_nhwc4(x4, int(size[0]), int(size[1])))
+            else:
+                pred = self.model(imgs)
             loss, items = self.compute_loss(pred, targets)
             loss.backward()                                       # unscaled: the SUM all-reduce supplies the WORLD_SIZE factor
         finally:
