@@ -15,7 +15,7 @@ from somi_amd.train import TrainStep  # noqa: E402
 
 B = 32
 m = fill_state(Model(somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS)), 1).cuda()
-tr = TrainStep(m, dict(HYP_VISDRONE), B)
+tr = TrainStep(m, dict(HYP_VISDRONE), B, amp=os.environ.get('SOMI_AMP') or None)    # SOMI_AMP=bf16 / bf16x3: the opt-in reduced-precision step
 imgs, tg = synthetic_batch(B, 640, seed=0)
 imgs, tg = imgs.cuda(), tg.cuda()
 tr.step(imgs, tg)
