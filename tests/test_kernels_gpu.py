@@ -502,3 +502,18 @@ def test_conv_reduced_precision_forms(prec, rel, B, H, Cin, Cout, k, s):
         rel_close(a_, b_, rel=rel, what=f'{prec} {what}')
         if what == 'forward':             # (small data-gradient / weight-gradient launches may plan a tile the bf16 forms do not cover)
             assert not torch.equal(a_, b_), f'{prec} {what}: bit-identical to fp32 - the reduced-precision kernel did not run'
+    if k == 3 and s == 2:                 # ODConv's shape: per-sample weight sets (forward and data gradient; its weight gradient stays fp32)
+        wps = (torch.randn(B, Cout, k * k * Cin, generator=g) / math.sqrt(k * k * Cin)).to(d)
+        wtps = (torch.randn(B, Cin, k * k * Cout, generator=g) / math.sqrt(k * k * Cout)).to(d)
+
+        def run_ps():
+            y = ops.conv2d_nhwc(x, wps, None, kh=k, kw=k, stride=s, pad=p, per_sample_w=True)
+            return y, ops.conv2d_dgrad_nhwc(torch.cos(y * 3.0), wtps, B=B, H=H, W=H, cin=Cin, kh=k, kw=k, stride=s, pad=p, per_sample_w=True)
+        want_ps = run_ps()
+        ops.CONV_PREC = ops.PREC[prec]
+        try:
+            got_ps = run_ps()
+        finally:
+            ops.CONV_PREC = 0
+        rel_close(got_ps[0], want_ps[0], rel=rel, what=f'{prec} per-sample forward')
+        rel_close(got_ps[1], want_ps[1], rel=10 * rel, what=f'{prec} per-sample dgrad (of the perturbed forward)')

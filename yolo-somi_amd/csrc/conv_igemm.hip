@@ -819,7 +819,7 @@ static int conv_launch(const somi_conv_desc *dp, somi_stream_t stream, int dgrad
                                  (!d.stat_pivot || aligned16(d.stat_pivot))),
                  SOMI_EINVAL, "conv: statistics need Cout %% 4 == 0, shared weights, 16 B aligned buffers");
     a.dgrad = dgrad;
-    a.ns = (d.prec == 1 || d.prec == 2) && !d.per_sample_w ? d.prec : 0;
+    a.ns = (d.prec == 1 || d.prec == 2) ? d.prec : 0;
     a.cls = 0;
     a.sk = 0;
     a.ws = nullptr;

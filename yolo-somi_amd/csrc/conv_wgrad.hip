@@ -73,13 +73,15 @@ __device__ __forceinline__ i16x4 lds_read_tr16(const char *p) {
 template <int BM, int BN, int NW = 4, int NS = 0>   // co rows x k columns per tile: 128 x {128,64,32} or 64 x {128,64}; NW waves (8: 128 x 128 only)
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const WgradArgs a) {
     constexpr int NT = NW * 64;
-    static_assert(NS == 0 || (BM == 128 && BN == 128 && NW == 8), "the bf16 forms exist for the 128 x 128 tile with 8 waves");
+    static_assert(NS == 0 || ((BM == 128 || BM == 64) && BN == 128 && NW == 8), "the bf16 forms exist for the 128 / 64 x 128 tiles with 8 waves");
     constexpr int WAVES_N = NW == 8 ? 4 : (BM == 64 ? 2 : (BN == 128 ? 2 : 1)), WAVES_M = NW / WAVES_N;
     static_assert(BM / WAVES_M >= 32 && BN / WAVES_N >= 32, "bad wgrad tiling");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_LD = BM, B_LD = BN;
     constexpr int TILE = WG_PIX * (A_LD + B_LD);
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    // (the bf16 image always has 256-byte rows - a 64-channel dy tile leaves the upper half of its rows to the swizzle - and four 8 KB planes)
+    constexpr int BUF = NS ? 8192 : TILE;                                // floats per buffer
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
         }
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
-            const char *cur = reinterpret_cast<const char *>(lds + (kt & 1) * TILE);
-            float *nxt = lds + ((kt + 1) & 1) * TILE;
+            const char *cur = reinterpret_cast<const char *>(lds + (kt & 1) * BUF);
+            float *nxt = lds + ((kt + 1) & 1) * BUF;
             const bool more = kt + 1 < nkt;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -422,9 +424,11 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid(a.tiles_co * a.tiles_k * a.splits, 1, sets);
     static const int eight = getenv("SOMI_WGRAD_8WAVE") ? atoi(getenv("SOMI_WGRAD_8WAVE")) : 2;
-    a.ns = (fwd->prec == 1 || fwd->prec == 2) && !a.per_sample && a.bm == 128 && a.bn == 128 ? fwd->prec : 0;
-    if (a.ns == 1) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8, 1>), grid, dim3(512), 0, s, a);
-    else if (a.ns == 2) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8, 2>), grid, dim3(512), 0, s, a);
+    a.ns = (fwd->prec == 1 || fwd->prec == 2) && !a.per_sample && a.bn == 128 ? fwd->prec : 0;
+    if (a.ns == 1 && a.bm == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8, 1>), grid, dim3(512), 0, s, a);
+    else if (a.ns == 2 && a.bm == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8, 2>), grid, dim3(512), 0, s, a);
+    else if (a.ns == 1) hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 128, 8, 1>), grid, dim3(512), 0, s, a);
+    else if (a.ns == 2) hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 128, 8, 2>), grid, dim3(512), 0, s, a);
     else if (a.bm == 128 && a.bn == 128 && eight) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128, 8>), grid, dim3(512), 0, s, a);
     else if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, s, a);
     else if (a.bm == 128 && a.bn == 64) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, s, a);

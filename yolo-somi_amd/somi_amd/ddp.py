@@ -63,8 +63,12 @@ class GradBuckets:
                 if self.timing:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
+                h = self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True)
+                self.handles.append(h)
                 if self.timing:
+                    # the collective runs on the backend's own stream: make the SIDE stream wait for its end before the closing event
+                    # (stream-side wait, the host does not block), otherwise e1 would mark the enqueue, not the end of the exchange
+                    h.wait()
                     e1.record()
                     self._spans.append((e0, e1))
         else:
