@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 11
+#define SOMI_ABI_VERSION 12
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -159,6 +159,21 @@ int somi_dcnv3_backward_f32(const float *input, const float *offset, const float
 size_t somi_dcnv3_backward_workspace_bytes(int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w,
                                            int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale);
 
+/* The same operator over offset / mask tensors that are column ranges of wider rows: the module (modules/dcnv3.py:330-334) computes both from
+ * the same activations, so ONE 1x1 GEMM with the two Linear weights stacked produces [pixel][2*G*K offsets | G*K mask logits] and the operator
+ * reads (and, backward, writes grad_offset / grad_mask) in place there.  offset_stride / mask_stride = floats between consecutive pixels
+ * (0 = packed, i.e. the entries above); offset_stride must be even and offset 8-byte aligned.  grad_offset / grad_mask use the same
+ * strides.  Arithmetic identical to the packed entries. */
+int somi_dcnv3_forward_strided_f32(const float *input, const float *offset, const float *mask, long offset_stride, long mask_stride,
+                                   float *output, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h,
+                                   int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
+                                   int im2col_step, somi_stream_t stream);
+int somi_dcnv3_backward_strided_f32(const float *input, const float *offset, const float *mask, long offset_stride, long mask_stride,
+                                    const float *grad_output, float *grad_input, float *grad_offset, float *grad_mask, int N, int H,
+                                    int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,
+                                    int pad_w, int dilation_h, int dilation_w, float offset_scale, int im2col_step,
+                                    void *workspace, size_t workspace_bytes, somi_stream_t stream);
+
 /* The other two dtypes the reference extension dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF, dcnv3_cuda.cu:69,136), same argument
  * meaning as the _f32 pair.  _f16: tensors are IEEE half (the AMP path of train.py:263), arithmetic fp32 (the reference's opmath_t),
  * and the three gradient outputs are FP32 buffers exactly like the reference's (dcnv3_cuda.cu:126-133: the caller casts them back,
@@ -186,6 +201,8 @@ int somi_dcnv3_backward_f64(const double *input, const double *offset, const dou
 int somi_layernorm_act_nhwc_f32(const float *x, const float *gamma, const float *beta, float eps, int act, float *y,
                                 long npix, int C, somi_stream_t stream);
 int somi_group_softmax_f32(const float *x, float *y, long n_groups, int K, somi_stream_t stream);
+/* group g of pixel p at x + p*x_stride + g*K (y likewise); x == y allowed */
+int somi_group_softmax_strided_f32(const float *x, long x_stride, float *y, long y_stride, long npix, int G, int K, somi_stream_t stream);
 int somi_dcnv3_cfs_blend_f32(const float *x, const float *xproj, const float *logit, int logit_cs, float *y, long npix,
                              int G, int Gc, somi_stream_t stream);
 
@@ -197,6 +214,9 @@ int somi_layernorm_gelu_bwd_nhwc_f32(const float *u, const float *gamma, const f
                                      float *dgamma_accumulate, float *dbeta_accumulate, float *workspace, long npix, int C,
                                      somi_stream_t stream);
 int somi_group_softmax_bwd_f32(const float *y, const float *dy, float *dx, long n_groups, int K, somi_stream_t stream);
+/* y rows of y_stride floats, dy / dx rows of d_stride floats; dx == dy allowed */
+int somi_group_softmax_bwd_strided_f32(const float *y, long y_stride, const float *dy, float *dx, long d_stride, long npix, int G, int K,
+                                       somi_stream_t stream);
 int somi_dcnv3_cfs_blend_bwd_f32(const float *x, const float *xproj, const float *logit, int logit_cs, const float *dout, float *dx,
                                  float *dxproj, float *dlogit, int dlogit_cs, long npix, int G, int Gc, somi_stream_t stream);
 

@@ -449,6 +449,59 @@ def test_dcnv3_backward_windowed_form(N, H, W, G, Gc, k, s, p, d, osc, spread):
         rel_close(got, ref, rel=1e-4, what=f'direct {what}')
 
 
+@pytest.mark.parametrize('N,H,W,G,Gc,k,s,p,d,pad,direct', [(2, 40, 40, 8, 32, 3, 1, 1, 1, 0, False),     # the bench graph's site shape: 216-float rows
+                                                           (2, 37, 29, 4, 16, 3, 1, 1, 1, 4, False),     # ragged tiles, padded rows
+                                                           (3, 21, 17, 4, 8, 3, 2, 1, 1, 0, False),      # stride 2
+                                                           (2, 19, 23, 2, 16, 5, 1, 2, 1, 2, True),      # 5x5 -> the tiled (non-windowed) kernels
+                                                           (1, 9, 11, 4, 6, 3, 1, 1, 1, 0, True)])       # group width 6: scalar kernels
+def test_dcnv3_merged_offset_mask_rows(N, H, W, G, Gc, k, s, p, d, pad, direct):
+    """The operator over ONE [pixel][2GK offsets | GK masks | pad] tensor (what a single 1x1 GEMM over the module's stacked offset / mask
+    weights produces) is bit-identical to the packed entry points, forward and backward, in every kernel form; the in-place strided group
+    softmax and its backward equal the packed ones."""
+    from oracle.somi_ref import dcnv3 as O
+    from somi_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + H)
+    dev = torch.device('cuda:0')
+    Ho, Wo = O.dcnv3_out_size(H, k, s, p, d), O.dcnv3_out_size(W, k, s, p, d)
+    K, GK = k * k, G * k * k
+    x = torch.randn(N, H, W, G * Gc, generator=g).to(dev)
+    off = (torch.randn(N, Ho, Wo, 2 * GK, generator=g) * 0.7).to(dev)
+    mlog = torch.randn(N, Ho, Wo, GK, generator=g).to(dev)
+    go = torch.randn(N, Ho, Wo, G * Gc, generator=g).to(dev)
+    R = 3 * GK + pad
+    om = torch.full((N, Ho, Wo, R), 7.0, device=dev)
+    om[..., :2 * GK] = off
+    om[..., 2 * GK:3 * GK] = mlog
+    mask = ops.group_softmax(mlog, K)
+    ops.group_softmax_cols_(om, G, K, 2 * GK)
+    assert torch.equal(om[..., 2 * GK:3 * GK], mask) and torch.equal(om[..., :2 * GK], off)
+    assert pad == 0 or bool((om[..., 3 * GK:] == 7.0).all()), 'the strided softmax wrote outside its columns'
+    cfg = (k, k, s, s, p, p, d, d, G, Gc, 1.0, 256)
+    ops.DCN_DIRECT = direct
+    try:
+        y0 = ops.dcnv3_forward_raw(x, off, mask, *cfg)
+        y1 = ops.dcnv3_forward_merged(x, om, *cfg)
+        assert torch.equal(y0, y1)
+        gi0, goff0, gm0 = ops.dcnv3_backward_raw(x, off, mask, go, *cfg)
+        gi1, d_om = ops.dcnv3_backward_merged(x, om, go, *cfg)
+        far = ops.dcn_overflow_taps()
+    finally:
+        ops.DCN_DIRECT = False
+    if Gc % 4:                                                   # the scalar kernel sums a pixel's channels with LDS atomics: order-dependent
+        rel_close(d_om[..., :2 * GK], goff0, rel=1e-5, what='grad_offset')
+        rel_close(d_om[..., 2 * GK:3 * GK], gm0, rel=1e-5, what='grad_mask')
+        goff0, gm0 = d_om[..., :2 * GK].clone(), d_om[..., 2 * GK:3 * GK].contiguous()
+    assert torch.equal(goff0, d_om[..., :2 * GK]) and torch.equal(gm0, d_om[..., 2 * GK:3 * GK])
+    assert pad == 0 or bool((d_om[..., 3 * GK:] == 0).all())
+    if direct or far:                                            # fp32 atomics into grad_input: order-dependent rounding
+        rel_close(gi1, gi0.cpu(), rel=1e-4, what='grad_input')
+    else:
+        assert torch.equal(gi0, gi1)
+    dlog = ops.group_softmax_backward(mask, gm0, K)
+    ops.group_softmax_backward_cols_(om, d_om, G, K, 2 * GK)
+    assert torch.equal(d_om[..., 2 * GK:3 * GK], dlog) and torch.equal(d_om[..., :2 * GK], goff0)
+
+
 def test_dcnv3_full_size_properties():
     """The operator at the bench graph's full site shape (N32, 80x80, C256, G8, K9 - too large for the CPU oracle in a test) through
     properties that do not depend on the size: the forward is LINEAR in its input, the LDS-window form equals the tiled form and the

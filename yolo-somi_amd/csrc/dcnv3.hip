@@ -60,6 +60,11 @@ struct DcnArgs {
     int TP;          // pixels per tile
     long npix;       // N*Ho*Wo
     int ntile;
+    // floats between consecutive pixels of offset / grad_offset (2*G*K when packed) and of mask / grad_mask (G*K when packed): a caller
+    // that computes offset and mask logits with ONE 1x1 GEMM hands both as column ranges of the same [pixel][3*G*K] rows
+    long off_ps, msk_ps;
+    __device__ __forceinline__ long off_at(long pix, int gk) const { return pix * off_ps + gk * 2; }
+    __device__ __forceinline__ long msk_at(long pix, int gk) const { return pix * msk_ps + gk; }
 };
 
 struct Rec {         // 32 B, one per (pixel, group, point)
@@ -72,9 +77,8 @@ struct Rec {         // 32 B, one per (pixel, group, point)
 template <bool BWD>
 __device__ __forceinline__ Rec make_record(const DcnArgs &a, long pix, int g, int k) {
     const int wo = (int)(pix % a.Wo), ho = (int)((pix / a.Wo) % a.Ho);
-    const long s = (pix * a.G + g) * a.K + k;
-    const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + s * 2);
-    const float m = a.mask[s];
+    const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + a.off_at(pix, g * a.K + k));
+    const float m = a.mask[a.msk_at(pix, g * a.K + k)];
     const int i = k / a.kh, j = k % a.kh;
     const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
     const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
@@ -275,9 +279,10 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const DcnArgs a) {
     }
     __syncthreads();
     for (int i = threadIdx.x; i < np * GK; i += 256) {
-        const long s = (pix0 * GK) + i;
-        a.grad_mask[s] = accs[i * 3];
-        *reinterpret_cast<float2 *>(a.grad_offset + s * 2) =
+        const long pix = pix0 + i / GK;
+        const int gk = i % GK;
+        a.grad_mask[a.msk_at(pix, gk)] = accs[i * 3];
+        *reinterpret_cast<float2 *>(a.grad_offset + a.off_at(pix, gk)) =
             make_float2(a.offset_scale * accs[i * 3 + 1], a.offset_scale * accs[i * 3 + 2]);
     }
 }
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const DcnArgs a) {
         const float *src = a.input + n * img + c;
         const Rec *rr = recs + (pl * a.G + g) * a.K;
         const f32x4 tg = live ? *reinterpret_cast<const f32x4 *>(a.grad_output + pix * a.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const long sbase = (pix * a.G + g) * a.K;
+        const int gk0 = g * a.K;
         for (int k0 = 0; k0 < a.K; k0 += 3) {
             const int nk = min(3, a.K - k0);
             f32x4 u[12];
@@ -342,9 +347,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const DcnArgs a) {
                     gh += __shfl_xor(gh, o);
                 }
                 if (live && (lane & (LG - 1)) == 0) {                // one lane per group owns the point: plain stores
-                    const long sp = sbase + k0 + j;
-                    a.grad_mask[sp] = gm;
-                    *reinterpret_cast<float2 *>(a.grad_offset + sp * 2) = make_float2(a.offset_scale * gw, a.offset_scale * gh);
+                    a.grad_mask[a.msk_at(pix, gk0 + k0 + j)] = gm;
+                    *reinterpret_cast<float2 *>(a.grad_offset + a.off_at(pix, gk0 + k0 + j)) =
+                        make_float2(a.offset_scale * gw, a.offset_scale * gh);
                 }
             }
         }
@@ -429,9 +434,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gin_kernel(const DcnArgs a, con
         r.cf[0] = r.cf[1] = r.cf[2] = r.cf[3] = 0.f;
         if (ho < a.Ho && wo < a.Wo) {
             const long pix = ((long)n * a.Ho + ho) * a.Wo + wo;
-            const long s = (pix * a.G + g) * a.K + k;
-            const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + s * 2);
-            const float m = a.mask[s];
+            const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + a.off_at(pix, g * a.K + k));
+            const float m = a.mask[a.msk_at(pix, g * a.K + k)];
             const int ii = k / a.kh, jj = k % a.kh;
             const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
             const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
@@ -617,9 +621,9 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
             const int pl = i / a.K, k = i % a.K;
             const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
             if (ho < a.Ho && wo < a.Wo) {
-                const long s = ((((long)n * a.Ho + ho) * a.Wo + wo) * a.G + g) * a.K + k;
-                ofs_r[j] = *reinterpret_cast<const float2 *>(a.offset + s * 2);
-                m_r[j] = a.mask[s];
+                const long pix = ((long)n * a.Ho + ho) * a.Wo + wo;
+                ofs_r[j] = *reinterpret_cast<const float2 *>(a.offset + a.off_at(pix, g * a.K + k));
+                m_r[j] = a.mask[a.msk_at(pix, g * a.K + k)];
             }
         }
     }
@@ -639,9 +643,9 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
                 ofs = j == 0 ? ofs_r[0] : ofs_r[1];
                 m = j == 0 ? m_r[0] : m_r[1];
             } else {
-                const long s = ((((long)n * a.Ho + ho) * a.Wo + wo) * a.G + g) * a.K + k;
-                ofs = *reinterpret_cast<const float2 *>(a.offset + s * 2);
-                m = a.mask[s];
+                const long pix = ((long)n * a.Ho + ho) * a.Wo + wo;
+                ofs = *reinterpret_cast<const float2 *>(a.offset + a.off_at(pix, g * a.K + k));
+                m = a.mask[a.msk_at(pix, g * a.K + k)];
             }
             const int ii = k / a.kh, jj = k % a.kh;
             const int half_w = (a.dw * (a.kw - 1)) >> 1, half_h = (a.dh * (a.kh - 1)) >> 1;
@@ -871,9 +875,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_near_kernel(const DcnArgs a, co
                 const int pl = i / a.K, k = i % a.K;
                 const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
                 if (ho < a.Ho && wo < a.Wo) {
-                    const long sidx = ((((long)n * a.Ho + ho) * a.Wo + wo) * a.G + g) * a.K + k;
-                    const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + sidx * 2);
-                    const float m = a.mask[sidx];
+                    const long pix = ((long)n * a.Ho + ho) * a.Wo + wo;
+                    const float2 ofs = *reinterpret_cast<const float2 *>(a.offset + a.off_at(pix, g * a.K + k));
+                    const float m = a.mask[a.msk_at(pix, g * a.K + k)];
                     const int ii = k / a.kh, jj = k % a.kh;
                     const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
                     const float p0h = (float)(half_h - a.ph + ho * a.sh) - (float)half_h * a.offset_scale;
@@ -978,9 +982,9 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
     // uniform 64-bit bases; everything per lane is 32-bit from here (win_plan checks the extents)
     const float *img = a.input + (long)n * a.H * a.W * a.C + g * GC;
     const long opix0 = (long)n * a.Ho * a.Wo;
-    const float *ofs_b = a.offset + (opix0 * a.G + g) * a.K * 2;
-    const float *msk_b = a.mask + (opix0 * a.G + g) * a.K;
-    const int GK = a.G * a.K;
+    const float *ofs_b = a.offset + opix0 * a.off_ps + g * a.K * 2;
+    const float *msk_b = a.mask + opix0 * a.msk_ps + g * a.K;
+    const int ops = (int)a.off_ps, mps = (int)a.msk_ps;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     // 1. loads first, all in flight together.  A thread builds the records of one (pixel, kernel column): kernel_h consecutive points
     //    (offsets and masks contiguous), the pixel decode and the base position shared.  Their first WIN_PF loads go out here ...
@@ -992,14 +996,14 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
         const int pl = (int)(((unsigned)t * q.rkw) >> 16), ii = t - pl * a.kw;
         const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
         const bool on = t < ncol && ho < a.Ho && wo < a.Wo;
-        const int s = (ho * a.Wo + wo) * GK + ii * a.kh;
+        const int so = (ho * a.Wo + wo) * ops + ii * a.kh * 2, sm = (ho * a.Wo + wo) * mps + ii * a.kh;
 #pragma unroll
         for (int j = 0; j < WIN_PF; ++j) {
             ofs_r[j] = make_float2(0.f, 0.f);
             m_r[j] = 0.f;
             if (on && j < a.kh) {
-                ofs_r[j] = *reinterpret_cast<const float2 *>(ofs_b + (s + j) * 2);
-                m_r[j] = msk_b[s + j];
+                ofs_r[j] = *reinterpret_cast<const float2 *>(ofs_b + so + j * 2);
+                m_r[j] = msk_b[sm + j];
             }
         }
     }
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
         const int pl = (int)(((unsigned)t * q.rkw) >> 16), ii = t - pl * a.kw;
         const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
         const bool on = ho < a.Ho && wo < a.Wo;
-        const int s = (ho * a.Wo + wo) * GK + ii * a.kh;
+        const int so = (ho * a.Wo + wo) * ops + ii * a.kh * 2, sm = (ho * a.Wo + wo) * mps + ii * a.kh;
         const float p0w = (float)(half_w - a.pw + wo * a.sw) - (float)half_w * a.offset_scale;
         const float p0h = (float)(half_h - a.ph + ho * a.sh) - (float)half_h * a.offset_scale;
         const float iw = (float)(ii * a.dw);
@@ -1048,8 +1052,8 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
                     ofs = jj == 0 ? ofs_r[0] : (jj == 1 ? ofs_r[1] : ofs_r[2]);
                     m = jj == 0 ? m_r[0] : (jj == 1 ? m_r[1] : m_r[2]);
                 } else {
-                    ofs = *reinterpret_cast<const float2 *>(ofs_b + (s + jj) * 2);
-                    m = msk_b[s + jj];
+                    ofs = *reinterpret_cast<const float2 *>(ofs_b + so + jj * 2);
+                    m = msk_b[sm + jj];
                 }
                 const float loc_w = p0w + (iw + ofs.x) * a.offset_scale;
                 const float loc_h = p0h + ((float)(jj * a.dh) + ofs.y) * a.offset_scale;
@@ -1129,8 +1133,8 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
             *reinterpret_cast<f32x4 *>(a.output + opix0 * a.C + g * GC + (lpix * a.C + part * 4)) = acc;
         } else {
             const f32x4 tg = live ? *reinterpret_cast<const f32x4 *>(a.grad_output + opix0 * a.C + g * GC + (lpix * a.C + part * 4)) : zero;
-            float *gm_b = a.grad_mask + (opix0 * a.G + g) * a.K + lpix * GK;
-            float *go_b = a.grad_offset + ((opix0 * a.G + g) * a.K + lpix * GK) * 2;
+            float *gm_b = a.grad_mask + opix0 * a.msk_ps + g * a.K + lpix * mps;
+            float *go_b = a.grad_offset + opix0 * a.off_ps + g * a.K * 2 + lpix * ops;
             for (int k0 = 0; k0 < a.K; k0 += 3) {
                 const int nk = min(3, a.K - k0);
                 int cd[3];
@@ -1216,7 +1220,7 @@ static size_t win_plan(const DcnArgs &a, GinGeo &q) {
     if (e && e[0] == '1') return 0;
     const size_t lds = ((size_t)q.WH * q.WW + q.WW + 2) * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(f32x4) + sizeof(int));
     if (lds > 64 * 1024 || (long)a.N * a.G * q.tiles_h * q.tiles_w >= (1L << 31)) return 0;
-    if ((long)a.Ho * a.Wo * a.G * a.K * 2 >= (1L << 31) || (long)a.Ho * a.Wo * a.C >= (1L << 31)) return 0;      // 32-bit indices inside one image
+    if ((long)a.Ho * a.Wo * a.off_ps >= (1L << 31) || (long)a.Ho * a.Wo * a.msk_ps >= (1L << 31) || (long)a.Ho * a.Wo * a.C >= (1L << 31)) return 0;      // 32-bit indices inside one image
     if (GIN_TP * a.kw + 256 >= 65536 / a.kw || q.WH * q.WW >= 65536 / q.WW) return 0;                             // the reciprocal divisions
     q.rkw = 65536u / a.kw + 1;
     q.rWW = 65536u / q.WW + 1;
@@ -1268,15 +1272,26 @@ static int fill_args(DcnArgs &a, int N, int H, int W, int G, int Gc, int kh, int
 
 using namespace somi;
 
-extern "C" int somi_dcnv3_forward_f32(const float *input, const float *offset, const float *mask, float *output, int N, int H,
-                                      int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,
-                                      int pad_w, int dilation_h, int dilation_w, float offset_scale, int im2col_step,
-                                      somi_stream_t stream) {
+// pixel strides of offset / mask: 0 = packed rows; otherwise both live inside wider rows (one GEMM's [pixel][>= 3*G*K] output)
+static int set_strides(DcnArgs &a, long offset_stride, long mask_stride) {
+    const long gk = (long)a.G * a.K;
+    a.off_ps = offset_stride ? offset_stride : 2 * gk;
+    a.msk_ps = mask_stride ? mask_stride : gk;
+    SOMI_REQUIRE(a.off_ps >= 2 * gk && a.msk_ps >= gk && a.off_ps % 2 == 0, SOMI_EINVAL,
+                 "dcnv3: offset / mask pixel strides (%ld, %ld) below the row lengths (%ld, %ld) or odd", a.off_ps, a.msk_ps, 2 * gk, gk);
+    return 0;
+}
+
+extern "C" int somi_dcnv3_forward_strided_f32(const float *input, const float *offset, const float *mask, long offset_stride, long mask_stride,
+                                              float *output, int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h,
+                                              int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale,
+                                              int im2col_step, somi_stream_t stream) {
     SOMI_REQUIRE(input && offset && mask && output, SOMI_EINVAL, "dcnv3 forward: null tensor");
     DcnArgs a{};
     int rc = fill_args(a, N, H, W, G, Gc, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
                        offset_scale, im2col_step, sizeof(Rec));
     if (rc) return rc;
+    if ((rc = set_strides(a, offset_stride, mask_stride))) return rc;
     a.input = input; a.offset = offset; a.mask = mask; a.output = output;
     SOMI_REQUIRE((reinterpret_cast<uintptr_t>(offset) & 7u) == 0, SOMI_EINVAL, "dcnv3: offset must be 8 B aligned");
     const size_t lds = (size_t)a.TP * G * a.K * sizeof(Rec);
@@ -1292,6 +1307,14 @@ extern "C" int somi_dcnv3_forward_f32(const float *input, const float *offset, c
     return launch_status("somi_dcnv3_forward_f32");
 }
 
+extern "C" int somi_dcnv3_forward_f32(const float *input, const float *offset, const float *mask, float *output, int N, int H,
+                                      int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,
+                                      int pad_w, int dilation_h, int dilation_w, float offset_scale, int im2col_step,
+                                      somi_stream_t stream) {
+    return somi_dcnv3_forward_strided_f32(input, offset, mask, 0, 0, output, N, H, W, G, Gc, kernel_h, kernel_w, stride_h, stride_w, pad_h,
+                                          pad_w, dilation_h, dilation_w, offset_scale, im2col_step, stream);
+}
+
 extern "C" size_t somi_dcnv3_backward_workspace_bytes(int N, int H, int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w,
                                                       int pad_h, int pad_w, int dilation_h, int dilation_w, float offset_scale) {
     DcnArgs a{};
@@ -1304,17 +1327,18 @@ extern "C" size_t somi_dcnv3_backward_workspace_bytes(int N, int H, int W, int G
     return gin_plan(a, q, lds, bytes, chunk, slab) ? bytes : 0;
 }
 
-extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, const float *mask, const float *grad_output,
-                                       float *grad_input, float *grad_offset, float *grad_mask, int N, int H, int W, int G,
-                                       int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
-                                       int dilation_h, int dilation_w, float offset_scale, int im2col_step, void *workspace,
-                                       size_t workspace_bytes, somi_stream_t stream) {
+extern "C" int somi_dcnv3_backward_strided_f32(const float *input, const float *offset, const float *mask, long offset_stride, long mask_stride,
+                                               const float *grad_output, float *grad_input, float *grad_offset, float *grad_mask, int N, int H,
+                                               int W, int G, int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,
+                                               int pad_w, int dilation_h, int dilation_w, float offset_scale, int im2col_step,
+                                               void *workspace, size_t workspace_bytes, somi_stream_t stream) {
     SOMI_REQUIRE(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask, SOMI_EINVAL,
                  "dcnv3 backward: null tensor");
     DcnArgs a{};
     int rc = fill_args(a, N, H, W, G, Gc, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
                        offset_scale, im2col_step, sizeof(Rec) + 3 * sizeof(float));
     if (rc) return rc;
+    if ((rc = set_strides(a, offset_stride, mask_stride))) return rc;      // grad_offset / grad_mask use the same pixel strides
     a.input = input; a.offset = offset; a.mask = mask; a.grad_output = grad_output;
     a.grad_input = grad_input; a.grad_offset = grad_offset; a.grad_mask = grad_mask;
     SOMI_REQUIRE((reinterpret_cast<uintptr_t>(offset) & 7u) == 0 && (reinterpret_cast<uintptr_t>(grad_offset) & 7u) == 0,
@@ -1351,15 +1375,15 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
                                   (int)mlds);                                                                               \
         hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC>), grid, dim3(GMM_NT), mlds, s, c, q);                                    \
     } while (0)
-        const size_t in_img = (size_t)H * W * a.C, out_img = (size_t)a.Ho * a.Wo * a.C, om_img = (size_t)a.Ho * a.Wo * G * a.K;
+        const size_t in_img = (size_t)H * W * a.C, out_img = (size_t)a.Ho * a.Wo * a.C, opix_img = (size_t)a.Ho * a.Wo;
         for (int n0 = 0; n0 < N; n0 += chunk) {
             DcnArgs c = a;                                         // the chunk as a batch of its own
             c.N = N - n0 < chunk ? N - n0 : chunk;
             c.input = a.input + n0 * in_img;
             c.grad_input = a.grad_input + n0 * in_img;
             c.grad_output = a.grad_output + n0 * out_img;
-            c.offset = a.offset + n0 * om_img * 2;
-            c.mask = a.mask + n0 * om_img;
+            c.offset = a.offset + n0 * opix_img * a.off_ps;
+            c.mask = a.mask + n0 * opix_img * a.msk_ps;
             c.npix = (long)c.N * a.Ho * a.Wo;
             const dim3 grid(q.tiles_h * q.tiles_w, c.N, G);
             long ditems = (long)((H + 7) / 8) * ((W + 7) / 8) * c.N * G;
@@ -1401,4 +1425,14 @@ extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, 
     if (vec) hipLaunchKernelGGL((dcnv3_bwd_kernel<4, true>), dim3(a.ntile), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((dcnv3_bwd_kernel<1, true>), dim3(a.ntile), dim3(256), lds, s, a);
     return launch_status("somi_dcnv3_backward_f32");
+}
+
+extern "C" int somi_dcnv3_backward_f32(const float *input, const float *offset, const float *mask, const float *grad_output,
+                                       float *grad_input, float *grad_offset, float *grad_mask, int N, int H, int W, int G,
+                                       int Gc, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                                       int dilation_h, int dilation_w, float offset_scale, int im2col_step, void *workspace,
+                                       size_t workspace_bytes, somi_stream_t stream) {
+    return somi_dcnv3_backward_strided_f32(input, offset, mask, 0, 0, grad_output, grad_input, grad_offset, grad_mask, N, H, W, G, Gc, kernel_h,
+                                           kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, offset_scale, im2col_step,
+                                           workspace, workspace_bytes, stream);
 }

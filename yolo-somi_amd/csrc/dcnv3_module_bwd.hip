@@ -77,13 +77,18 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restr
     if (c < C) dgamma[c] += (float)s; else dbeta[c - C] += (float)s;
 }
 
-// y = softmax(x) over K: dx_k = y_k * (dy_k - sum_j dy_j y_j); one lane per (pixel, group)
-__global__ __launch_bounds__(256) void group_softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
-                                                                long n, int K) {
+// y = softmax(x) over K: dx_k = y_k * (dy_k - sum_j dy_j y_j); one lane per (pixel, group).  Group g of pixel p starts at p*ps + g*K
+// (packed rows or a column range of wider rows); dx == dy (in place) is allowed, hence no __restrict__ on them.
+__global__ __launch_bounds__(256) void group_softmax_bwd_kernel(const float *__restrict__ y, const float *dy, float *dx, long n, int G, int K,
+                                                                long y_ps, long d_ps) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long p = i / G;
+        const int g = (int)(i - p * G);
+        const float *yr = y + p * y_ps + g * K, *dr = dy + p * d_ps + g * K;
+        float *o = dx + p * d_ps + g * K;
         float dot = 0.f;
-        for (int k = 0; k < K; ++k) dot += dy[i * K + k] * y[i * K + k];
-        for (int k = 0; k < K; ++k) dx[i * K + k] = y[i * K + k] * (dy[i * K + k] - dot);
+        for (int k = 0; k < K; ++k) dot += dr[k] * yr[k];
+        for (int k = 0; k < K; ++k) o[k] = yr[k] * (dr[k] - dot);
     }
 }
 
@@ -142,8 +147,18 @@ extern "C" int somi_layernorm_gelu_bwd_nhwc_f32(const float *u, const float *gam
 
 extern "C" int somi_group_softmax_bwd_f32(const float *y, const float *dy, float *dx, long n_groups, int K, somi_stream_t stream) {
     SOMI_REQUIRE(y && dy && dx && n_groups > 0 && K > 0, SOMI_EINVAL, "group softmax backward: bad arguments");
-    hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(n_groups)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n_groups, K);
+    hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(n_groups)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n_groups, 1, K, (long)K,
+                       (long)K);
     return launch_status("somi_group_softmax_bwd_f32");
+}
+
+extern "C" int somi_group_softmax_bwd_strided_f32(const float *y, long y_stride, const float *dy, float *dx, long d_stride, long npix, int G, int K,
+                                                  somi_stream_t stream) {
+    SOMI_REQUIRE(y && dy && dx && npix > 0 && G > 0 && K > 0 && y_stride >= (long)G * K && d_stride >= (long)G * K, SOMI_EINVAL,
+                 "group softmax backward (strided): bad arguments");
+    hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(npix * G)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, npix * G, G, K, y_stride,
+                       d_stride);
+    return launch_status("somi_group_softmax_bwd_strided_f32");
 }
 
 extern "C" int somi_dcnv3_cfs_blend_bwd_f32(const float *x, const float *xproj, const float *logit, int logit_cs, const float *dout, float *dx,

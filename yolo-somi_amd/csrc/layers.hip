@@ -533,16 +533,20 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(const float *__restr
     }
 }
 
-// softmax over the K sampling points of every (pixel, group) (modules/dcnv3.py:334); one lane per (pixel, group)
-__global__ __launch_bounds__(256) void group_softmax_kernel(const float *__restrict__ x, float *__restrict__ y, long n, int K) {
+// softmax over the K sampling points of every (pixel, group) (modules/dcnv3.py:334); one lane per (pixel, group).  Group g of pixel p
+// starts at p*ps + g*K: packed rows (ps = G*K) or a column range of wider rows; x == y (in place) is allowed, hence no __restrict__.
+__global__ __launch_bounds__(256) void group_softmax_kernel(const float *x, float *y, long n, int G, int K, long x_ps, long y_ps) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const float *r = x + i * K;
+        const long p = i / G;
+        const int g = (int)(i - p * G);
+        const float *r = x + p * x_ps + g * K;
+        float *o = y + p * y_ps + g * K;
         float m = r[0];
         for (int k = 1; k < K; ++k) m = fmaxf(m, r[k]);
         float den = 0.f;
         for (int k = 0; k < K; ++k) den += expf(r[k] - m);
         const float inv = 1.f / den;
-        for (int k = 0; k < K; ++k) y[i * K + k] = expf(r[k] - m) * inv;
+        for (int k = 0; k < K; ++k) o[k] = expf(r[k] - m) * inv;
     }
 }
 
@@ -575,8 +579,16 @@ extern "C" int somi_layernorm_act_nhwc_f32(const float *x, const float *gamma, c
 
 extern "C" int somi_group_softmax_f32(const float *x, float *y, long n_groups, int K, somi_stream_t stream) {
     SOMI_REQUIRE(x && y && n_groups > 0 && K > 0, SOMI_EINVAL, "group softmax: bad arguments");
-    hipLaunchKernelGGL(group_softmax_kernel, dim3(ew_grid(n_groups)), dim3(256), 0, (hipStream_t)stream, x, y, n_groups, K);
+    hipLaunchKernelGGL(group_softmax_kernel, dim3(ew_grid(n_groups)), dim3(256), 0, (hipStream_t)stream, x, y, n_groups, 1, K, (long)K, (long)K);
     return launch_status("somi_group_softmax_f32");
+}
+
+extern "C" int somi_group_softmax_strided_f32(const float *x, long x_stride, float *y, long y_stride, long npix, int G, int K,
+                                              somi_stream_t stream) {
+    SOMI_REQUIRE(x && y && npix > 0 && G > 0 && K > 0 && x_stride >= (long)G * K && y_stride >= (long)G * K, SOMI_EINVAL,
+                 "group softmax (strided): bad arguments");
+    hipLaunchKernelGGL(group_softmax_kernel, dim3(ew_grid(npix * G)), dim3(256), 0, (hipStream_t)stream, x, y, npix * G, G, K, x_stride, y_stride);
+    return launch_status("somi_group_softmax_strided_f32");
 }
 
 extern "C" int somi_dcnv3_cfs_blend_f32(const float *x, const float *xproj, const float *logit, int logit_cs, float *y, long npix,

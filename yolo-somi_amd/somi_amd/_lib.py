@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SOMI_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 11         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
+ABI_VERSION = 12         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
 
@@ -71,12 +71,16 @@ SIGNATURES = {
     'somi_dcnv3_forward_f32': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
     'somi_dcnv3_backward_workspace_bytes': (Z, [I] * 13 + [F]),
     'somi_dcnv3_backward_f32': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
+    'somi_dcnv3_forward_strided_f32': (I, [P, P, P, C.c_long, C.c_long, P] + [I] * 13 + [F, I, S]),
+    'somi_dcnv3_backward_strided_f32': (I, [P, P, P, C.c_long, C.c_long, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
     'somi_dcnv3_forward_f16': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
     'somi_dcnv3_backward_f16': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
     'somi_dcnv3_forward_f64': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
     'somi_dcnv3_backward_f64': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
     'somi_layernorm_act_nhwc_f32': (I, [P, P, P, F, I, P, C.c_long, I, S]),
     'somi_group_softmax_f32': (I, [P, P, C.c_long, I, S]),
+    'somi_group_softmax_strided_f32': (I, [P, C.c_long, P, C.c_long, C.c_long, I, I, S]),
+    'somi_group_softmax_bwd_strided_f32': (I, [P, C.c_long, P, P, C.c_long, C.c_long, I, I, S]),
     'somi_layernorm_act_bwd_workspace_floats': (Z, [C.c_long, I]),
     'somi_layernorm_gelu_bwd_nhwc_f32': (I, [P, P, P, F, P, P, P, P, P, C.c_long, I, S]),
     'somi_group_softmax_bwd_f32': (I, [P, P, P, C.c_long, I, S]),

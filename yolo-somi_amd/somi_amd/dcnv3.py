@@ -151,15 +151,28 @@ class DCNv3(nn.Module):
         u = ops.dwconv3x3(input, wdw, dw.bias.detach().float().contiguous())
         x1 = ops.layernorm_act(u, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
         K = self.kernel_size * self.kernel_size
-        offset = self._linear(x1, self.offset.weight, self.offset.bias)
-        mlog = self._linear(x1, self.mask.weight, self.mask.bias)
-        if offset.shape[-1] != self.group * K * 2:
-            offset = offset[..., :self.group * K * 2].contiguous()
-        if mlog.shape[-1] != self.group * K:
-            mlog = mlog[..., :self.group * K].contiguous()
-        mask = ops.group_softmax(mlog, K)
-        y = dcnv3_forward(x_proj, offset, mask, self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad,
-                          self.pad, self.dilation, self.dilation, self.group, self.group_channels, self.offset_scale, 256)
+        GK = self.group * K
+        cfg = (self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad, self.pad, self.dilation, self.dilation, self.group,
+               self.group_channels, self.offset_scale, 256)
+        if GK % 4 == 0:
+            # offset and mask logits share their input: ONE 1x1 GEMM over the stacked weights -> rows [2GK offsets | GK logits]; the softmax
+            # runs in place on the logit columns and the operator reads both column ranges where they lie (modules/dcnv3.py:330-334)
+            w_om = torch.cat([self.offset.weight.detach(), self.mask.weight.detach()]).float().contiguous()
+            b_om = torch.cat([self.offset.bias.detach(), self.mask.bias.detach()]).float().contiguous()
+            om = ops.conv2d_nhwc(x1, w_om, b_om, kh=1, kw=1)
+            ops.group_softmax_cols_(om, self.group, K, 2 * GK)
+            offset = mask = None
+            y = ops.dcnv3_forward_merged(x_proj, om, *cfg)
+        else:
+            om = None
+            offset = self._linear(x1, self.offset.weight, self.offset.bias)
+            mlog = self._linear(x1, self.mask.weight, self.mask.bias)
+            if offset.shape[-1] != GK * 2:
+                offset = offset[..., :GK * 2].contiguous()
+            if mlog.shape[-1] != GK:
+                mlog = mlog[..., :GK].contiguous()
+            mask = ops.group_softmax(mlog, K)
+            y = dcnv3_forward(x_proj, offset, mask, *cfg)
         logit, yb = None, y
         if self.center_feature_scale:
             logit = self._linear(x1, self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias)
@@ -169,7 +182,7 @@ class DCNv3(nn.Module):
         else:
             out = self._linear(yb, self.output_proj.weight, self.output_proj.bias)
         if keep:
-            return out, (input, x_proj, wdw, u, x1, offset, mask, y, logit, yb)
+            return out, (input, x_proj, wdw, u, x1, om, y, logit, yb)
         return out
 
     def forward(self, input):
@@ -180,7 +193,7 @@ class DCNv3(nn.Module):
     # ------------------------------------------------------------------------------------------ backward of the whole module
     def _backward_impl(self, saved, dout):
         """-> (dinput, [parameter gradients in the order of _params()])."""
-        input, x_proj, wdw, u, x1, offset, mask, y, logit, yb = saved
+        input, x_proj, wdw, u, x1, om, y, logit, yb = saved
         N, H, W, C = input.shape
         G, Gc, K = self.group, self.group_channels, self.kernel_size * self.kernel_size
         if (G * K) % 4 or (self.center_feature_scale and G % 4) or (H, W) != tuple(y.shape[1:3]):
@@ -209,14 +222,17 @@ class DCNv3(nn.Module):
             dx1, g_wc, g_bc = lin_bwd(x1, self.center_feature_scale_proj_weight, dlogit)
         else:
             dy, dxp = dyb, None
-        dxp_op, doff, dmask = dcnv3_backward(x_proj, offset, mask, self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad,
-                                             self.pad, self.dilation, self.dilation, G, Gc, self.offset_scale, dy.contiguous(), 256)
+        # the operator writes grad_offset / grad_mask into one tensor laid out like `om`; the softmax backward runs in place on its mask
+        # columns, and ONE weight-gradient / data-gradient pair over the stacked Linear weights finishes both layers
+        dxp_op, d_om = ops.dcnv3_backward_merged(x_proj, om, dy.contiguous(), self.kernel_size, self.kernel_size, self.stride, self.stride,
+                                                 self.pad, self.pad, self.dilation, self.dilation, G, Gc, self.offset_scale, 256)
         dxp = dxp_op if dxp is None else ops.add_(dxp, 0, dxp_op, 0, C)
-        dmlog = ops.group_softmax_backward(mask, dmask, K)
-        d1, g_woff, g_boff = lin_bwd(x1, self.offset.weight, doff)
-        d2, g_wm, g_bm = lin_bwd(x1, self.mask.weight, dmlog)
+        ops.group_softmax_backward_cols_(om, d_om, G, K, 2 * G * K)
+        w_om = torch.cat([self.offset.weight.detach(), self.mask.weight.detach()])
+        d1, g_wom, g_bom = lin_bwd(x1, w_om, d_om)
+        g_woff, g_wm = g_wom[:2 * G * K], g_wom[2 * G * K:]
+        g_boff, g_bm = g_bom[:2 * G * K], g_bom[2 * G * K:]
         dx1 = d1 if dx1 is None else ops.add_(dx1, 0, d1, 0, C)
-        ops.add_(dx1, 0, d2, 0, C)
         ln = self.dw_conv[1][1]
         g_lnw, g_lnb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         du = ops.layernorm_gelu_backward(u, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, dx1,

@@ -185,6 +185,72 @@ def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw,
     return gi, go, gm
 
 
+def dcnv3_forward_merged(input, om, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels, offset_scale, im2col_step):
+    """The fp32 operator over ONE tensor om (N,Ho,Wo,R >= 3*G*K) holding [2*G*K offsets | G*K masks (already soft-maxed) | pad] per pixel -
+    the output of a single 1x1 GEMM with the two Linear weights stacked (modules/dcnv3.py:330-334).  Same arithmetic as dcnv3_forward_raw."""
+    N, H, W, _ = input.shape
+    Ho, Wo = conv_out_size(H, kh, sh, ph, dh), conv_out_size(W, kw, sw, pw, dw)
+    R, GK = om.shape[-1], group * kh * kw
+    if om.shape[:3] != (N, Ho, Wo) or R < 3 * GK or not om.is_contiguous() or om.dtype != torch.float32:
+        raise RuntimeError(f'dcnv3 (merged offset/mask): om must be contiguous float32 ({N},{Ho},{Wo},>={3 * GK}), got {tuple(om.shape)}')
+    out = torch.empty(N, Ho, Wo, group * group_channels, device=input.device, dtype=torch.float32)
+    prof = PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().somi_dcnv3_forward_strided_f32(_ptr(input), om.data_ptr(), om.data_ptr() + 8 * GK, R, R, _ptr(out), N, H, W, group,
+                                                    group_channels, kh, kw, sh, sw, ph, pw, dh, dw, float(offset_scale), int(im2col_step),
+                                                    _stream()), 'dcnv3_forward')
+    if prof:
+        e1.record()
+        C_ = group * group_channels
+        PROFILE.append(('dcnv3_fwd_kernel', 4.0 * N * Ho * Wo * (2 * C_ + 3 * GK), e0, e1, (N, H, W, C_, group, kh, sh, 10)))
+    return out
+
+
+def dcnv3_backward_merged(input, om, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, group, group_channels, offset_scale, im2col_step):
+    """-> (grad_input, d_om): d_om has om's layout - grad_offset in the first 2*G*K columns, grad_mask (w.r.t. the soft-maxed mask) in the
+    next G*K, zeros in the pad."""
+    N, H, W, _ = input.shape
+    R, GK = om.shape[-1], group * kh * kw
+    gi = torch.zeros_like(input)
+    d_om = torch.empty_like(om) if R == 3 * GK else torch.zeros_like(om)
+    prof = PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L = _lib.lib()
+    nbytes = 0 if DCN_DIRECT else L.somi_dcnv3_backward_workspace_bytes(N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw, dh, dw, float(offset_scale))
+    ws = _dcn_workspace(nbytes, input.device) if nbytes else None
+    global DCN_LAST_WORKSPACE
+    DCN_LAST_WORKSPACE = ws
+    check(L.somi_dcnv3_backward_strided_f32(_ptr(input), om.data_ptr(), om.data_ptr() + 8 * GK, R, R, _ptr(grad_output), _ptr(gi),
+                                            d_om.data_ptr(), d_om.data_ptr() + 8 * GK, N, H, W, group, group_channels, kh, kw, sh, sw, ph, pw,
+                                            dh, dw, float(offset_scale), int(im2col_step), _ptr(ws), nbytes, _stream()), 'dcnv3_backward')
+    if prof:
+        e1.record()
+        C_ = group * group_channels
+        Ho, Wo = grad_output.shape[1], grad_output.shape[2]
+        PROFILE.append(('dcnv3_bwd_kernel', 4.0 * N * Ho * Wo * (4 * C_ + 6 * GK), e0, e1, (N, H, W, C_, group, kh, sh, 11)))
+    return gi, d_om
+
+
+def group_softmax_cols_(om, G, K, col):
+    """In place: softmax over each of the G groups of K columns starting at column `col` of every row of om (..., R)."""
+    R = om.shape[-1]
+    p = om.data_ptr() + 4 * col
+    check(_lib.lib().somi_group_softmax_strided_f32(p, R, p, R, om.numel() // R, G, K, _stream()), 'group_softmax')
+    return om
+
+
+def group_softmax_backward_cols_(om, d_om, G, K, col):
+    """In place on d_om's columns [col, col + G*K): dmask -> dlogits, with the soft-maxed masks read from the same columns of om."""
+    R = om.shape[-1]
+    check(_lib.lib().somi_group_softmax_bwd_strided_f32(om.data_ptr() + 4 * col, R, d_om.data_ptr() + 4 * col, d_om.data_ptr() + 4 * col, R,
+                                                        om.numel() // R, G, K, _stream()), 'group_softmax_bwd')
+    return d_om
+
+
 def image_to_nhwc4(img, scale=1.0 / 255.0):
     """(B,C<=4,H,W) uint8 or float32 NCHW -> (B,H,W,4) float32 (train.py:249 `/255`)."""
     B, Cc, H, W = img.shape
