@@ -92,6 +92,38 @@ __global__ __launch_bounds__(256) void group_softmax_bwd_kernel(const float *__r
     }
 }
 
+// The same for 16-byte aligned rows: SMB_P pixels' y and dy rows staged in LDS by coalesced float4 loads, a lane per (pixel, group) there
+// (see group_softmax_tile_kernel in layers.hip), dx back as float4.  Arithmetic identical to the kernel above.
+constexpr int SMB_P = 32;
+__global__ __launch_bounds__(256) void group_softmax_bwd_tile_kernel(const float *__restrict__ y, const float *dy, float *dx, long npix, int G, int K,
+                                                                     long y_ps, long d_ps) {
+    extern __shared__ float smb_rows[];
+    const int GK = G * K, Q = GK >> 2;
+    float *sy = smb_rows, *sd = smb_rows + SMB_P * GK;
+    for (long p0 = (long)blockIdx.x * SMB_P; p0 < npix; p0 += (long)gridDim.x * SMB_P) {
+        const int np = (int)min((long)SMB_P, npix - p0);
+        for (int i = threadIdx.x; i < np * Q; i += 256) {
+            const int pl = i / Q, q = i - pl * Q;
+            reinterpret_cast<f32x4 *>(sy)[i] = *reinterpret_cast<const f32x4 *>(y + (p0 + pl) * y_ps + q * 4);
+            reinterpret_cast<f32x4 *>(sd)[i] = *reinterpret_cast<const f32x4 *>(dy + (p0 + pl) * d_ps + q * 4);
+        }
+        __syncthreads();
+        for (int gi = threadIdx.x; gi < np * G; gi += 256) {
+            const float *yr = sy + gi * K;
+            float *dr = sd + gi * K;
+            float dot = 0.f;
+            for (int k = 0; k < K; ++k) dot += dr[k] * yr[k];
+            for (int k = 0; k < K; ++k) dr[k] = yr[k] * (dr[k] - dot);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * Q; i += 256) {
+            const int pl = i / Q, q = i - pl * Q;
+            *reinterpret_cast<f32x4 *>(dx + (p0 + pl) * d_ps + q * 4) = reinterpret_cast<const f32x4 *>(sd)[i];
+        }
+        __syncthreads();
+    }
+}
+
 // out = x*(1-s) + xproj*s, s = sigmoid(logit[p][g]):  dx = dout*(1-s); dxproj = dout*s; dlogit[p][g] = s(1-s) * sum_c dout*(xproj - x).
 // One wave per pixel, lanes over channels; the sum over a group's channels is an LDS-free segmented reduction per group.
 __global__ __launch_bounds__(256) void cfs_blend_bwd_kernel(const float *__restrict__ x, const float *__restrict__ xproj,
@@ -156,8 +188,15 @@ extern "C" int somi_group_softmax_bwd_strided_f32(const float *y, long y_stride,
                                                   somi_stream_t stream) {
     SOMI_REQUIRE(y && dy && dx && npix > 0 && G > 0 && K > 0 && y_stride >= (long)G * K && d_stride >= (long)G * K, SOMI_EINVAL,
                  "group softmax backward (strided): bad arguments");
-    hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(npix * G)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, npix * G, G, K, y_stride,
-                       d_stride);
+    const size_t lds = 2 * (size_t)SMB_P * G * K * sizeof(float);
+    if ((G * K) % 4 == 0 && y_stride % 4 == 0 && d_stride % 4 == 0 && aligned16(y) && aligned16(dy) && aligned16(dx) && lds <= 48 * 1024) {
+        const long g = (npix + SMB_P - 1) / SMB_P;
+        hipLaunchKernelGGL(group_softmax_bwd_tile_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), lds, (hipStream_t)stream, y, dy, dx, npix, G,
+                           K, y_stride, d_stride);
+    } else {
+        hipLaunchKernelGGL(group_softmax_bwd_kernel, dim3(grid_for(npix * G)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, npix * G, G, K, y_stride,
+                           d_stride);
+    }
     return launch_status("somi_group_softmax_bwd_strided_f32");
 }
 

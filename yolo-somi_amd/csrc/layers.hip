@@ -550,6 +550,48 @@ __global__ __launch_bounds__(256) void group_softmax_kernel(const float *x, floa
     }
 }
 
+// The same softmax for rows whose G*K floats are 16-byte aligned float4 runs: a workgroup stages SM_P pixels' rows in LDS with coalesced
+// 16-byte loads (a lane per group reading K scalars with a K-float stride costs K cache transactions per line), every lane then owns one
+// (pixel, group) in LDS (stride K words: conflict-free for odd K), and the rows go back as float4.  Arithmetic identical to the kernel above.
+constexpr int SM_P = 32;
+__global__ __launch_bounds__(256) void group_softmax_tile_kernel(const float *x, float *y, long npix, int G, int K, long x_ps, long y_ps) {
+    extern __shared__ float sm_rows[];
+    const int GK = G * K, Q = GK >> 2;
+    for (long p0 = (long)blockIdx.x * SM_P; p0 < npix; p0 += (long)gridDim.x * SM_P) {
+        const int np = (int)min((long)SM_P, npix - p0);
+        for (int i = threadIdx.x; i < np * Q; i += 256) {
+            const int pl = i / Q, q = i - pl * Q;
+            reinterpret_cast<f32x4 *>(sm_rows)[i] = *reinterpret_cast<const f32x4 *>(x + (p0 + pl) * x_ps + q * 4);
+        }
+        __syncthreads();
+        for (int gi = threadIdx.x; gi < np * G; gi += 256) {
+            float *r = sm_rows + gi * K;
+            float m = r[0];
+            for (int k = 1; k < K; ++k) m = fmaxf(m, r[k]);
+            float den = 0.f;
+            for (int k = 0; k < K; ++k) den += expf(r[k] - m);
+            const float inv = 1.f / den;
+            for (int k = 0; k < K; ++k) r[k] = expf(r[k] - m) * inv;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * Q; i += 256) {
+            const int pl = i / Q, q = i - pl * Q;
+            *reinterpret_cast<f32x4 *>(y + (p0 + pl) * y_ps + q * 4) = reinterpret_cast<const f32x4 *>(sm_rows)[i];
+        }
+        __syncthreads();
+    }
+}
+
+static void launch_group_softmax(const float *x, float *y, long npix, int G, int K, long x_ps, long y_ps, hipStream_t s) {
+    const size_t lds = (size_t)SM_P * G * K * sizeof(float);
+    if ((G * K) % 4 == 0 && x_ps % 4 == 0 && y_ps % 4 == 0 && aligned16(x) && aligned16(y) && lds <= 48 * 1024) {
+        long g = (npix + SM_P - 1) / SM_P;
+        hipLaunchKernelGGL(group_softmax_tile_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), lds, s, x, y, npix, G, K, x_ps, y_ps);
+    } else {
+        hipLaunchKernelGGL(group_softmax_kernel, dim3(ew_grid(npix * G)), dim3(256), 0, s, x, y, npix * G, G, K, x_ps, y_ps);
+    }
+}
+
 // centre-feature-scale blend (modules/dcnv3.py:370-376): s = sigmoid(logit[p][g]); y = x*(1-s) + xproj*s
 __global__ __launch_bounds__(256) void cfs_blend_kernel(const float *__restrict__ x, const float *__restrict__ xproj,
                                                         const float *__restrict__ logit, int logit_cs, float *__restrict__ y,
@@ -587,7 +629,7 @@ extern "C" int somi_group_softmax_strided_f32(const float *x, long x_stride, flo
                                               somi_stream_t stream) {
     SOMI_REQUIRE(x && y && npix > 0 && G > 0 && K > 0 && x_stride >= (long)G * K && y_stride >= (long)G * K, SOMI_EINVAL,
                  "group softmax (strided): bad arguments");
-    hipLaunchKernelGGL(group_softmax_kernel, dim3(ew_grid(npix * G)), dim3(256), 0, (hipStream_t)stream, x, y, npix * G, G, K, x_stride, y_stride);
+    launch_group_softmax(x, y, npix, G, K, x_stride, y_stride, (hipStream_t)stream);
     return launch_status("somi_group_softmax_strided_f32");
 }
 

@@ -32,6 +32,16 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     }
 }
 
+// ---- element-wise sweeps: a thread keeps ONE channel quad for the whole launch (the host makes the thread count a multiple of C/4), so
+// the per-channel vectors are loaded once and there is no division in the loop; it walks its pixels EW_U at a time with all the loads of a
+// group issued before the first use (~64-128 KiB of HBM reads in flight per CU: what it takes to stream at 5+ TB/s, MI355X guide).
+constexpr int EW_U = 4;
+struct EwMap { int c; long p, pstep; };
+__device__ __forceinline__ EwMap ew_map(int C4) {
+    const unsigned nthreads = gridDim.x * 256u, t = blockIdx.x * 256u + threadIdx.x;
+    return {(int)(t % (unsigned)C4) * 4, (long)(t / (unsigned)C4), (long)(nthreads / (unsigned)C4)};
+}
+
 // ---- generic two-stage per-channel reduction over pixels: each workgroup reduces RED_CHUNK pixels for all channels.
 // F(p, c4) returns up to two float4 terms for pixel p, channel quad c4.
 template <typename F>
@@ -45,8 +55,11 @@ __device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, fl
         const int rows_par = 256 / ncq;
         const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-        if (rr < rows_par)
+        if (rr < rows_par) {
+            // four pixels per trip: the loads of all four go out before the first sum (the order of the sums is unchanged)
+#pragma unroll 4
             for (long p = p0 + rr; p < p1; p += rows_par) f(p, (cq0 + cq) * 4, s1, s2);
+        }
         l1[threadIdx.x] = s1;
         l2[threadIdx.x] = s2;
         __syncthreads();
@@ -61,7 +74,7 @@ __device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, fl
 }
 
 // stage-2 helper: 256 threads = 16 channels x 16 chunk groups (the walk over ~1024 chunk partials is latency bound: short
-// per-thread chains, 4 loads in flight); returns (for group 0 lanes) the sums over all chunks of p1 / p2, combined in a fixed order
+// per-thread chains, 16 loads in flight); returns (for group 0 lanes) the sums over all chunks of p1 / p2, combined in a fixed order
 constexpr int S2_CH = 16, S2_GRP = 256 / S2_CH;
 __device__ __forceinline__ bool stage2_sums(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C, int &c, double &s1, double &s2) {
     __shared__ double l1[256], l2[256];
@@ -69,7 +82,19 @@ __device__ __forceinline__ bool stage2_sums(const float *__restrict__ p1, const 
     c = blockIdx.x * S2_CH + cl;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     if (c < C) {
+        // S2_DEEP rows of both partial arrays requested before the first sum: the walk is a chain of memory latencies otherwise (one per trip)
+        constexpr int S2_DEEP = 8;
         int k = grp;
+        for (; k + (S2_DEEP - 1) * S2_GRP < nchunk; k += S2_DEEP * S2_GRP) {
+            float v[S2_DEEP], w[S2_DEEP];
+#pragma unroll
+            for (int j = 0; j < S2_DEEP; ++j) {
+                v[j] = p1[(long)(k + j * S2_GRP) * C + c];
+                w[j] = p2 ? p2[(long)(k + j * S2_GRP) * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < S2_DEEP; j += 2) { a0 += v[j]; a1 += v[j + 1]; b0 += w[j]; b1 += w[j + 1]; }
+        }
         for (; k + S2_GRP < nchunk; k += 2 * S2_GRP) {
             const float v0 = p1[(long)k * C + c], v1 = p1[(long)(k + S2_GRP) * C + c];
             const float w0 = p2 ? p2[(long)k * C + c] : 0.f, w1 = p2 ? p2[(long)(k + S2_GRP) * C + c] : 0.f;
@@ -214,17 +239,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_sync_stage2(const double *__re
 
 // ------------------------------------------------------------------------------------------------ affine + activation
 // order 0: z = act(x*scale + shift) ; order 1: z = act(x)*scale + shift        (x, z: channel slices; in place allowed)
-__global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__restrict__ x, int x_cs, int x_coff,
-                                                              const float *__restrict__ scale, const float *__restrict__ shift, int act,
-                                                              int order, float *__restrict__ z, int z_cs, int z_coff, long npix, int C,
-                                                              const float *__restrict__ res, int res_cs, int res_coff) {
-    const int C4 = C >> 2;
-    const long items = npix * C4;
-    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C4) * 4;
-        const long p = it / C4;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+// SILU0: the conv block's case (SiLU after the norm) compiled on its own - the run-time activation switch costs registers (occupancy)
+template <bool SILU0>
+__global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *x, int x_cs, int x_coff, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, int act_rt, int order_rt, float *z, int z_cs,
+                                                              int z_coff, long npix, int C, const float *res, int res_cs, int res_coff) {
+    const int act = SILU0 ? (int)SOMI_ACT_SILU : act_rt, order = SILU0 ? 0 : order_rt;
+    const EwMap m = ew_map(C >> 2);
+    const int c = m.c;
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+    x += x_coff + c;
+    z += z_coff + c;
+    if (res) res += res_coff + c;
+    auto one = [&](f32x4 v) {
         if (order == 0) {
             v = v * sc + sh;
 #pragma unroll
@@ -234,18 +261,41 @@ __global__ __launch_bounds__(256) void chan_affine_act_kernel(const float *__res
             for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
             v = v * sc + sh;
         }
-        if (res) v += *reinterpret_cast<const f32x4 *>(res + p * res_cs + res_coff + c);
-        *reinterpret_cast<f32x4 *>(z + p * z_cs + z_coff + c) = v;
+        return v;
+    };
+    long p = m.p;
+    for (; p + (EW_U - 1) * m.pstep < npix; p += EW_U * m.pstep) {
+        f32x4 v[EW_U], r[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) v[u] = *reinterpret_cast<const f32x4 *>(x + (p + u * m.pstep) * x_cs);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) r[u] = *reinterpret_cast<const f32x4 *>(res + (p + u * m.pstep) * res_cs);
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            f32x4 o = one(v[u]);
+            if (res) o += r[u];
+            *reinterpret_cast<f32x4 *>(z + (p + u * m.pstep) * z_cs) = o;
+        }
+    }
+    for (; p < npix; p += m.pstep) {
+        f32x4 o = one(*reinterpret_cast<const f32x4 *>(x + p * x_cs));
+        if (res) o += *reinterpret_cast<const f32x4 *>(res + p * res_cs);
+        *reinterpret_cast<f32x4 *>(z + p * z_cs) = o;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: reduce
 // order 0 (norm then act): d = dz * act'(x*scale+shift), v = x.      S1 = sum d, S2 = sum d*v
 // order 1 (act then norm): d = dz,                       v = act(x). S1 = sum d, S2 = sum d*v
+template <bool SILU0>
 __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
                                                          int x_cs, int x_coff, const float *__restrict__ scale,
-                                                         const float *__restrict__ shift, const float *__restrict__ mean, int act, int order,
-                                                         long npix, int C, float *__restrict__ p1, float *__restrict__ p2, int chunk) {
+                                                         const float *__restrict__ shift, const float *__restrict__ mean, int act_rt,
+                                                         int order_rt, long npix, int C, float *__restrict__ p1, float *__restrict__ p2,
+                                                         int chunk) {
+    const int act = SILU0 ? (int)SOMI_ACT_SILU : act_rt, order = SILU0 ? 0 : order_rt;
     // S2 is accumulated as sum d*(v - mean) directly (not sum d*v minus mean * sum d afterwards: that difference cancels)
     chunk_reduce2(npix, C, p1, p2, chunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
         const f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
@@ -294,32 +344,47 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float *__restrict
 }
 // apply: order 0: dx = A*d + Bc*(x - mean) + Cc with d = dz*act'(x*scale+shift)
 //        order 1: dx = (A*dz + Bc*(act(x) - mean) + Cc) * act'(x)
-__global__ __launch_bounds__(256) void bn_act_bwd_apply(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
-                                                        int x_cs, int x_coff, const float *__restrict__ scale,
-                                                        const float *__restrict__ shift, const float *__restrict__ mean,
-                                                        const float *__restrict__ coefA, const float *__restrict__ coefB,
-                                                        const float *__restrict__ coefC, int act, int order, float *__restrict__ dx, int dx_cs,
-                                                        int dx_coff, long npix, int C) {
-    const int C4 = C >> 2;
-    const long items = npix * C4;
-    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C4) * 4;
-        const long p = it / C4;
-        const f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
-        const f32x4 A = *reinterpret_cast<const f32x4 *>(coefA + c), Bc = *reinterpret_cast<const f32x4 *>(coefB + c),
-                    Cc = *reinterpret_cast<const f32x4 *>(coefC + c), M = *reinterpret_cast<const f32x4 *>(mean + c);
+template <bool SILU0>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        const float *__restrict__ mean, const float *__restrict__ coefA,
+                                                        const float *__restrict__ coefB, const float *__restrict__ coefC, int act_rt,
+                                                        int order_rt, float *dx, int dx_cs, int dx_coff, long npix, int C) {
+    const int act = SILU0 ? (int)SOMI_ACT_SILU : act_rt, order = SILU0 ? 0 : order_rt;
+    const EwMap m = ew_map(C >> 2);
+    const int c = m.c;
+    const f32x4 A = *reinterpret_cast<const f32x4 *>(coefA + c), Bc = *reinterpret_cast<const f32x4 *>(coefB + c),
+                Cc = *reinterpret_cast<const f32x4 *>(coefC + c), M = *reinterpret_cast<const f32x4 *>(mean + c),
+                sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+    dz += dz_coff + c;
+    x += x_coff + c;
+    dx += dx_coff + c;
+    auto one = [&](const f32x4 g, const f32x4 v) {
         f32x4 r;
         if (order == 0) {
-            const f32x4 u = v * *reinterpret_cast<const f32x4 *>(scale + c) + *reinterpret_cast<const f32x4 *>(shift + c);
+            const f32x4 u = v * sc + sh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = A[e] * (g[e] * act_grad(u[e], act)) + Bc[e] * (v[e] - M[e]) + Cc[e];
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = (A[e] * g[e] + Bc[e] * (act_fwd(v[e], act) - M[e]) + Cc[e]) * act_grad(v[e], act);
         }
-        *reinterpret_cast<f32x4 *>(dx + p * dx_cs + dx_coff + c) = r;
+        return r;
+    };
+    long p = m.p;
+    for (; p + (EW_U - 1) * m.pstep < npix; p += EW_U * m.pstep) {
+        f32x4 g[EW_U], v[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            g[u] = *reinterpret_cast<const f32x4 *>(dz + (p + u * m.pstep) * dz_cs);
+            v[u] = *reinterpret_cast<const f32x4 *>(x + (p + u * m.pstep) * x_cs);
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) *reinterpret_cast<f32x4 *>(dx + (p + u * m.pstep) * dx_cs) = one(g[u], v[u]);
     }
+    for (; p < npix; p += m.pstep)
+        *reinterpret_cast<f32x4 *>(dx + p * dx_cs) =
+            one(*reinterpret_cast<const f32x4 *>(dz + p * dz_cs), *reinterpret_cast<const f32x4 *>(x + p * x_cs));
 }
 
 // per-channel sum over pixels of a tensor (bias gradients): out[c] += sum_p x[p,c]
@@ -337,22 +402,71 @@ __global__ __launch_bounds__(256) void chan_sum_stage2(const float *__restrict__
 }
 
 // out = a + b on channel slices (residual adds / gradient accumulation); out may alias a or b
-__global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, int a_cs, int a_coff, const float *__restrict__ b, int b_cs,
-                                                  int b_coff, float *__restrict__ o, int o_cs, int o_coff, long npix, int C) {
-    const int C4 = C >> 2;
-    const long items = npix * C4;
-    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C4) * 4;
-        const long p = it / C4;
-        *reinterpret_cast<f32x4 *>(o + p * o_cs + o_coff + c) =
-            *reinterpret_cast<const f32x4 *>(a + p * a_cs + a_coff + c) + *reinterpret_cast<const f32x4 *>(b + p * b_cs + b_coff + c);
+__global__ __launch_bounds__(256) void add_kernel(const float *a, int a_cs, int a_coff, const float *b, int b_cs, int b_coff, float *o,
+                                                  int o_cs, int o_coff, long npix, int C) {
+    const EwMap m = ew_map(C >> 2);
+    a += a_coff + m.c;
+    b += b_coff + m.c;
+    o += o_coff + m.c;
+    long p = m.p;
+    for (; p + (EW_U - 1) * m.pstep < npix; p += EW_U * m.pstep) {
+        f32x4 va[EW_U], vb[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            va[u] = *reinterpret_cast<const f32x4 *>(a + (p + u * m.pstep) * a_cs);
+            vb[u] = *reinterpret_cast<const f32x4 *>(b + (p + u * m.pstep) * b_cs);
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) *reinterpret_cast<f32x4 *>(o + (p + u * m.pstep) * o_cs) = va[u] + vb[u];
     }
+    for (; p < npix; p += m.pstep)
+        *reinterpret_cast<f32x4 *>(o + p * o_cs) = *reinterpret_cast<const f32x4 *>(a + p * a_cs) + *reinterpret_cast<const f32x4 *>(b + p * b_cs);
 }
 
-static inline int ew_grid(long items) {
-    long g = (items + 255) / 256;
-    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+// grid of an element-wise sweep in the ew_map layout: enough 256-thread workgroups for one item per thread, at most `EW_WG_MAX` = 256 CUs x the workgroups of that kernel
+// one CU holds (one resident round of the chip - a second, partial round would idle most CUs), rounded up to a thread count that is a multiple of C/4
+static inline int ew_grid_c(long npix, int C, int EW_WG_MAX) {
+    const int C4 = C / 4;
+    int a = C4, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }              // a = gcd(C4, 256)
+    const long mult = C4 / a;                                     // workgroups per whole number of pixels
+    long g = (npix * C4 + 255) / 256;
+    g = g < 1 ? 1 : (g > EW_WG_MAX ? EW_WG_MAX : g);
+    g = (g + mult - 1) / mult * mult;
+    return (int)g;
 }
+// workgroups per CU (from the kernels' register counts: 512 VGPRs per SIMD lane, one wave of a 256-thread workgroup per SIMD) x 256 CUs
+constexpr int WG_AFFINE = 5 * 256, WG_AFFINE_RT = 5 * 256, WG_APPLY = 5 * 256, WG_APPLY_RT = 4 * 256, WG_ADD = 7 * 256;
+
+static void launch_affine_act(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, int act, int order, float *z, int z_cs,
+                              int z_coff, long npix, int C, const float *res, int res_cs, int res_coff, hipStream_t s) {
+    if (act == SOMI_ACT_SILU && order == 0)
+        hipLaunchKernelGGL(chan_affine_act_kernel<true>, dim3(ew_grid_c(npix, C, WG_AFFINE)), dim3(256), 0, s, x, x_cs, x_coff, scale, shift, act, order,
+                           z, z_cs, z_coff, npix, C, res, res_cs, res_coff);
+    else
+        hipLaunchKernelGGL(chan_affine_act_kernel<false>, dim3(ew_grid_c(npix, C, WG_AFFINE_RT)), dim3(256), 0, s, x, x_cs, x_coff, scale, shift, act,
+                           order, z, z_cs, z_coff, npix, C, res, res_cs, res_coff);
+}
+static void launch_bwd_stage1(int nchunk, const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *scale,
+                              const float *shift, const float *mean, int act, int order, long npix, int C, float *p1, float *p2, hipStream_t s) {
+    if (act == SOMI_ACT_SILU && order == 0)
+        hipLaunchKernelGGL(bn_act_bwd_stage1<true>, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order,
+                           npix, C, p1, p2, red_chunk(npix));
+    else
+        hipLaunchKernelGGL(bn_act_bwd_stage1<false>, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order,
+                           npix, C, p1, p2, red_chunk(npix));
+}
+static void launch_bwd_apply(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *scale, const float *shift,
+                             const float *mean, const float *cA, const float *cB, const float *cC, int act, int order, float *dx, int dx_cs,
+                             int dx_coff, long npix, int C, hipStream_t s) {
+    if (act == SOMI_ACT_SILU && order == 0)
+        hipLaunchKernelGGL(bn_act_bwd_apply<true>, dim3(ew_grid_c(npix, C, WG_APPLY)), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift,
+                           mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, npix, C);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply<false>, dim3(ew_grid_c(npix, C, WG_APPLY_RT)), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale,
+                           shift, mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, npix, C);
+}
+
 static inline bool slice_ok(const void *p, int cs, int coff, int C) { return p && cs % 4 == 0 && coff % 4 == 0 && coff + C <= cs && aligned16(p); }
 
 }  // namespace somi
@@ -405,8 +519,7 @@ extern "C" int somi_chan_affine_act_nhwc_f32(const float *x, int x_cs, int x_cof
     SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && slice_ok(z, z_cs, z_coff, C) && scale && shift && npix > 0 && C % 4 == 0 &&
                      (order == 0 || order == 1) && aligned16(scale) && aligned16(shift), SOMI_EINVAL, "chan affine act: bad arguments");
     SOMI_REQUIRE(!residual || slice_ok(residual, res_cs, res_coff, C), SOMI_EINVAL, "chan affine act: bad residual slice");
-    hipLaunchKernelGGL(chan_affine_act_kernel, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, scale, shift,
-                       act, order, z, z_cs, z_coff, npix, C, residual, res_cs, res_coff);
+    launch_affine_act(x, x_cs, x_coff, scale, shift, act, order, z, z_cs, z_coff, npix, C, residual, res_cs, res_coff, (hipStream_t)stream);
     return launch_status("somi_chan_affine_act_nhwc_f32");
 }
 
@@ -420,12 +533,10 @@ extern "C" int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_
     const size_t cpad = ((size_t)C + 3) / 4 * 4;
     float *p1 = workspace, *p2 = p1 + (size_t)nchunk * C, *cA = p2 + (size_t)nchunk * C, *cB = cA + cpad, *cC = cB + cpad;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order, npix, C,
-                       p1, p2, red_chunk(npix));
+    launch_bwd_stage1(nchunk, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order, npix, C, p1, p2, s);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, mean, rstd, scale, batch_stats, cA, cB, cC,
                        dgamma, dbeta);
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, cA,
-                       cB, cC, act, order, dx, dx_cs, dx_coff, npix, C);
+    launch_bwd_apply(dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, npix, C, s);
     return launch_status("somi_bn_act_backward_nhwc_f32");
 }
 
@@ -474,8 +585,7 @@ extern "C" int somi_bn_act_backward_sums_f64(const float *dz, int dz_cs, int dz_
     const int nchunk = somi_red_nchunk(npix);
     float *p1 = workspace, *p2 = p1 + (size_t)nchunk * C;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(nchunk), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order, npix, C,
-                       p1, p2, red_chunk(npix));
+    launch_bwd_stage1(nchunk, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act, order, npix, C, p1, p2, s);
     hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums, nullptr, 0);
     return launch_status("somi_bn_act_backward_sums_f64");
 }
@@ -493,8 +603,7 @@ extern "C" int somi_bn_act_backward_apply_sync_f32(const float *dz, int dz_cs, i
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_act_bwd_sync_stage2, dim3(cdiv(C, 256)), dim3(256), 0, s, local_sums, all_sums, nranks, C, mean, rstd, scale, cA, cB, cC,
                        dgamma, dbeta);
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, cA,
-                       cB, cC, act, order, dx, dx_cs, dx_coff, npix, C);
+    launch_bwd_apply(dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, npix, C, s);
     return launch_status("somi_bn_act_backward_apply_sync_f32");
 }
 
@@ -512,7 +621,7 @@ extern "C" int somi_add_nhwc_f32(const float *a, int a_cs, int a_coff, const flo
                                  int o_coff, long npix, int C, somi_stream_t stream) {
     SOMI_REQUIRE(slice_ok(a, a_cs, a_coff, C) && slice_ok(b, b_cs, b_coff, C) && slice_ok(out, o_cs, o_coff, C) && npix > 0 && C % 4 == 0,
                  SOMI_EINVAL, "add: bad arguments");
-    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, a_cs, a_coff, b, b_cs, b_coff, out, o_cs,
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid_c(npix, C, WG_ADD)), dim3(256), 0, (hipStream_t)stream, a, a_cs, a_coff, b, b_cs, b_coff, out, o_cs,
                        o_coff, npix, C);
     return launch_status("somi_add_nhwc_f32");
 }
