@@ -325,10 +325,12 @@ def conditioned_errors(named_grads, named_ref64, sums, eps=2.0 ** -24, rel=1e-3)
     return out
 
 
-def noise_scaled_errors(named_grads, named_ref64, rss):
+def noise_scaled_errors(named_grads, named_ref64, rss, against=None):
     """Per parameter with a measured root-sum-square Q of its gradient's terms (AbsTermSums.rss): (name, r, rel) with
         r   = max |g - g64| / max (|g64| + Q)     the error in units of the parameter's own noise scale,
         rel = max |g - g64| / max |g64|           the plain relative error.
+    against: {name: gradient} of another run - the DIFFERENCE is then taken against that run instead of g64 (same normalisation): how far
+    two runs of one path are apart, e.g. with and without a rounding-sized perturbation of the weights (the parameter's measured condition).
     Independent relative perturbations of size u of the terms (what the fp32 rounding of every layer upstream amounts to) move the sum by
     about u * Q; correlated ones by up to u * |g|: r is directly comparable to u across well- and ill-conditioned parameters."""
     out = []
@@ -336,6 +338,7 @@ def noise_scaled_errors(named_grads, named_ref64, rss):
         g64, q = named_ref64.get(n), rss.get(n)
         if g64 is None or q is None:
             continue
-        d = (g.detach().cpu().double() - g64.double()).abs().max().item()
+        other = g64 if against is None else against[n].detach().cpu()
+        d = (g.detach().cpu().double() - other.double()).abs().max().item()
         out.append((n, d / ((g64.double().abs() + q.double()).max().item() + 1e-300), d / (g64.abs().max().item() + 1e-300)))
     return out

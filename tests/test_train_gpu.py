@@ -223,7 +223,23 @@ def _train_cfg(odconv):
     return cfg
 
 
-def _conditioned_gradient_check(mine, ref32, ref64, cond, what, k_pop=4.0, k_each=12.0):
+def _perturbed_twin(cfg, state, run):
+    """The HIP path a second time with every weight moved by at most one fp32 rounding (x (1 +- 2^-23), random signs): `run(model)` must
+    do forward + loss + backward.  -> {name: gradient}.  How far these gradients are from the unperturbed run's is the parameter's measured
+    condition with respect to rounding-sized input changes - what no arithmetic, fp32 or other, can undercut."""
+    from somi_amd.model import Model
+    twin = Model(cfg)
+    twin.load_state_dict(state)
+    g = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for p in twin.parameters():
+            p.mul_(1.0 + (torch.randint(0, 2, p.shape, generator=g).to(p.dtype) * 2 - 1) * 2.0 ** -23)
+    twin = twin.cuda().train()
+    run(twin)
+    return {n: p.grad.detach().cpu() for n, p in twin.named_parameters() if p.grad is not None}
+
+
+def _conditioned_gradient_check(mine, ref32, ref64, cond, what, twin_grads, k_pop=4.0, k_each=6.0):
     """The full-size gradient bar: conditioning-aware, calibrated on the fp32 CPU path, no name patterns.
 
     A parameter gradient is a sum of terms, g = sum_t a_t b_t.  The fp64 oracle pass measures, per gradient element, Q = sqrt(sum_t (a_t b_t)^2)
@@ -231,9 +247,19 @@ def _conditioned_gradient_check(mine, ref32, ref64, cond, what, k_pop=4.0, k_eac
     rounding of every layer upstream, amplified by the depth of the graph - do to the sum (about u * Q; correlated ones up to u * |g|).
     So an error is judged as   r(p) = max |g - g64| / max (|g64| + Q)   - directly comparable to u across well-conditioned parameters
     (Q <= |g|) and sums of cancelling terms (the 7x7 spatial-attention convs: Q = 10 ... 40 |g| at 320x320, which is why their plain relative
-    error reads 0.3 ... 2 in EITHER fp32 path).  u itself is measured: the fp32 CPU oracle's own r on the same inputs.  The bar:
-      * population: median and 90th percentile of r(HIP) within k_pop x those of the fp32 CPU path,
-      * every parameter: r(HIP) <= k_each x the CPU path's 90th percentile (or its own r on that parameter, if larger).
+    error reads 0.3 ... 2 in EITHER fp32 path).  u itself is measured: the fp32 CPU oracle's own r on the same inputs.
+    Q sees the cancellation inside the last sum only.  What the layers UPSTREAM do to a rounding - batch statistics over 2 ... 32 values in the
+    ODConv attention and on the 4x4 maps divide by a spread that can be smaller than sqrt(eps), max-pools and ReLUs switch - is measured
+    by perturbation: the HIP path runs a second time with every weight moved by one fp32 rounding (_perturbed_twin), and s(p) = the distance
+    of the two HIP runs in the same units is that parameter's response to ONE rounding-sized change of its inputs.  (Round 3: changing only
+    the summation order of the BatchNorm partial sums, 128- to 32-pixel chunks, moved the count of parameters beyond 12 u from 14 to 16 in the
+    128x128 case - all 16 inside one ODConv block whose attention norm sees 2 samples - which a fixed count allowance cannot be told from
+    an error.  Measured with the twin: the HIP path is as far from its own one-rounding twin as from fp64 - median s 2.3e-3 / q90 4.7e-3
+    against r 1.3e-3 / 3.7e-3 at 128x128, 3.6e-2 / 7.1e-2 against 3.5e-2 / 6.8e-2 at 1280x1280; the worst parameter sits at 2.4 x its bar base.)
+    The bar:
+      * population: median of r(HIP) within k_pop x the fp32 CPU path's, 90th percentile within k_pop x max(u, the 90th percentile of s),
+      * every parameter: r(HIP) <= k_each x max(u, the CPU path's own r on that parameter, s(p)),
+      * no O(1) error anywhere (r <= 0.5) whatever s says.
     An indexing / layout mistake moves a well-conditioned gradient by O(|g|): r ~ 0.5, against u ~ 1e-4 ... 2e-2 - caught at any depth; on a
     cancelling sum it moves it by O(Q) - caught as well.  (Layer-isolated tests hold the same kernels to 1e-3 without upstream noise.)"""
     from oracle.somi_ref.testing import noise_scaled_errors
@@ -241,22 +267,27 @@ def _conditioned_gradient_check(mine, ref32, ref64, cond, what, k_pop=4.0, k_eac
     for n, p in mine.named_parameters():
         assert (p.grad is not None) == (n in g64), f'{what}: {n} gradient presence differs from the oracle'
     rss = cond.rss
-    hip = noise_scaled_errors([(n, p.grad) for n, p in mine.named_parameters() if p.grad is not None], g64, rss)
+    mine_g = [(n, p.grad) for n, p in mine.named_parameters() if p.grad is not None]
+    hip = noise_scaled_errors(mine_g, g64, rss)
     cpu = {t[0]: t[1] for t in noise_scaled_errors([(n, p.grad) for n, p in ref32.named_parameters() if p.grad is not None], g64, rss)}
-    assert len(hip) == len(g64), f'{what}: {len(g64) - len(hip)} parameters without a measured term scale'
+    own = {t[0]: t[1] for t in noise_scaled_errors(mine_g, g64, rss, against=twin_grads)}
+    assert len(hip) == len(g64) == len(own), f'{what}: {len(g64) - len(hip)} parameters without a measured term scale'
     rh, rc = torch.tensor([t[1] for t in hip]), torch.tensor([cpu[t[0]] for t in hip])
+    rs = torch.tensor([own[t[0]] for t in hip])
     u = max(float(rc.quantile(0.9)), 64 * 2.0 ** -24)             # floor: a few fp32 roundings (isolated, shallow graphs)
-    worst = sorted(hip, key=lambda t: -t[1] / max(u, cpu[t[0]]))[:5]
+    bar = {n: max(u, cpu[n], own[n]) for n, _, _ in hip}
+    worst = sorted(hip, key=lambda t: -t[1] / bar[t[0]])[:5]
     print(f'{what}: noise-scaled error r  HIP median {float(rh.median()):.2e} q90 {float(rh.quantile(0.9)):.2e} max {float(rh.max()):.2e} | '
-          f'fp32 CPU median {float(rc.median()):.2e} q90 {float(rc.quantile(0.9)):.2e} max {float(rc.max()):.2e} | worst vs u: '
-          + ', '.join(f'{n} x{r / max(u, cpu[n]):.1f}' for n, r, _ in worst))
-    bad = [(n, f'r {r:.2e}', f'cpu {cpu[n]:.2e}', f'rel {rel:.2e}') for n, r, rel in hip if r > k_each * max(u, cpu[n])]
-    assert len(bad) <= max(3, len(hip) // 50), (f'{what}: {len(bad)} parameters beyond {k_each} x the fp32 CPU path\'s noise level u = {u:.2e} '
-                                                 f'(in units of |g| + Q): {bad[:8]}')
+          f'fp32 CPU median {float(rc.median()):.2e} q90 {float(rc.quantile(0.9)):.2e} max {float(rc.max()):.2e} | HIP vs its one-rounding twin '
+          f'median {float(rs.median()):.2e} q90 {float(rs.quantile(0.9)):.2e} max {float(rs.max()):.2e} | worst vs bar: '
+          + ', '.join(f'{n} x{r / bar[n]:.1f} (s {own[n]:.1e})' for n, r, _ in worst))
+    bad = [(n, f'r {r:.2e}', f'cpu {cpu[n]:.2e}', f'twin {own[n]:.2e}', f'rel {rel:.2e}') for n, r, rel in hip if r > k_each * bar[n]]
+    assert not bad, (f'{what}: {len(bad)} parameters beyond {k_each} x max(u = {u:.2e}, the fp32 CPU path\'s error, the response to one rounding) '
+                     f'(in units of |g| + Q): {bad[:8]}')
     gross = [(n, f'r {r:.2e}') for n, r, _ in hip if r > 0.5]
     assert not gross, f'{what}: O(1) gradient errors: {gross[:8]}'
     assert rh.median() <= k_pop * max(float(rc.median()), 16 * 2.0 ** -24), (float(rh.median()), float(rc.median()))
-    assert rh.quantile(0.9) <= k_pop * u, (float(rh.quantile(0.9)), u)
+    assert rh.quantile(0.9) <= k_pop * max(u, float(rs.quantile(0.9))), (float(rh.quantile(0.9)), u, float(rs.quantile(0.9)))
 
 
 def test_cbam_block_backward_isolated_at_320():
@@ -315,6 +346,7 @@ def test_full_width_model_train_step_gradients():
     mine.load_state_dict(ref.state_dict())
     ref.hyp = mine.hyp = dict(HYP_VISDRONE)
     ref64 = copy.deepcopy(ref).double()
+    state0 = copy.deepcopy(ref.state_dict())
     imgs, targets = synthetic_batch(2, 128, seed=4)
     ref.train(), ref64.train()
     l32, _ = OLoss(ref)(ref(imgs.float() / 255), targets)
@@ -326,7 +358,11 @@ def test_full_width_model_train_step_gradients():
     lm, _ = ComputeLoss(mine)(mine(imgs.cuda()), targets.cuda())
     rel_close(lm, l64.detach().float(), rel=1e-4, what='loss')
     lm.backward()
-    _conditioned_gradient_check(mine, ref, ref64, cond, 'full width @128')
+
+    def run(m):
+        m.hyp = dict(HYP_VISDRONE)
+        ComputeLoss(m)(m(imgs.cuda()), targets.cuda())[0].backward()
+    _conditioned_gradient_check(mine, ref, ref64, cond, 'full width @128', _perturbed_twin(cfg, state0, run))
 
 
 @pytest.mark.parametrize('odconv', [False, True])
@@ -816,6 +852,7 @@ def test_uavdt_1280_nc3_training_step_gradients():
     mine.load_state_dict(ref.state_dict())
     ref.hyp = mine.hyp = dict(HYP_VISDRONE)
     ref64 = copy.deepcopy(ref).double()
+    state0 = copy.deepcopy(ref.state_dict())
     imgs, targets = synthetic_batch(2, 1280, nc=3, seed=14)
     mine = mine.cuda().train()
     pm = mine(imgs.cuda())
@@ -840,7 +877,13 @@ def test_uavdt_1280_nc3_training_step_gradients():
         e_o32 = (b32.detach().double() - b64).abs().max().item() / scale
         assert e_mine <= max(4 * e_o32, 1e-3), f'train outputs @1280: HIP {e_mine:.2e} vs fp32 CPU {e_o32:.2e} (relative to fp64)'
     del p64, p32
-    _conditioned_gradient_check(mine, ref, ref64, cond, '1280 nc=3 with DCNv3 sites')
+
+    def run(m):
+        m.hyp = dict(HYP_VISDRONE)
+        ComputeLoss(m)(m(imgs.cuda()), targets.cuda())[0].backward()
+    twin = _perturbed_twin(cfg, state0, run)
+    torch.cuda.empty_cache()
+    _conditioned_gradient_check(mine, ref, ref64, cond, '1280 nc=3 with DCNv3 sites', twin)
 
 
 @pytest.mark.parametrize('amp,loss_rel,grad_med,grad_q90,cos_min', [('bf16x3', 2e-5, 2e-3, 1e-2, 0.99999), ('bf16', 1e-2, None, None, 0.8)])

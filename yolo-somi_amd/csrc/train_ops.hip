@@ -14,11 +14,12 @@ namespace somi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// pixels per stage-1 workgroup: about 1024 chunks for large tensors (stage 2 walks the chunks), never fewer than 128 pixels
+// pixels per stage-1 workgroup: about 1024 chunks for large tensors (stage 2 walks the chunks), never fewer than 32 pixels (the 20x20 maps of
+// a batch of 32 are 12800 pixels: 128-pixel chunks left 156 of the 256 CUs without a workgroup)
 static inline int red_chunk(long npix) {
     long c = (npix + 1023) / 1024;
-    c = (c + 63) / 64 * 64;
-    return (int)(c < 128 ? 128 : (c > 4096 ? 4096 : c));
+    c = (c + 31) / 32 * 32;
+    return (int)(c < 32 ? 32 : (c > 4096 ? 4096 : c));
 }
 
 __device__ __forceinline__ float act_fwd(float u, int act) { return apply_act_rt(u, act); }
