@@ -69,11 +69,30 @@ __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const float *__restric
     for (int c = threadIdx.x; c < 2 * C; c += 256)                    // fixed order over the 4 waves
         part[(size_t)blockIdx.x * 2 * C + c] = (sm[c] + sm[2 * C + c]) + (sm[4 * C + c] + sm[6 * C + c]);
 }
+// 256 threads = 16 columns x 16 row groups: a group walks every 16th partial row with 8 loads in flight (one thread per column walking all
+// <= 1024 rows was a chain of 1024 memory latencies: 0.25 ms for a 512-column sum), the 16 group sums are added in a fixed order
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restrict__ part, int nblk, int C, float *dgamma, float *dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 2 * C) return;
+    __shared__ double l[256];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0;
+    if (c < 2 * C) {
+        int b = grp;
+        for (; b + 7 * 16 < nblk; b += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(b + j * 16) * 2 * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += v[j];
+        }
+        for (; b < nblk; b += 16) a += part[(size_t)b * 2 * C + c];
+    }
+    l[threadIdx.x] = a;
+    __syncthreads();
+    if (grp != 0 || c >= 2 * C) return;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 2 * C + c];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += l[g * 16 + cl];
     if (c < C) dgamma[c] += (float)s; else dbeta[c - C] += (float)s;
 }
 
@@ -173,7 +192,7 @@ extern "C" int somi_layernorm_gelu_bwd_nhwc_f32(const float *u, const float *gam
     const int nblk = grid_for(npix * 64, 1024);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ln_gelu_bwd_kernel, dim3(nblk), dim3(256), (size_t)C * 8 * sizeof(float), s, u, gamma, beta, eps, dz, du, workspace, npix, C);
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(2L * C, 256)), dim3(256), 0, s, workspace, nblk, C, dgamma_accumulate, dbeta_accumulate);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(2L * C, 16)), dim3(256), 0, s, workspace, nblk, C, dgamma_accumulate, dbeta_accumulate);
     return launch_status("somi_layernorm_gelu_bwd_nhwc_f32");
 }
 
