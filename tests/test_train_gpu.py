@@ -68,6 +68,47 @@ def test_bn_act_forward_backward(order, act, batch_stats):
     rel_close(dbet, bn.bias.grad, what='dbeta')
 
 
+@pytest.mark.parametrize('npix,C', [(1, 4), (7, 12), (353, 1028), (5000, 64), (70001, 256), (33, 2048)])
+def test_elementwise_sweeps_cover_every_pixel_and_channel(npix, C):
+    """The sweeps' thread -> (channel quad, pixel walk) mapping at awkward sizes: a single pixel, C/4 that does not divide 256, more channel quads
+    than a workgroup has threads, pixel counts that leave a tail behind the four-deep groups, grids at the resident-round cap; in place too.
+    Against the formulas in fp64."""
+    from somi_amd import ops
+    g = torch.Generator().manual_seed(npix + C)
+    d = torch.device('cuda')
+    x = torch.randn(1, 1, npix, C, generator=g)
+    dz = torch.randn(1, 1, npix, C, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    res = torch.randn(1, 1, npix, C, generator=g)
+    u = x.double() * sc.double() + sh.double()
+    want = u * torch.sigmoid(u) + res.double()
+    xd, resd = x.to(d), res.to(d)
+    out = ops.chan_affine_act(xd, C, 0, sc.to(d), sh.to(d), 'silu', 0, torch.full_like(xd, 9.0), 0, residual=resd, res_coff=0)
+    rel_close(out, want.float(), rel=1e-5, what='affine + silu + residual')
+    inplace = xd.clone()
+    ops.chan_affine_act(inplace, C, 0, sc.to(d), sh.to(d), 'silu', 0, inplace, 0)
+    rel_close(inplace, (u * torch.sigmoid(u)).float(), rel=1e-5, what='affine + silu in place')
+    relu_out = ops.chan_affine_act(xd, C, 0, sc.to(d), sh.to(d), 'relu', 1, torch.empty_like(xd), 0)          # the run-time switch form
+    rel_close(relu_out, (torch.relu(x.double()) * sc.double() + sh.double()).float(), rel=1e-5, what='relu then affine')
+    both = ops.add_(xd.clone(), 0, resd, 0, C)
+    assert torch.equal(both.cpu(), x + res)
+    # backward with frozen statistics: dx = scale * dz * silu'(u)
+    mean, rstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gam = torch.rand(C, generator=g) + 0.5
+    scale = gam * rstd
+    shift = -mean * scale
+    u2 = x.double() * scale.double() + shift.double()
+    sg = torch.sigmoid(u2)
+    want_dx = scale.double() * dz.double() * (sg * (1 + u2 * (1 - sg)))
+    dgam, dbet = torch.zeros(C, device=d), torch.zeros(C, device=d)
+    dx = ops.bn_act_backward(dz.to(d), 0, xd, 0, C, mean.to(d), rstd.to(d), scale.to(d), shift.to(d), 'silu', 0, False,
+                             torch.full_like(xd, 9.0), 0, dgam, dbet)
+    rel_close(dx, want_dx.float(), rel=1e-5, what='frozen-statistics backward dx')
+    dact = dz.double() * (sg * (1 + u2 * (1 - sg)))
+    rel_close(dbet, dact.sum((0, 1, 2)).float(), rel=1e-4, what='dbeta')
+    rel_close(dgam, (dact * (x.double() - mean.double()) * rstd.double()).sum((0, 1, 2)).float(), rel=1e-4, what='dgamma')
+
+
 def _grads_close(mine, ref, what):
     for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
         if q.grad is None:
