@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void global_pool_stage1(const float *__restric
         const float ninf = -__builtin_huge_valf();
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {ninf, ninf, ninf, ninf};
         if (rr < rows_par) {
-            for (int p = p0 + rr; p < p1; p += rows_par) {
+#pragma unroll 4
+            for (int p = p0 + rr; p < p1; p += rows_par) {            // unrolled: four rows' loads in flight, sums in row order
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)b * HW + p) * x_cs + x_coff + (cq0 + cq) * 4);
                 s += v;
 #pragma unroll
@@ -275,25 +276,27 @@ __global__ __launch_bounds__(256) void attn_mlp_kernel(int mode, const float *__
 __global__ __launch_bounds__(256) void chan_stats_kernel(const float *__restrict__ x, int x_cs, int x_coff,
                                                          const float *__restrict__ ca, float *__restrict__ stats, int B,
                                                          int HW, int C) {
-    const int lane = threadIdx.x & 63;
+    int LG = 64;                                                     // lanes per pixel: the smallest power of two covering C / 4 channel quads
+    while (LG > 1 && (LG >> 1) * 4 >= C) LG >>= 1;
+    const int lane = threadIdx.x & 63, sub = lane / LG, sl = lane % LG, ppw = 64 / LG;
     const long wave_id = (blockIdx.x * 256L + threadIdx.x) >> 6, nwave = (long)gridDim.x * 4;
     const long npix = (long)B * HW;
     const float inv_c = 1.0f / (float)C;
-    for (long p = wave_id; p < npix; p += nwave) {
+    for (long p = wave_id * ppw + sub; p < npix; p += nwave * ppw) {
         const long b = p / HW;
         const float *xr = x + p * x_cs + x_coff;
         const float *cr = ca + b * C;
         float s = 0.f, m = -__builtin_huge_valf();
-        for (int c = lane * 4; c < C; c += 256) {
+        for (int c = sl * 4; c < C; c += LG * 4) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c) * *reinterpret_cast<const f32x4 *>(cr + c);
             s += (v[0] + v[1]) + (v[2] + v[3]);
             m = fmaxf(fmaxf(fmaxf(m, v[0]), fmaxf(v[1], v[2])), v[3]);
         }
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = LG >> 1; o > 0; o >>= 1) {
             s += __shfl_xor(s, o);
             m = fmaxf(m, __shfl_xor(m, o));
         }
-        if (lane == 0) {
+        if (sl == 0) {
             stats[p * 2] = s * inv_c;
             stats[p * 2 + 1] = m;
         }

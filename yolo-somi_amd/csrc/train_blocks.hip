@@ -26,15 +26,19 @@ static inline int ew_grid(long items) {
 __global__ __launch_bounds__(256) void cbam_bwd_pixel_kernel(const float *__restrict__ dt2, int d_cs, int d_coff, const float *__restrict__ t,
                                                              int t_cs, int t_coff, const float *__restrict__ ca, const float *__restrict__ sa,
                                                              float *__restrict__ dlogit, int *__restrict__ amaxc, int B, int HW, int C) {
-    const int lane = threadIdx.x & 63;
+    // LG lanes per pixel: the smallest power of two that covers the C / 4 channel quads (64 channels: 16 lanes, four pixels per wave and trip -
+    // a whole wave per pixel left 48 lanes idle there and one 256-byte row in flight per wave)
+    int LG = 64;
+    while (LG > 1 && (LG >> 1) * 4 >= C) LG >>= 1;
+    const int lane = threadIdx.x & 63, sub = lane / LG, sl = lane % LG, ppw = 64 / LG;
     const long wave_id = (blockIdx.x * 256L + threadIdx.x) >> 6, nwave = (long)gridDim.x * 4;
     const long npix = (long)B * HW;
-    for (long p = wave_id; p < npix; p += nwave) {
+    for (long p = wave_id * ppw + sub; p < npix; p += nwave * ppw) {
         const long b = p / HW;
         const float *tr = t + p * t_cs + t_coff, *dr = dt2 + p * d_cs + d_coff, *cr = ca + b * C;
         float s = 0.f, m = -__builtin_huge_valf();
         int mi = 0x7fffffff;
-        for (int c = lane * 4; c < C; c += 256) {
+        for (int c = sl * 4; c < C; c += LG * 4) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + c) * *reinterpret_cast<const f32x4 *>(cr + c);
             const f32x4 g = *reinterpret_cast<const f32x4 *>(dr + c);
             s += (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
@@ -42,13 +46,13 @@ __global__ __launch_bounds__(256) void cbam_bwd_pixel_kernel(const float *__rest
             for (int e = 0; e < 4; ++e)
                 if (v[e] > m) { m = v[e]; mi = c + e; }                  // first maximum inside the lane (ascending c)
         }
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = LG >> 1; o > 0; o >>= 1) {
             s += __shfl_xor(s, o);
             const float om = __shfl_xor(m, o);
             const int oi = __shfl_xor(mi, o);
             if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }   // lowest index on ties (torch.max)
         }
-        if (lane == 0) {
+        if (sl == 0) {
             const float a = sa[p];
             dlogit[p] = s * a * (1.f - a);
             amaxc[p] = mi;
@@ -106,13 +110,76 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_kernel(const floa
     __syncthreads();
     if (threadIdx.x == 0) part[(long)blockIdx.x * (nw + 1) + j] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
-__global__ __launch_bounds__(128) void spatial_attn_bwd_weight_final(const float *__restrict__ part, int nblk, int nw, float *dw, float *dbias) {
-    const int j = threadIdx.x;
-    if (j > nw) return;
+// The same sums, one workgroup per SAW_CHUNK pixels for ALL weights: the chunk's dlogit, its pixel coordinates and the stats rows it can reach
+// (+- pad rows and columns) are staged in LDS once; thread (kernel position, slice) then walks every nsl-th pixel of the chunk for both input
+// channels in fp64, and the slices are added in a fixed order.  (Round 3: the form above - a workgroup per (chunk, weight), 64-bit division per
+// pixel and term - took 121 us per call at 160x160 for 81 M multiply-adds.)
+constexpr int SAW_CHUNK = 2048;
+__global__ __launch_bounds__(256) void spatial_attn_bwd_weight_tile_kernel(const float *__restrict__ dlogit, const float *__restrict__ stats,
+                                                                           float *__restrict__ part, int B, int H, int W, int k) {
+    extern __shared__ __attribute__((aligned(16))) float saw_lds[];
+    const long npix = (long)B * H * W;
+    const int nw = k * k * 2, kk = k * k, pad = k >> 1, halo = pad * W + pad, tid = threadIdx.x;
+    const long p0 = (long)blockIdx.x * SAW_CHUNK;
+    const int np = (int)min((long)SAW_CHUNK, npix - p0);
+    float *sdl = saw_lds;                                              // [SAW_CHUNK] dlogit
+    int *shw = reinterpret_cast<int *>(saw_lds + SAW_CHUNK);           // [SAW_CHUNK] row << 16 | column
+    float *sst = saw_lds + 2 * SAW_CHUNK;                              // [SAW_CHUNK + 2 halo][2] stats
+    for (int i = tid; i < np; i += 256) {
+        const long p = p0 + i;
+        sdl[i] = dlogit[p];
+        shw[i] = (int)((p / W) % H) << 16 | (int)(p % W);
+    }
+    for (int i = tid; i < np + 2 * halo; i += 256) {
+        const long q = p0 - halo + i;
+        const float2 v = (q >= 0 && q < npix) ? *reinterpret_cast<const float2 *>(stats + q * 2) : make_float2(0.f, 0.f);
+        sst[i * 2] = v.x;
+        sst[i * 2 + 1] = v.y;
+    }
+    __syncthreads();
+    const int nsl = 256 / kk;                                          // 5 / 10 / 28 slices for k = 7 / 5 / 3; thread 255 is never one of them
+    double a0 = 0.0, a1 = 0.0;
+    if (tid < kk * nsl) {
+        const int rq = tid % kk, sl = tid / kk, r = rq / k, q = rq % k;
+        const int off = (r - pad) * W + (q - pad) + halo;
+        for (int i = sl; i < np; i += nsl) {
+            const int hw = shw[i];
+            const int hi = (hw >> 16) + r - pad, wi = (hw & 0xffff) + q - pad;
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+                const double g = (double)sdl[i];
+                a0 += g * (double)sst[(i + off) * 2];
+                a1 += g * (double)sst[(i + off) * 2 + 1];
+            }
+        }
+    } else if (tid == 255) {
+        for (int i = 0; i < np; ++i) a0 += (double)sdl[i];             // the bias
+    }
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(saw_lds);
+    red[tid * 2] = a0;
+    red[tid * 2 + 1] = a1;
+    __syncthreads();
+    if (tid < kk) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int sl = 0; sl < nsl; ++sl) { s0 += red[(sl * kk + tid) * 2]; s1 += red[(sl * kk + tid) * 2 + 1]; }
+        part[(long)blockIdx.x * (nw + 1) + tid * 2] = (float)s0;
+        part[(long)blockIdx.x * (nw + 1) + tid * 2 + 1] = (float)s1;
+    }
+    if (tid == 255) part[(long)blockIdx.x * (nw + 1) + nw] = (float)a0;
+}
+// one workgroup per weight: the chunk partials in fp64, fixed order (thread-strided sums, then waves, then the four wave sums)
+__global__ __launch_bounds__(256) void spatial_attn_bwd_weight_final(const float *__restrict__ part, int nblk, int nw, float *dw, float *dbias) {
+    __shared__ double red[4];
+    const int j = blockIdx.x;
     double s = 0.0;
-    for (int i = 0; i < nblk; ++i) s += part[(long)i * (nw + 1) + j];
-    if (j == nw) *dbias += (float)s;
-    else dw[j] += (float)s;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += (double)part[(long)i * (nw + 1) + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float v = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    if (j == nw) *dbias += v;
+    else dw[j] += v;
 }
 
 // ------------------------------------------------------------------------------------------------ C
@@ -134,18 +201,36 @@ __global__ __launch_bounds__(256) void cbam_bwd_chan_kernel(float *__restrict__ 
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
         if (rr < rows_par) {
             const f32x4 cav = *reinterpret_cast<const f32x4 *>(ca + (long)b * C + c);
-            for (int pl = p0 + rr; pl < p1; pl += rows_par) {
-                const long p = (long)b * HW + pl;
-                const f32x4 tv = *reinterpret_cast<const f32x4 *>(t + p * t_cs + t_coff + c);
-                f32x4 g = *reinterpret_cast<const f32x4 *>(dt2 + p * d_cs + d_coff + c);
-                const float2 ds = *reinterpret_cast<const float2 *>(dstats + p * 2);
-                const int am = amaxc[p];
-                g = g * sa[p] + ds.x * inv_c;
+            auto one = [&](long p, const f32x4 tv, f32x4 g, const float2 ds, int am, float sav) {
+                g = g * sav + ds.x * inv_c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (c + e == am) g[e] += ds.y;
                 s1 += g * tv;                                            // d ca
                 *reinterpret_cast<f32x4 *>(dt2 + p * d_cs + d_coff + c) = g * cav;
+            };
+            int pl = p0 + rr;
+            for (; pl + 3 * rows_par < p1; pl += 4 * rows_par) {          // four pixels' loads go out together; sums and stores in pixel order
+                f32x4 tv[4], g[4];
+                float2 ds[4];
+                int am[4];
+                float sav[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long p = (long)b * HW + pl + u * rows_par;
+                    tv[u] = *reinterpret_cast<const f32x4 *>(t + p * t_cs + t_coff + c);
+                    g[u] = *reinterpret_cast<const f32x4 *>(dt2 + p * d_cs + d_coff + c);
+                    ds[u] = *reinterpret_cast<const float2 *>(dstats + p * 2);
+                    am[u] = amaxc[p];
+                    sav[u] = sa[p];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) one((long)b * HW + pl + u * rows_par, tv[u], g[u], ds[u], am[u], sav[u]);
+            }
+            for (; pl < p1; pl += rows_par) {
+                const long p = (long)b * HW + pl;
+                one(p, *reinterpret_cast<const f32x4 *>(t + p * t_cs + t_coff + c), *reinterpret_cast<const f32x4 *>(dt2 + p * d_cs + d_coff + c),
+                    *reinterpret_cast<const float2 *>(dstats + p * 2), amaxc[p], sa[p]);
             }
         }
         l1[threadIdx.x] = s1;
@@ -183,13 +268,15 @@ __global__ __launch_bounds__(256) void pool_argmax_stage1(const float *__restric
         int mi[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { m[e] = -__builtin_huge_valf(); mi[e] = 0x7fffffff; }
-        if (rr < rows_par)
-            for (int pl = p0 + rr; pl < p1; pl += rows_par) {
+        if (rr < rows_par) {
+#pragma unroll 4
+            for (int pl = p0 + rr; pl < p1; pl += rows_par) {            // unrolled: four rows' loads in flight
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)b * HW + pl) * x_cs + x_coff + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (v[e] > m[e]) { m[e] = v[e]; mi[e] = pl; }
             }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { lm[threadIdx.x][e] = m[e]; li[threadIdx.x][e] = mi[e]; }
         __syncthreads();
@@ -317,24 +404,50 @@ __global__ __launch_bounds__(256) void attn_mlp_bwd_weights_kernel(int mode, con
 }
 
 // ------------------------------------------------------------------------------------------------ F
-__global__ __launch_bounds__(256) void pool_bwd_add_kernel(float *__restrict__ dt, int d_cs, int d_coff, const float *__restrict__ davg,
+// blockIdx.y = image; a thread keeps one channel quad of that image (its pooled gradients and argmax positions live in registers) and walks
+// the image's pixels four at a time with the loads issued together - no division, no per-element index loads in the loop (round 3: the
+// item-indexed form ran at 2.4 TB/s).  The host makes gridDim.x * 256 a multiple of C / 4.
+__global__ __launch_bounds__(256) void pool_bwd_add_kernel(float *dt, int d_cs, int d_coff, const float *__restrict__ davg,
                                                            const float *__restrict__ dmax, const int *__restrict__ amaxp, int B, int HW, int C) {
-    const int C4 = C >> 2;
-    const long items = (long)B * HW * C4;
-    const float inv = 1.f / (float)HW;
-    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C4) * 4;
-        const long p = it / C4, b = p / HW;
-        const int pl = (int)(p % HW);
-        f32x4 g = *reinterpret_cast<const f32x4 *>(dt + p * d_cs + d_coff + c);
-        g += *reinterpret_cast<const f32x4 *>(davg + b * C + c) * inv;
-        if (dmax) {
+    const unsigned C4 = (unsigned)C >> 2, nthreads = gridDim.x * 256u, t = blockIdx.x * 256u + threadIdx.x;
+    const int c = (int)(t % C4) * 4, b = blockIdx.y;
+    const int pstep = (int)(nthreads / C4);
+    const f32x4 avg = *reinterpret_cast<const f32x4 *>(davg + (long)b * C + c) * (1.f / (float)HW);
+    f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+    int am[4] = {-1, -1, -1, -1};
+    if (dmax) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (amaxp[b * C + c + e] == pl) g[e] += dmax[b * C + c + e];
-        }
-        *reinterpret_cast<f32x4 *>(dt + p * d_cs + d_coff + c) = g;
+        for (int e = 0; e < 4; ++e) { mx[e] = dmax[(long)b * C + c + e]; am[e] = amaxp[(long)b * C + c + e]; }
     }
+    float *base = dt + (long)b * HW * d_cs + d_coff + c;
+    auto one = [&](f32x4 g, int pl) {
+        g += avg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (am[e] == pl) g[e] += mx[e];
+        return g;
+    };
+    int p = (int)(t / C4);
+    for (; p + 3 * pstep < HW; p += 4 * pstep) {
+        f32x4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const f32x4 *>(base + (long)(p + u * pstep) * d_cs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4 *>(base + (long)(p + u * pstep) * d_cs) = one(g[u], p + u * pstep);
+    }
+    for (; p < HW; p += pstep) *reinterpret_cast<f32x4 *>(base + (long)p * d_cs) = one(*reinterpret_cast<const f32x4 *>(base + (long)p * d_cs), p);
+}
+
+// workgroups per image for the kernel above: one item per thread up to `cap` workgroups over the whole batch, a multiple of C4 / gcd(C4, 256)
+static inline int img_grid_c(int B, int HW, int C, int cap) {
+    const int C4 = C / 4;
+    int a = C4, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const long mult = C4 / a;
+    long g = ((long)HW * C4 + 255) / 256, per = cap / (B > 0 ? B : 1);
+    if (per < 1) per = 1;
+    g = g < 1 ? 1 : (g > per ? per : g);
+    return (int)((g + mult - 1) / mult * mult);
 }
 
 static inline bool sl_ok(const void *p, int cs, int coff, int C) { return p && cs % 4 == 0 && coff % 4 == 0 && coff + C <= cs && aligned16(p); }
@@ -361,9 +474,18 @@ extern "C" int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)B * H * W;
     hipLaunchKernelGGL(spatial_attn_bwd_data_kernel, dim3(ew_grid(npix)), dim3(256), 0, s, dlogit, w, dstats, B, H, W, k);
-    const int chunk = 1024 * 16, nblk = (int)((npix + chunk - 1) / chunk), nw = k * k * 2;
-    hipLaunchKernelGGL(spatial_attn_bwd_weight_kernel, dim3(nblk, nw + 1), dim3(256), 0, s, dlogit, stats, workspace, B, H, W, k, chunk);
-    hipLaunchKernelGGL(spatial_attn_bwd_weight_final, dim3(1), dim3(128), 0, s, workspace, nblk, nw, dw_accumulate, dbias_accumulate);
+    const int nw = k * k * 2, halo = (k >> 1) * (W + 1);
+    const size_t lds = (size_t)(4 * SAW_CHUNK + 4 * halo) * sizeof(float);
+    int nblk;
+    if (lds <= 64 * 1024 && H < 32768 && W < 65536) {                // workspace: (npix / 1024 rounded up) rows of nw + 1 floats - half of them used
+        nblk = (int)((npix + SAW_CHUNK - 1) / SAW_CHUNK);
+        hipLaunchKernelGGL(spatial_attn_bwd_weight_tile_kernel, dim3(nblk), dim3(256), lds, s, dlogit, stats, workspace, B, H, W, k);
+    } else {
+        const int chunk = 1024 * 16;
+        nblk = (int)((npix + chunk - 1) / chunk);
+        hipLaunchKernelGGL(spatial_attn_bwd_weight_kernel, dim3(nblk, nw + 1), dim3(256), 0, s, dlogit, stats, workspace, B, H, W, k, chunk);
+    }
+    hipLaunchKernelGGL(spatial_attn_bwd_weight_final, dim3(nw + 1), dim3(256), 0, s, workspace, nblk, nw, dw_accumulate, dbias_accumulate);
     return launch_status("somi_spatial_attn_bwd_f32");
 }
 
@@ -412,7 +534,8 @@ extern "C" int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff,
                                           int B, int HW, int C, somi_stream_t stream) {
     SOMI_REQUIRE(sl_ok(dt_inout, d_cs, d_coff, C) && davg && (!dmax || amaxp) && B > 0 && HW > 0 && C % 4 == 0 && aligned16(davg), SOMI_EINVAL,
                  "pool bwd add: bad arguments");
-    hipLaunchKernelGGL(pool_bwd_add_kernel, dim3(ew_grid((long)B * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, dt_inout, d_cs, d_coff, davg,
+    SOMI_REQUIRE(B <= 65535, SOMI_EINVAL, "pool bwd add: batch beyond the grid's y range");
+    hipLaunchKernelGGL(pool_bwd_add_kernel, dim3(img_grid_c(B, HW, C, 7 * 256), B), dim3(256), 0, (hipStream_t)stream, dt_inout, d_cs, d_coff, davg,
                        dmax, amaxp, B, HW, C);
     return launch_status("somi_pool_bwd_add_nhwc_f32");
 }
