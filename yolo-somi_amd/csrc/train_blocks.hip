@@ -137,27 +137,27 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_tile_kernel(const
         sst[i * 2 + 1] = v.y;
     }
     __syncthreads();
-    const int nsl = 256 / kk;                                          // 5 / 10 / 28 slices for k = 7 / 5 / 3; thread 255 is never one of them
-    double a0 = 0.0, a1 = 0.0;
+    const int nsl = 256 / kk;                                          // 5 / 10 / 28 slices for k = 7 / 5 / 3
+    double a0 = 0.0, a1 = 0.0, ab = 0.0;
     if (tid < kk * nsl) {
         const int rq = tid % kk, sl = tid / kk, r = rq / k, q = rq % k;
         const int off = (r - pad) * W + (q - pad) + halo;
         for (int i = sl; i < np; i += nsl) {
             const int hw = shw[i];
             const int hi = (hw >> 16) + r - pad, wi = (hw & 0xffff) + q - pad;
+            const double g = (double)sdl[i];
+            if (rq == 0) ab += g;                                      // the bias: each slice's position-0 thread sums its pixels' dlogit
             if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
-                const double g = (double)sdl[i];
                 a0 += g * (double)sst[(i + off) * 2];
                 a1 += g * (double)sst[(i + off) * 2 + 1];
             }
         }
-    } else if (tid == 255) {
-        for (int i = 0; i < np; ++i) a0 += (double)sdl[i];             // the bias
     }
     __syncthreads();
-    double *red = reinterpret_cast<double *>(saw_lds);
+    double *red = reinterpret_cast<double *>(saw_lds), *redb = red + 512;
     red[tid * 2] = a0;
     red[tid * 2 + 1] = a1;
+    if (tid < kk * nsl && tid % kk == 0) redb[tid / kk] = ab;
     __syncthreads();
     if (tid < kk) {
         double s0 = 0.0, s1 = 0.0;
@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_tile_kernel(const
         part[(long)blockIdx.x * (nw + 1) + tid * 2] = (float)s0;
         part[(long)blockIdx.x * (nw + 1) + tid * 2 + 1] = (float)s1;
     }
-    if (tid == 255) part[(long)blockIdx.x * (nw + 1) + nw] = (float)a0;
+    if (tid == 255) {
+        double sb = 0.0;
+        for (int sl = 0; sl < nsl; ++sl) sb += redb[sl];
+        part[(long)blockIdx.x * (nw + 1) + nw] = (float)sb;
+    }
 }
 // one workgroup per weight: the chunk partials in fp64, fixed order (thread-strided sums, then waves, then the four wave sums)
 __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_final(const float *__restrict__ part, int nblk, int nw, float *dw, float *dbias) {

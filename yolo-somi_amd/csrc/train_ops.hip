@@ -74,34 +74,30 @@ __device__ __forceinline__ void chunk_reduce2(long npix, int C, float *part1, fl
     }
 }
 
-// stage-2 helper: 256 threads = 16 channels x 16 chunk groups (the walk over ~1024 chunk partials is latency bound: short
-// per-thread chains, 16 loads in flight); returns (for group 0 lanes) the sums over all chunks of p1 / p2, combined in a fixed order
-constexpr int S2_CH = 16, S2_GRP = 256 / S2_CH;
+// stage-2 helper: 256 threads = 4 channels x 64 chunk groups.  The walk over <= 1024 chunk partials is a chain of memory latencies (the rows were
+// written by the kernel just before: every trip is an L2 miss), so it is made SHORT - a thread sees at most 16 rows - and each trip has 16 loads
+// in flight; 16 channels x 16 groups took 17-18 us per launch, 282 launches per step.  Returns (for group 0 lanes) the sums over all chunks of
+// p1 / p2, combined in a fixed order
+constexpr int S2_CH = 4, S2_GRP = 256 / S2_CH;
 __device__ __forceinline__ bool stage2_sums(const float *__restrict__ p1, const float *__restrict__ p2, int nchunk, int C, int &c, double &s1, double &s2) {
     __shared__ double l1[256], l2[256];
     const int cl = threadIdx.x % S2_CH, grp = threadIdx.x / S2_CH;
     c = blockIdx.x * S2_CH + cl;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     if (c < C) {
-        // S2_DEEP rows of both partial arrays requested before the first sum: the walk is a chain of memory latencies otherwise (one per trip)
-        constexpr int S2_DEEP = 8;
-        int k = grp;
-        for (; k + (S2_DEEP - 1) * S2_GRP < nchunk; k += S2_DEEP * S2_GRP) {
+        constexpr int S2_DEEP = 8;                                     // rows requested together (rows past the end contribute +0.0: exact)
+        for (int k = grp; k < nchunk; k += S2_DEEP * S2_GRP) {
             float v[S2_DEEP], w[S2_DEEP];
 #pragma unroll
             for (int j = 0; j < S2_DEEP; ++j) {
-                v[j] = p1[(long)(k + j * S2_GRP) * C + c];
-                w[j] = p2 ? p2[(long)(k + j * S2_GRP) * C + c] : 0.f;
+                const int r = k + j * S2_GRP;
+                const bool ok = r < nchunk;
+                v[j] = ok ? p1[(long)r * C + c] : 0.f;
+                w[j] = (ok && p2) ? p2[(long)r * C + c] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < S2_DEEP; j += 2) { a0 += v[j]; a1 += v[j + 1]; b0 += w[j]; b1 += w[j + 1]; }
         }
-        for (; k + S2_GRP < nchunk; k += 2 * S2_GRP) {
-            const float v0 = p1[(long)k * C + c], v1 = p1[(long)(k + S2_GRP) * C + c];
-            const float w0 = p2 ? p2[(long)k * C + c] : 0.f, w1 = p2 ? p2[(long)(k + S2_GRP) * C + c] : 0.f;
-            a0 += v0; a1 += v1; b0 += w0; b1 += w1;
-        }
-        if (k < nchunk) { a0 += p1[(long)k * C + c]; if (p2) b0 += p2[(long)k * C + c]; }
     }
     l1[threadIdx.x] = a0 + a1;
     l2[threadIdx.x] = b0 + b1;
