@@ -317,32 +317,36 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_f32_kernel(const W
     }
 }
 
-// dW = (accumulate ? accumulate : 0) + sum_s part[s]   (fixed order: 4 interleaved partial sums, combined 0..3).
-// 64 float4 columns x 4 split groups per workgroup: four times the loads in flight of a one-thread-per-column sweep.
+// dW = (accumulate ? accumulate : 0) + sum_s part[s]   (fixed order: per group two interleaved partial sums, the 16 groups combined 0..15).
+// 16 float4 columns x 16 split groups per workgroup, four rows requested per trip: the walk over the ~100 split partials of a layer is a chain
+// of memory latencies (4 groups with two rows per trip took 13.6 us per launch, 140 launches per step).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int splits, long n, const float *accumulate,
                                                            float *__restrict__ dw) {
-    __shared__ f32x4 sm[4][64];
+    __shared__ f32x4 sm[16][16];
     const long n4 = n >> 2;
-    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (long i0 = blockIdx.x * 64L; i0 < n4; i0 += (long)gridDim.x * 64) {
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long i0 = blockIdx.x * 16L; i0 < n4; i0 += (long)gridDim.x * 16) {
         const long i = i0 + col;
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        f32x4 s0 = zero, s1 = zero;
         if (i < n4) {
-            int k = grp;
-            for (; k + 4 < splits; k += 8) {
-                s0 += *reinterpret_cast<const f32x4 *>(part + (size_t)k * n + i * 4);
-                s1 += *reinterpret_cast<const f32x4 *>(part + (size_t)(k + 4) * n + i * 4);
+            for (int k = grp; k < splits; k += 64) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = k + u * 16 < splits ? *reinterpret_cast<const f32x4 *>(part + (size_t)(k + u * 16) * n + i * 4) : zero;
+                s0 += v[0];
+                s1 += v[1];
+                s0 += v[2];
+                s1 += v[3];
             }
-            if (k < splits) s0 += *reinterpret_cast<const f32x4 *>(part + (size_t)k * n + i * 4);
         }
         sm[grp][col] = s0 + s1;
         __syncthreads();
         if (grp == 0 && i < n4) {
-            f32x4 s = accumulate ? *reinterpret_cast<const f32x4 *>(accumulate + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            s += sm[0][col];
-            s += sm[1][col];
-            s += sm[2][col];
-            s += sm[3][col];
+            f32x4 s = accumulate ? *reinterpret_cast<const f32x4 *>(accumulate + i * 4) : zero;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += sm[g][col];
             *reinterpret_cast<f32x4 *>(dw + i * 4) = s;
         }
         __syncthreads();
@@ -438,7 +442,7 @@ extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float
     else hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 64>), grid, dim3(256), 0, s, a);
     if (!direct) {
         const long n = (long)sets * a.Cout * a.K;
-        long g = (n / 4 + 63) / 64;
+        long g = (n / 4 + 15) / 16;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s,
                            static_cast<const float *>(workspace), a.splits, n, accumulate, dw);
     }

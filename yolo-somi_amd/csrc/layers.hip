@@ -211,20 +211,40 @@ __global__ __launch_bounds__(256) void global_pool_stage1(const float *__restric
         __syncthreads();
     }
 }
+// 256 threads = 16 (sample, channel) columns x 16 chunk groups, four rows requested per trip (one thread per column walking all chunks was a
+// chain of `nchunk` memory latencies); group sums combined in ascending group order
 __global__ __launch_bounds__(256) void global_pool_stage2(const float *__restrict__ part_sum, const float *__restrict__ part_max,
                                                           int nchunk, int C, int B, float inv_hw, float *__restrict__ out_avg,
                                                           float *__restrict__ out_max) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
+    __shared__ double ls[256];
+    __shared__ float lm[256];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
     // the chunk partials are folded in double: at 1280x1280 a channel's mean is the sum of 1600 partials, and ODConv's squeeze
     // BatchNorm over a batch of two turns the DIFFERENCE of two such means into an O(1) signal (tools/layer_drift.py)
     double s = 0.0;
     float m = -__builtin_huge_valf();
-    for (int k = 0; k < nchunk; ++k) {
-        s += (double)part_sum[((long)b * nchunk + k) * C + c];
-        m = fmaxf(m, part_max[((long)b * nchunk + k) * C + c]);
+    if (i < B * C) {
+        const int b = i / C, c = i % C;
+        const float *ps = part_sum + (long)b * nchunk * C + c, *pm = part_max + (long)b * nchunk * C + c;
+        for (int k = grp; k < nchunk; k += 64) {
+            float v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = k + u * 16 < nchunk;
+                v[u] = ok ? ps[(long)(k + u * 16) * C] : 0.f;
+                w[u] = ok ? pm[(long)(k + u * 16) * C] : -__builtin_huge_valf();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += (double)v[u]; m = fmaxf(m, w[u]); }
+        }
     }
+    ls[threadIdx.x] = s;
+    lm[threadIdx.x] = m;
+    __syncthreads();
+    if (grp != 0 || i >= B * C) return;
+#pragma unroll
+    for (int g = 1; g < 16; ++g) { s += ls[g * 16 + cl]; m = fmaxf(m, lm[g * 16 + cl]); }
     out_avg[i] = (float)(s * (double)inv_hw);
     if (out_max) out_max[i] = m;
 }
@@ -710,7 +730,7 @@ extern "C" int somi_global_pool_nhwc_f32(const float *x, int x_cs, int x_coff, i
     const int nchunk = somi_pool_nchunk(HW);
     float *ps = workspace, *pm = workspace + (size_t)B * nchunk * C;
     hipLaunchKernelGGL(global_pool_stage1, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, HW, C, ps, pm, nchunk);
-    hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, ps, pm, nchunk, C, B,
+    hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, (hipStream_t)stream, ps, pm, nchunk, C, B,
                        1.0f / (float)HW, out_avg, out_max);
     return launch_status("somi_global_pool_nhwc_f32");
 }

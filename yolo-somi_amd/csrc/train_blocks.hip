@@ -246,12 +246,28 @@ __global__ __launch_bounds__(256) void cbam_bwd_chan_kernel(float *__restrict__ 
         __syncthreads();
     }
 }
+// 16 (sample, channel) columns x 16 chunk groups per workgroup, four rows per trip; fp64, groups combined in ascending order
 __global__ __launch_bounds__(256) void img_partial_sum_kernel(const float *__restrict__ part, int nchunk, int C, int B, float *__restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
+    __shared__ double ls[256];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int k = 0; k < nchunk; ++k) s += (double)part[((long)b * nchunk + k) * C + c];
+    if (i < B * C) {
+        const int b = i / C, c = i % C;
+        const float *pp = part + (long)b * nchunk * C + c;
+        for (int k = grp; k < nchunk; k += 64) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = k + u * 16 < nchunk ? pp[(long)(k + u * 16) * C] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (double)v[u];
+        }
+    }
+    ls[threadIdx.x] = s;
+    __syncthreads();
+    if (grp != 0 || i >= B * C) return;
+#pragma unroll
+    for (int g = 1; g < 16; ++g) s += ls[g * 16 + cl];
     out[i] = (float)s;
 }
 
@@ -299,16 +315,42 @@ __global__ __launch_bounds__(256) void pool_argmax_stage1(const float *__restric
         __syncthreads();
     }
 }
+// 16 columns x 16 chunk groups; a group keeps its first maximum (chunks ascend in pixel order inside a group), the groups are merged by
+// (value, lowest pixel index) - the first maximum in pixel order, as torch.max returns it
 __global__ __launch_bounds__(256) void pool_argmax_stage2(const float *__restrict__ pmax, const int *__restrict__ pidx, int nchunk, int C, int B,
                                                           int *__restrict__ amaxp) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
+    __shared__ float lm[256];
+    __shared__ int li[256];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
     float m = -__builtin_huge_valf();
     int mi = 0x7fffffff;
-    for (int k = 0; k < nchunk; ++k) {                                   // chunks ascend in pixel order: strict > keeps the first maximum
-        const float om = pmax[((long)b * nchunk + k) * C + c];
-        if (om > m) { m = om; mi = pidx[((long)b * nchunk + k) * C + c]; }
+    if (i < B * C) {
+        const int b = i / C, c = i % C;
+        const long base = (long)b * nchunk * C + c;
+        for (int k = grp; k < nchunk; k += 64) {
+            float v[4];
+            int x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = k + u * 16 < nchunk;
+                v[u] = ok ? pmax[base + (long)(k + u * 16) * C] : -__builtin_huge_valf();
+                x[u] = ok ? pidx[base + (long)(k + u * 16) * C] : 0x7fffffff;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (v[u] > m || (v[u] == m && x[u] < mi)) { m = v[u]; mi = x[u]; }
+        }
+    }
+    lm[threadIdx.x] = m;
+    li[threadIdx.x] = mi;
+    __syncthreads();
+    if (grp != 0 || i >= B * C) return;
+#pragma unroll
+    for (int g = 1; g < 16; ++g) {
+        const float om = lm[g * 16 + cl];
+        const int oi = li[g * 16 + cl];
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
     }
     amaxp[i] = mi;
 }
@@ -502,7 +544,7 @@ extern "C" int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, co
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cbam_bwd_chan_kernel, dim3(nchunk, B), dim3(256), 0, s, dt2_inout, d_cs, d_coff, t, t_cs, t_coff, ca, sa, dstats, amaxc,
                        workspace, HW, C, nchunk);
-    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, workspace, nchunk, C, B, dca);
+    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, workspace, nchunk, C, B, dca);
     return launch_status("somi_cbam_bwd_chan_f32");
 }
 
@@ -514,7 +556,7 @@ extern "C" int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, i
     int *pi = reinterpret_cast<int *>(pm + (size_t)B * nchunk * C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(pool_argmax_stage1, dim3(nchunk, B), dim3(256), 0, s, x, x_cs, x_coff, HW, C, pm, pi, nchunk);
-    hipLaunchKernelGGL(pool_argmax_stage2, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, pm, pi, nchunk, C, B, amaxp);
+    hipLaunchKernelGGL(pool_argmax_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, pm, pi, nchunk, C, B, amaxp);
     return launch_status("somi_pool_argmax_nhwc_f32");
 }
 
@@ -915,6 +957,6 @@ extern "C" int somi_scale_channels_bwd_nhwc_f32(const float *dout, const float *
     const int nchunk = somi_img_nchunk(HW);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(scale_channels_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, dout, x, s, dx, workspace, HW, C, nchunk);
-    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, workspace, nchunk, C, B, ds);
+    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 16)), dim3(256), 0, st, workspace, nchunk, C, B, ds);
     return launch_status("somi_scale_channels_bwd_nhwc_f32");
 }
