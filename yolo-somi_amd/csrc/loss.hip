@@ -360,8 +360,18 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const LossArgs a, floa
         // fixed-order reductions: thread-strided partial sums, then a tree over the 256 lanes
         double sb = 0.0, sc = 0.0, so = 0.0;
         const float *sl = a.slots + (size_t)l * per_level * SLOT;
-        for (int i = threadIdx.x; i < per_level; i += 256)
-            if (sl[i * SLOT] >= 0.f) { sb += sl[i * SLOT]; sc += sl[i * SLOT + 1]; }
+        for (int i = threadIdx.x; i < per_level; i += 4 * 256) {      // four slots requested per trip (one workgroup walks ~34000 of them per level)
+            float vb[4], vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = i + u * 256;
+                vb[u] = j < per_level ? sl[(size_t)j * SLOT] : -1.f;
+                vc[u] = j < per_level ? sl[(size_t)j * SLOT + 1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (vb[u] >= 0.f) { sb += vb[u]; sc += vc[u]; }
+        }
         for (int i = threadIdx.x; i < a.nblk[l]; i += 256) so += a.partial[a.blk_off[l] + i];
         double vals[3] = {sb, sc, so};
         for (int q = 0; q < 3; ++q) {
