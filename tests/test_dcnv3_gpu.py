@@ -132,20 +132,20 @@ def test_dcnv3_forward_wide_offsets(N, H, W, G, Gc, k, s, p, d, spread):
     rel_close(got, want, rel=1e-5, what='forward')
 
 
-@pytest.mark.parametrize('cfs', [True, False])
-def test_dcnv3_module_backward_matches_oracle(cfs):
+@pytest.mark.parametrize('cfs,C,G', [(True, 64, 4), (False, 64, 4), (False, 256, 8), (True, 512, 8)])   # 256 / 512: the register-resident LN+GELU backward
+def test_dcnv3_module_backward_matches_oracle(cfs, C, G):
     """Training through the whole DCNv3 module (modules/dcnv3.py:222-379): input gradient and every parameter gradient from the
     HIP autograd node against CPU autograd of the oracle module."""
     from oracle.somi_ref.dcnv3 import DCNv3 as ODCN
     from oracle.somi_ref.testing import fill_state
     from somi_amd.dcnv3 import DCNv3
-    ref = fill_state(ODCN(64, 3, group=4, offset_scale=1.5, center_feature_scale=cfs), 3).train()
-    mod = DCNv3(64, 3, group=4, offset_scale=1.5, center_feature_scale=cfs)
+    ref = fill_state(ODCN(C, 3, group=G, offset_scale=1.5, center_feature_scale=cfs), 3).train()
+    mod = DCNv3(C, 3, group=G, offset_scale=1.5, center_feature_scale=cfs)
     mod.load_state_dict(ref.state_dict())
     mod = mod.cuda().train()
     g = torch.Generator().manual_seed(17)
-    x = torch.randn(2, 12, 10, 64, generator=g)
-    dout = torch.randn(2, 12, 10, 64, generator=g)
+    x = torch.randn(2, 12, 10, C, generator=g)
+    dout = torch.randn(2, 12, 10, C, generator=g)
     xr = x.clone().requires_grad_(True)
     ref(xr).backward(dout)
     xm = x.cuda().requires_grad_(True)

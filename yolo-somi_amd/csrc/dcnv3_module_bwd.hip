@@ -69,6 +69,92 @@ __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const float *__restric
     for (int c = threadIdx.x; c < 2 * C; c += 256)                    // fixed order over the 4 waves
         part[(size_t)blockIdx.x * 2 * C + c] = (sm[c] + sm[2 * C + c]) + (sm[4 * C + c] + sm[6 * C + c]);
 }
+// The same for C = NV * 256 (the DCNv3 sites: 256): a lane keeps its NV float4 of the row, of dz and of gamma / beta in registers, so a row costs
+// ONE round of loads instead of four dependent ones (the form above re-reads the row for the mean, the variance, the sums and the result), the
+// next row's loads are issued before this row's three reductions, gelu' is evaluated once, and the lane's columns of the dgamma / dbeta
+// partials stay in registers until the end.  Same expressions in the same order: bit-identical results.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_gelu_bwd_reg_kernel(const float *__restrict__ u, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float eps, const float *__restrict__ dz,
+                                                              float *__restrict__ du, float *__restrict__ part, long npix) {
+    constexpr int C = NV * 256;
+    extern __shared__ float sm[];                                   // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *mg = sm + (size_t)wave * 2 * C, *mb = mg + C;
+    f32x4 gm[NV], bt[NV], ag[NV], ab[NV], v[NV], d[NV], nv[NV], nd[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        gm[k] = *reinterpret_cast<const f32x4 *>(gamma + k * 256 + lane * 4);
+        bt[k] = *reinterpret_cast<const f32x4 *>(beta + k * 256 + lane * 4);
+        ag[k] = ab[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long wave_id = blockIdx.x * 4L + wave, nwave = (long)gridDim.x * 4;
+    long p = wave_id;
+    if (p < npix) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            nv[k] = *reinterpret_cast<const f32x4 *>(u + p * C + k * 256 + lane * 4);
+            nd[k] = *reinterpret_cast<const f32x4 *>(dz + p * C + k * 256 + lane * 4);
+        }
+    }
+    for (; p < npix; p += nwave) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { v[k] = nv[k]; d[k] = nd[k]; }
+        if (p + nwave < npix) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                nv[k] = *reinterpret_cast<const f32x4 *>(u + (p + nwave) * C + k * 256 + lane * 4);
+                nd[k] = *reinterpret_cast<const f32x4 *>(dz + (p + nwave) * C + k * 256 + lane * 4);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const f32x4 w = v[k] - mean;
+            q += (w[0] * w[0] + w[1] * w[1]) + (w[2] * w[2] + w[3] * w[3]);
+        }
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+        f32x4 xh[NV], g[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            xh[k] = (v[k] - mean) * rstd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g0 = d[k][e] * gelu_grad(xh[k][e] * gm[k][e] + bt[k][e]);
+                ag[k][e] += g0 * xh[k][e];
+                ab[k][e] += g0;
+                g[k][e] = g0 * gm[k][e];
+                sg += g[k][e];
+                sgx += g[k][e] * xh[k][e];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sgx += __shfl_xor(sgx, o); }
+        const float m1 = sg / (float)C, m2 = sgx / (float)C;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rstd * (g[k][e] - m1 - xh[k][e] * m2);
+            *reinterpret_cast<f32x4 *>(du + p * C + k * 256 + lane * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        *reinterpret_cast<f32x4 *>(mg + k * 256 + lane * 4) = ag[k];
+        *reinterpret_cast<f32x4 *>(mb + k * 256 + lane * 4) = ab[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256)                    // fixed order over the 4 waves
+        part[(size_t)blockIdx.x * 2 * C + c] = (sm[c] + sm[2 * C + c]) + (sm[4 * C + c] + sm[6 * C + c]);
+}
+
 // 256 threads = 16 columns x 16 row groups: a group walks every 16th partial row with 8 loads in flight (one thread per column walking all
 // <= 1024 rows was a chain of 1024 memory latencies: 0.25 ms for a 512-column sum), the 16 group sums are added in a fixed order
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restrict__ part, int nblk, int C, float *dgamma, float *dbeta) {
@@ -191,7 +277,10 @@ extern "C" int somi_layernorm_gelu_bwd_nhwc_f32(const float *u, const float *gam
     SOMI_REQUIRE((size_t)C * 8 * sizeof(float) <= 64 * 1024, SOMI_ENOTIMPL, "layernorm+gelu backward: C up to 2048");
     const int nblk = grid_for(npix * 64, 1024);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ln_gelu_bwd_kernel, dim3(nblk), dim3(256), (size_t)C * 8 * sizeof(float), s, u, gamma, beta, eps, dz, du, workspace, npix, C);
+    const size_t lds = (size_t)C * 8 * sizeof(float);
+    if (C == 256) hipLaunchKernelGGL(ln_gelu_bwd_reg_kernel<1>, dim3(nblk), dim3(256), lds, s, u, gamma, beta, eps, dz, du, workspace, npix);
+    else if (C == 512) hipLaunchKernelGGL(ln_gelu_bwd_reg_kernel<2>, dim3(nblk), dim3(256), lds, s, u, gamma, beta, eps, dz, du, workspace, npix);
+    else hipLaunchKernelGGL(ln_gelu_bwd_kernel, dim3(nblk), dim3(256), lds, s, u, gamma, beta, eps, dz, du, workspace, npix, C);
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(2L * C, 16)), dim3(256), 0, s, workspace, nblk, C, dgamma_accumulate, dbeta_accumulate);
     return launch_status("somi_layernorm_gelu_bwd_nhwc_f32");
 }
