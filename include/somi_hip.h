@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 12
+#define SOMI_ABI_VERSION 13
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -316,6 +316,11 @@ int somi_red_nchunk(long npix);
 int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float eps, float momentum,
                            const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
                            float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
+/* The same statistics of act(x) (enum somi_act) without act(x) ever being stored: SEAM's act-then-norm stages (models/common.py:8455-8457)
+ * then are two passes - this one, and somi_chan_affine_act_nhwc_f32 with order 1 - instead of act, statistics, affine. */
+int somi_bn_stats_act_nhwc_f32(const float *x, int x_cs, int x_coff, int act, long npix, int C, float eps, float momentum,
+                               const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                               float *running_mean, float *running_var, float *workspace, somi_stream_t stream);
 /* The same from the partial sums a convolution left behind (somi_conv_desc.stat_sum / stat_sumsq, `rows` rows, taken around
  * running_mean as the pivot when running_mean is given - pass the same pointer as stat_pivot).  workspace: 2*1024*C floats. */
 int somi_bn_stats_partials_f32(const float *part_sum, const float *part_sumsq, int rows, long npix, int C, float eps, float momentum,

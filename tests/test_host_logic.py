@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(L, name), f'{name} is declared in include/somi_hip.h but not exported'
-    assert _lib.lib().somi_abi_version() == _lib.ABI_VERSION == 12
+    assert _lib.lib().somi_abi_version() == _lib.ABI_VERSION == 13
 
 
 def test_struct_layouts_match_header():

@@ -429,7 +429,8 @@ __global__ __launch_bounds__(256) void attn_mlp_bwd_weights_kernel(int mode, con
     for (long it = blockIdx.x * 256L + threadIdx.x; it < n; it += (long)gridDim.x * 256) {
         const int c = (int)(it % C), j = (int)(it / C);                  // consecutive lanes: consecutive channels
         float s1 = 0.f, s2 = 0.f;
-        for (int b = 0; b < B; ++b) {
+#pragma unroll 8
+        for (int b = 0; b < B; ++b) {                                    // unrolled: eight samples' loads in flight, sums in sample order
             const float *wb = ws + (long)b * stride;
             s2 += wb[c] * wb[C + j];
             s1 += wb[C + mid + j] * avg[(long)b * C + c] + (mx ? wb[C + 2 * mid + j] * mx[(long)b * C + c] : 0.f);

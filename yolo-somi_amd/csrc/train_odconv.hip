@@ -21,11 +21,20 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
     __shared__ float pre[1024];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *xr = x + (long)b * ldx;
-    for (int o = wave; o < nout; o += 4) {
-        float s = 0.f;
-        for (int i = lane; i < nin; i += 64) s += W[(long)o * nin + i] * xr[i];
-        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_down(s, sft);
-        if (lane == 0) pre[o] = s + (bias ? bias[o] : 0.f);
+    if (nin <= 32) {
+        // the attention heads (hidden 16 -> up to 1024 outputs): a thread per output - a wave per output left 48 lanes idle and walked 256 outputs each
+        for (int o = threadIdx.x; o < nout; o += 256) {
+            float s = 0.f;
+            for (int i = 0; i < nin; ++i) s += W[(long)o * nin + i] * xr[i];
+            pre[o] = s + (bias ? bias[o] : 0.f);
+        }
+    } else {
+        for (int o = wave; o < nout; o += 4) {
+            float s = 0.f;
+            for (int i = lane; i < nin; i += 64) s += W[(long)o * nin + i] * xr[i];
+            for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_down(s, sft);
+            if (lane == 0) pre[o] = s + (bias ? bias[o] : 0.f);
+        }
     }
     __syncthreads();
     if (act == ACT_SOFTMAX) {
@@ -69,6 +78,7 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float *__r
         if (e < n) {
             const int o = (int)(e / nin), i = (int)(e % nin);
             float s = 0.f;
+#pragma unroll 8
             for (int b = 0; b < B; ++b) s += dpre[(long)b * ldp + o] * x[(long)b * ldx + i];
             dW[e] += s;
         } else if (db) {
@@ -235,7 +245,8 @@ __global__ __launch_bounds__(256) void odconv_synth_bwd_finish_kernel(const floa
     for (int i = threadIdx.x; i < np; i += 256) {                        // i indexes [da_s | da_c | da_w] exactly like the partial rows
         float s = 0.f;
         const bool is_w = i >= kk + Cin;
-        for (int n = 0; n < Cout; ++n) {
+#pragma unroll 8
+        for (int n = 0; n < Cout; ++n) {                                 // unrolled: eight rows' loads in flight, sums in row order
             s += at[n] * part[((long)b * Cout + n) * np + i];
             if (is_w && biask) s += dbias_b[(long)b * Cout + n] * biask[(i - kk - Cin) * Cout + n];
         }

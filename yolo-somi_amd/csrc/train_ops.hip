@@ -114,11 +114,16 @@ __device__ __forceinline__ bool stage2_sums(const float *__restrict__ p1, const 
 // ------------------------------------------------------------------------------------------------ BN statistics
 // Sums are taken around a per-channel pivot (the running mean before this step's update, when there is one): the variance
 // sum_sq/n - mean^2 then does not cancel catastrophically for channels whose mean is large against their spread.
+// act != NONE: the statistics of act(x) - the act-then-norm stages (SEAM) need no materialised act(x): the normalise pass applies act again
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float *__restrict__ x, int cs, int coff, long npix, int C,
                                                        const float *__restrict__ pivot, float *__restrict__ p1, float *__restrict__ p2,
-                                                       int chunk) {
+                                                       int chunk, int act) {
     chunk_reduce2(npix, C, p1, p2, chunk, [&](long p, int c, f32x4 &s1, f32x4 &s2) {
         f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * cs + coff + c);
+        if (act != SOMI_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
+        }
         if (pivot) v -= f32x4{pivot[c], pivot[c + 1], pivot[c + 2], pivot[c + 3]};
         s1 += v;
         s2 += v * v;
@@ -475,17 +480,24 @@ extern "C" int somi_red_nchunk(long npix) { const int c = red_chunk(npix); retur
 extern "C" int somi_bn_stats_nhwc_f32(const float *x, int x_cs, int x_coff, long npix, int C, float eps, float momentum,
                                       const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
                                       float *running_mean, float *running_var, float *workspace, somi_stream_t stream) {
-    SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && npix > 0 && C > 0 && C % 4 == 0 && mean && rstd && scale && shift && workspace, SOMI_EINVAL,
-                 "bn stats: bad arguments");
+    return somi_bn_stats_act_nhwc_f32(x, x_cs, x_coff, SOMI_ACT_NONE, npix, C, eps, momentum, gamma, beta, mean, rstd, scale, shift, running_mean,
+                                      running_var, workspace, stream);
+}
+
+extern "C" int somi_bn_stats_act_nhwc_f32(const float *x, int x_cs, int x_coff, int act, long npix, int C, float eps, float momentum,
+                                          const float *gamma, const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                                          float *running_mean, float *running_var, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C) && npix > 0 && C > 0 && C % 4 == 0 && mean && rstd && scale && shift && workspace && act >= 0 &&
+                     act <= 4, SOMI_EINVAL, "bn stats: bad arguments");
     SOMI_REQUIRE(!running_mean == !running_var, SOMI_EINVAL, "bn stats: running_mean and running_var go together");
     const int nchunk = somi_red_nchunk(npix);
     float *p1 = workspace, *p2 = workspace + (size_t)nchunk * C;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, (const float *)running_mean, p1, p2,
-                       red_chunk(npix));
+                       red_chunk(npix), act);
     hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, eps, momentum, gamma, beta, mean, rstd,
                        scale, shift, running_mean, running_var);
-    return launch_status("somi_bn_stats_nhwc_f32");
+    return launch_status("somi_bn_stats_act_nhwc_f32");
 }
 
 extern "C" int somi_bn_stats_partials_f32(const float *part_sum, const float *part_sumsq, int rows, long npix, int C, float eps, float momentum,
@@ -557,7 +569,7 @@ extern "C" int somi_bn_local_sums_f64(const float *x, int x_cs, int x_coff, long
         SOMI_REQUIRE(slice_ok(x, x_cs, x_coff, C), SOMI_EINVAL, "bn local sums: bad slice");
         nchunk = somi_red_nchunk(npix);
         float *o1 = workspace, *o2 = workspace + (size_t)nchunk * C;
-        hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, pivot, o1, o2, red_chunk(npix));
+        hipLaunchKernelGGL(bn_stats_stage1, dim3(nchunk), dim3(256), 0, s, x, x_cs, x_coff, npix, C, pivot, o1, o2, red_chunk(npix), (int)SOMI_ACT_NONE);
         p1 = o1; p2 = o2;
     }
     hipLaunchKernelGGL(sums_fold_f64_kernel, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, nchunk, C, npix, sums, pivot, 1);

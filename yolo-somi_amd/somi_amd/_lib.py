@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SOMI_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 12         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
+ABI_VERSION = 13         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
 
@@ -102,6 +102,7 @@ SIGNATURES = {
     'somi_detect_decode_f32': (I, [P, I, P, I, C.POINTER(C.c_float), F, P, P, I, I, I, I, I, I, I, S]),
     'somi_red_nchunk': (I, [C.c_long]),
     'somi_bn_stats_nhwc_f32': (I, [P, I, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
+    'somi_bn_stats_act_nhwc_f32': (I, [P, I, I, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
     'somi_bn_stats_partials_f32': (I, [P, P, I, C.c_long, I, F, F, P, P, P, P, P, P, P, P, P, S]),
     'somi_bn_local_sums_f64': (I, [P, I, I, C.c_long, I, P, P, P, I, P, P, S]),
     'somi_bn_stats_from_sums_f64': (I, [P, I, I, F, F, P, P, P, P, P, P, P, P, S]),

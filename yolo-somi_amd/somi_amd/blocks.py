@@ -765,15 +765,21 @@ class SEAM(_Packed):
     def _bn_train(self, u, bn):
         """z = BN_batch(GELU(u)) (act before the norm, models/common.py:8455-8457); returns z and the saved statistics."""
         dev, c = u.device, u.shape[3]
-        g = ops.chan_affine_act(u, c, 0, torch.ones(c, device=dev), torch.zeros(c, device=dev), 'gelu', 0, torch.empty_like(u))
         rm, rv = bn.running_mean.detach().clone(), bn.running_var.detach().clone()
-        mean, rstd, scale, shift = ops.bn_stats(g, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv)
+        if ops.SYNC_BN is None:
+            # two passes over u: the statistics of gelu(u) taken on the fly, then z = gelu(u) * scale + shift (order 1) - gelu(u) is never stored
+            # (the backward reads u too); three passes and a tensor less than act -> statistics -> affine
+            st = ops.bn_stats(u, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv, act='gelu')
+            z = ops.chan_affine_act(u, c, 0, st[2], st[3], 'gelu', 1, torch.empty_like(u))
+        else:
+            g = ops.chan_affine_act(u, c, 0, torch.ones(c, device=dev), torch.zeros(c, device=dev), 'gelu', 0, torch.empty_like(u))
+            st = ops.bn_stats(g, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv)
+            z = ops.chan_affine_act(g, c, 0, st[2], st[3], 'none', 0, g)
         with torch.no_grad():
             bn.running_mean.copy_(rm)
             bn.running_var.copy_(rv)
             _bump_batches_tracked(bn)
-        z = ops.chan_affine_act(g, c, 0, scale, shift, 'none', 0, g)
-        return z, (mean, rstd, scale, shift)
+        return z, tuple(st)
 
     def _bn_backward(self, dz, u, st, bn):
         """gradient w.r.t. u of BN_batch(GELU(u)) (order 1), parameter gradients accumulated."""

@@ -601,17 +601,20 @@ def _bn_stats_sync(x, x_coff, n, c, part, rows, gamma, beta, eps, momentum, runn
     return mean, rstd, scale, shift
 
 
-def bn_stats(x, c, x_coff, gamma, beta, eps, momentum, running_mean=None, running_var=None):
-    """Batch statistics of a channel slice -> (mean, rstd, scale, shift); optionally updates the running statistics."""
+def bn_stats(x, c, x_coff, gamma, beta, eps, momentum, running_mean=None, running_var=None, act='none'):
+    """Batch statistics of a channel slice - of act(x) when `act` is given, without storing act(x) - -> (mean, rstd, scale, shift);
+    optionally updates the running statistics."""
     dev = x.device
     n = _npix(x)
     if SYNC_BN is not None:
+        if act != 'none':
+            raise RuntimeError('bn_stats(act=...) has no sync-BN form: materialise act(x) first (blocks.SEAM does)')
         return _bn_stats_sync(x, x_coff, n, c, None, 0, gamma, beta, eps, momentum, running_mean, running_var)
     mean, rstd, scale, shift = (torch.empty(c, device=dev, dtype=torch.float32) for _ in range(4))
     ws = torch.empty(2 * _lib.lib().somi_red_nchunk(n) * c, device=dev, dtype=torch.float32)
-    check(_lib.lib().somi_bn_stats_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, n, c, float(eps), float(momentum), _ptr(gamma), _ptr(beta),
-                                            _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var),
-                                            _ptr(ws), _stream()), 'bn_stats')
+    check(_lib.lib().somi_bn_stats_act_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, ACT[act], n, c, float(eps), float(momentum), _ptr(gamma),
+                                                _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean),
+                                                _ptr(running_var), _ptr(ws), _stream()), 'bn_stats')
     return mean, rstd, scale, shift
 
 
