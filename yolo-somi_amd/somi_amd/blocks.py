@@ -1160,10 +1160,15 @@ class DCNv3_YOLO(_Packed):
             w, b = self._packed(x.t.device)
             return Act(self.dcnv3._forward_impl(x.t, out_proj=(w, b, _act_name(self.act))), 0, c)
         self.invalidate()
-        u, saved = self.dcnv3._forward_impl(x.t, keep=True)
         bn, dev = self.bn, x.t.device
         rm, rv = bn.running_mean.detach().clone(), bn.running_var.detach().clone()
-        st = ops.bn_stats(u, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv)
+        sd = {'pivot': rm} if ops.FUSED_BN_STATS and x.t.numel() * 4 <= 0xE0000000 else None
+        u, saved = self.dcnv3._forward_impl(x.t, keep=True, bn_stats=sd)
+        if sd is not None and 'part' in sd:                       # the output projection's epilogue left the partial sums: no extra read of u
+            st = ops.bn_stats_from_partials(sd['part'], sd['rows'], u.numel() // c, c, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
+                                            rm, rv)
+        else:
+            st = ops.bn_stats(u, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv)
         with torch.no_grad():
             bn.running_mean.copy_(rm)
             bn.running_var.copy_(rv)

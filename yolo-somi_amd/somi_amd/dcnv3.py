@@ -112,7 +112,7 @@ class DCNv3(nn.Module):
             self.center_feature_scale_proj_weight = nn.Parameter(torch.zeros(group, channels))
             self.center_feature_scale_proj_bias = nn.Parameter(torch.zeros(group))
 
-    def _linear(self, x, weight, bias):
+    def _linear(self, x, weight, bias, bn_stats=None):
         """nn.Linear on NHWC == 1x1 conv on the MFMA kernel; weight (out,in) is already [Cout][K].  Cout is padded to a
         multiple of 4 with zero rows (the pad columns are sliced off by the caller when it matters)."""
         cout, cin = weight.shape
@@ -123,7 +123,7 @@ class DCNv3(nn.Module):
             pad = 4 - cout % 4
             w = torch.cat([w, w.new_zeros(pad, cin)])
             b = torch.cat([b, b.new_zeros(pad)])
-        return ops.conv2d_nhwc(x, w.contiguous(), b.contiguous(), kh=1, kw=1)
+        return ops.conv2d_nhwc(x, w.contiguous(), b.contiguous(), kh=1, kw=1, bn_stats=bn_stats if cout % 4 == 0 else None)
 
     def _params(self):
         dw, ln = self.dw_conv[0], self.dw_conv[1][1]
@@ -133,11 +133,12 @@ class DCNv3(nn.Module):
             ps += [self.center_feature_scale_proj_weight, self.center_feature_scale_proj_bias]
         return ps
 
-    def _forward_impl(self, input, keep=False, out_proj=None):
+    def _forward_impl(self, input, keep=False, out_proj=None, bn_stats=None):
         """Every arithmetic step runs in libsomi_hip.so: 4 Linear layers = 1x1 MFMA convs, depthwise conv, LayerNorm+GELU,
         mask softmax, the deformable gather and the centre-feature-scale blend.  keep: also return what backward needs.
         out_proj = (weight, bias, act): replaces the output projection's parameters (a caller folding a following BatchNorm into it)
-        and puts `act` into that conv's epilogue."""
+        and puts `act` into that conv's epilogue.  bn_stats = {'pivot': running_mean}: the output projection's epilogue also leaves the
+        per-channel partial sums of the output for a following batch-statistics BatchNorm (ops.conv2d_nhwc(..., bn_stats=))."""
         N, H, W, C = input.shape
         if self.dw_kernel_size != 3:
             raise NotImplementedError('depthwise kernel size 3 only on the MI355X path')
@@ -180,7 +181,7 @@ class DCNv3(nn.Module):
         if out_proj is not None:
             out = ops.conv2d_nhwc(yb, out_proj[0], out_proj[1], kh=1, kw=1, act=out_proj[2])
         else:
-            out = self._linear(yb, self.output_proj.weight, self.output_proj.bias)
+            out = self._linear(yb, self.output_proj.weight, self.output_proj.bias, bn_stats=bn_stats)
         if keep:
             return out, (input, x_proj, wdw, u, x1, om, y, logit, yb)
         return out
