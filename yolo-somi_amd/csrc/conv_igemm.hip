@@ -211,8 +211,15 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned of
 // bf16 values and hi*hi + hi*lo + lo*hi accumulated in fp32 - 16 mantissa bits per operand, ~1e-5 relative error, 3 MFMAs at 16x the
 // fp32 rate.  The operands stay fp32 in HBM and are converted while they are staged into LDS ([row][32 bf16 hi | 32 bf16 lo] = the
 // fp32 image's 128-byte rows), so nothing outside this kernel changes.
+// Waves per SIMD the register budget is set for: 4 (two 8-wave workgroups per CU), 2 for the big experiment tile, and 6 for the 8-wave
+// 128 x 64 tile's plain fp32 form - its 48 KB of LDS let THREE workgroups share a CU, which the 64-channel layers (K = 576: 18 K-tiles
+// between a prologue and an epilogue) use to hide those phases behind two neighbours instead of one.
+template <int BM, int BN, int WAVES, bool MODULATE, bool FAST, int NS>
+constexpr int conv_waves_per_simd() {
+    return BM + BN > 320 ? 2 : (WAVES == 8 && BM + BN <= 192 && !MODULATE && FAST && NS == 0 ? 6 : WAVES / 2);
+}
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool MODULATE, bool FAST, int NS = 0>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_M * WAVES_N / 2)) void conv_igemm_f32_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (conv_waves_per_simd<BM, BN, WAVES_M * WAVES_N, MODULATE, FAST, NS>())) void conv_igemm_f32_kernel(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;             // 32x32 MFMA tiles per wave
     constexpr int NT = WAVES_M * WAVES_N * 64, RPP = NT / 8;   // threads; rows fetched per pass (8 threads x 16 B cover a row's K-tile)
@@ -653,7 +660,15 @@ struct TilePlan {
     bool sk;       // stream-K schedule
 };
 static const int kTileBM[8] = {128, 64, 128, 128, 128, 128, 256, 256}, kTileBN[8] = {128, 128, 64, 32, 128, 64, 128, 64};
-static inline int sk_slots(int variant) { return variant == 6 ? SK_GRID / 2 : SK_GRID; }   // resident workgroups chip-wide
+// resident workgroups chip-wide: two per CU; one for the big tile; three for the plain fp32 form of the 8-wave 128 x 64 tile
+static inline bool three_per_cu(int variant, const somi_conv_desc &d) {
+    static const bool on = [] { const char *e = getenv("SOMI_CONV_3WG"); return !(e && e[0] == '0'); }();
+    return on && variant == 5 && !d.a_chan_scale && !d.a_pix_scale && d.prec != 1 && d.prec != 2;
+}
+static bool fast_path(const somi_conv_desc &d);
+static inline int sk_slots(int variant, const somi_conv_desc &d) {
+    return variant == 6 ? SK_GRID / 2 : (three_per_cu(variant, d) && fast_path(d) ? SK_GRID * 3 / 2 : SK_GRID);
+}
 
 static bool fast_path(const somi_conv_desc &d) {
     return d.Cin % BK == 0 && d.kh * d.kw <= 32 && (size_t)d.kh * d.kw * d.Cin * 4 < (1u << 27);
@@ -692,7 +707,7 @@ static TilePlan plan_tiles(const somi_conv_desc &d, int M, int dgrad) {
     if (sk_ok) {
         const int bm = kTileBM[p.variant], bn = kTileBN[p.variant];
         const long ntile = (long)cdiv(M, bm) * cdiv(d.Cout, bn), nkt = (long)d.kh * d.kw * d.Cin / BK;
-        const int slots = sk_slots(p.variant);
+        const int slots = sk_slots(p.variant, d);
         const long rounds = (ntile + slots - 1) / slots;
         static const int sk_pct = getenv("SOMI_SK_PCT") ? atoi(getenv("SOMI_SK_PCT")) : 90;   // stream-K below this slot efficiency (%)
         p.sk = ntile * 100 < rounds * slots * sk_pct && ntile * nkt >= 32 &&       // (the grid shrinks to >= 8 K-tiles per workgroup)
@@ -716,7 +731,7 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
     // stream-K grid: all 512 slots, unless that would leave a workgroup fewer than min_kt K-tiles (prologue, partial store and
     // fix-up then cost more than the MFMA work of the piece)
     static const int min_kt = getenv("SOMI_SK_MIN_KT") ? atoi(getenv("SOMI_SK_MIN_KT")) : 8;
-    int sk_grid = BM + BN > 320 ? SK_GRID / 2 : SK_GRID;
+    int sk_grid = BM + BN > 320 ? SK_GRID / 2 : (WAVES_M * WAVES_N == 8 && BM + BN <= 192 && fast && three_per_cu(5, a.d) ? SK_GRID * 3 / 2 : SK_GRID);
     if (sk) {
         const long U = (long)args.tiles_m * args.tiles_n * (a.K / BK);
         if (U / min_kt < sk_grid) sk_grid = (int)(U / min_kt);
