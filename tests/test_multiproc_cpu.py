@@ -29,10 +29,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _free_port():
+    """A port nobody listens on right now (a fixed pid-derived port can meet another process's, or a socket still in TIME_WAIT)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def test_two_rank_sharding_and_timing():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -85,7 +93,7 @@ def test_gradient_buckets_all_reduce_sum_two_ranks():
     """DDP semantics of train.py:208-209,266-267 (mean x WORLD_SIZE == SUM) with buckets launched as layers finish."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

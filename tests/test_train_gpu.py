@@ -753,7 +753,11 @@ def test_rccl_call_pattern_single_rank_rehearsal():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SOMI_DDP_SINGLE_RANK='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29563', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port nobody listens on (a fixed one can meet a socket in TIME_WAIT)
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SOMI_DDP_SINGLE_RANK='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch', '4', '--size', '256',
