@@ -154,6 +154,24 @@ def test_warmup_and_one_cycle_schedule():
     assert math.isclose(lf(100), hyp['lrf'])
 
 
+def test_reduction_chunking_covers_every_pixel_and_bounds_the_partial_rows():
+    """somi_red_nchunk (host arithmetic of the BatchNorm / column-sum reductions; sizes every caller's workspace): the chunks cover all pixels,
+    small maps get enough workgroups (>= 32-pixel chunks: a 20x20 map at batch 32 must not leave most of the 256 CUs idle), and the number of
+    partial rows a stage-2 fold walks stays <= 1024 up to 4 M pixels."""
+    from somi_amd import _lib
+    L = _lib.lib()
+    for npix in (1, 31, 32, 33, 400, 12800, 51200, 204800, 819200, 3276800, 4194304, 13107200):
+        n = L.somi_red_nchunk(npix)
+        assert n >= 1
+        chunk = -(-npix // n)                                     # pixels per chunk is at least this
+        assert n * 4096 >= npix, (npix, n)                        # chunks are capped at 4096 pixels
+        if npix <= 4194304:
+            assert n <= 1024, (npix, n)
+        if npix >= 12800:
+            assert n >= 256, (npix, n)                            # every CU gets a workgroup
+        assert chunk >= 1
+
+
 def test_header_is_plain_c():
     """include/somi_hip.h is the drop-in boundary: it must compile as C (no C++ or torch types) and the INTEGRATION.md conv
     example must compile against it."""
