@@ -274,18 +274,22 @@ def main():
     if ensemble:                                                # configs[4]: "fused NMS + WBF" = wbf.py over the label sets of several models
         model2 = fill_state(Model(cfg), 2).to(dev).eval()     # the second synthetic "model": same graph, other weights
 
-    def infer_step():
+    def ensemble_step(m1, m2, batch_imgs):
+        """configs[4]: two models x (forward + decode + NMS) + device WBF of their detections, image by image (val.py:148-189, wbf.py:55-68)."""
         with torch.no_grad():
-            z, _ = model(imgs)
-            if args.no_nms:
-                return None
-            if not ensemble:
-                return non_max_suppression(z, 0.001, 0.6, multi_label=True)
+            z, _ = m1(batch_imgs)
             d1 = non_max_suppression_raw(z, 0.001, 0.6, multi_label=True)          # val.sh:1 thresholds; rows stay on the device
-            z2, _ = model2(imgs)
+            z2, _ = m2(batch_imgs)
             d2 = non_max_suppression_raw(z2, 0.001, 0.6, multi_label=True)
             return weighted_boxes_fusion_batch([d1[0], d2[0]], [d1[1], d2[1]], (args.size, args.size), weights=None,
                                                iou_thr=0.67, skip_box_thr=0.01)       # wbf.py:34-35,68
+
+    def infer_step():
+        with torch.no_grad():
+            if ensemble:
+                return ensemble_step(model, model2, imgs)
+            z, _ = model(imgs)
+            return None if args.no_nms else non_max_suppression(z, 0.001, 0.6, multi_label=True)
 
     def single_step():                                          # one model: forward + decode + NMS
         with torch.no_grad():
@@ -344,6 +348,30 @@ def main():
                     'algbw_GBps': round(alg, 1), 'busbw_GBps': round(alg * 2 * (world - 1) / world, 1),
                     'xgmi_peak_GBps_per_gpu': XGMI_LINKS * XGMI_LINK_GBPS, 'backend': backend, 'ranks': dist.get_world_size(),
                     'note': 'bucketed SUM all-reduce of the flat fp32 gradient buffers, not overlapped with anything'}
+
+    # BASELINE's metric is "train+infer": after the timed training region of the DEFAULT shape (one GPU), the configs[4] pipeline - batch 128,
+    # two synthetic models x (forward + NMS) + device WBF - runs 2 warm + 5 timed steps with the trained weights in eval mode, so the one line
+    # the driver records covers both halves.  Inference shards by image with no collective: replicas only, so N = 1 only.
+    configs4 = None
+    if (args.mode == 'train' and world == 1 and not rehearsal and not args.no_infer and args.model != 'yolov5s' and args.size == 640 and nc == 10
+            and args.amp is None):
+        torch.cuda.empty_cache()
+        model.eval()
+        m2 = fill_state(Model(cfg), 2).to(dev).eval()           # the second synthetic "model": same graph, other weights
+        imgs128 = synthetic_images(128, args.size, 2000, dev)
+        for _ in range(2):
+            ensemble_step(model, m2, imgs128)
+        torch.cuda.synchronize()
+        ops.PROFILE = prof4 = []
+        t4 = timed_steps(lambda: ensemble_step(model, m2, imgs128), 5, dist=None, sync=torch.cuda.synchronize, device=dev)
+        ops.PROFILE = None
+        conv4 = sum(e0.elapsed_time(e1) for nm, _, e0, e1, _ in prof4 if not nm.startswith('dcnv3')) * 1e-3
+        configs4 = {'workload': 'BASELINE configs[4]: inference batch 128, 640x640, 2 synthetic models x (forward + decode + NMS(conf 0.001, iou 0.6, '
+                                'multi_label)) + WBF(iou 0.67, skip 0.01) per image; 2 warm + 5 timed steps after the training region',
+                    'images_per_s': round(128 * 5 / t4, 2), 'latency_ms_per_image': round(t4 / 5 * 1e3 / 128, 4), 'ms_per_step': round(t4 / 5 * 1e3, 2),
+                    'conv_frac': round(conv4 / t4, 3), 'steps': 5, 'batch': 128}
+        del m2, imgs128
+        model.train()
 
     if rank == 0:
         # dominant kernel = the conv tile variant with the largest total time; DCNv3 launches carry bytes instead of FLOPs
@@ -415,6 +443,8 @@ def main():
             out['roofline_dcnv3'] = {'bound': 'hbm', 'achieved': round(tb / ts / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                      'frac': round(tb / ts / 1e9 / HBM_PEAK_GBPS, 4), 'share_of_step': round(ts / dt, 4), 'kernels': kernels,
                                      'note': 'algorithmic bytes 4(2C+3GK) forward / 4(4C+6GK) backward per output pixel (SURVEY 8d)'}
+        if configs4:
+            out['configs4'] = configs4
         if exchange:
             out['allreduce'] = exchange
         if world == 1 and not args.no_cpu_baseline:

@@ -82,6 +82,10 @@ def _ddp_worker(rank, world, port, q):
         gb.layer_done(layer)
         order.append(len(gb.launched))
     gb.finish()
+    stats = torch.arange(6, dtype=torch.float32) + 10 * rank  # "BatchNorm running statistics" that drifted apart between the ranks
+    gb.broadcast_buffers(stats)                               # DDP's broadcast_buffers (train.py:208-209): rank 0's overwrite everyone's
+    assert torch.equal(stats, torch.arange(6, dtype=torch.float32)), stats
+    gb.broadcast_buffers(torch.empty(0))                      # a graph without buffers: no collective, no hang
     res = (rank, order, list(gb.launched), g0.clone(), g1.clone())
     secs, nbytes = gb.measure_exchange(iters=2)              # what bench.py reports as `allreduce` at N > 1 (collective)
     assert secs > 0 and nbytes == 1010 * 4 and float(g0.abs().sum()) == 0.0 and gb.launched == []

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Capture-and-isolate: where is the error of a full-size gradient GENERATED?
+
+One whole-graph fp64 oracle pass (forward + loss + backward) records, for every top-level layer, its inputs and the gradient of its
+outputs.  Every layer that owns parameters is then run ALONE on those captured tensors rounded to fp32 - the fp64 oracle block, the fp32
+CPU oracle block and the HIP block see bit-identical inputs, output gradients and weights - and each parameter gradient, the input
+gradient and the output are compared with the fp64 block's: what a block shows here is error it generates itself; what it shows only in
+the whole-graph pass arrived from upstream.  Per parameter the tool prints the isolated relative error of both fp32 paths, the error
+beyond 1e-3 in units of one fp32 rounding of the gradient's own terms (c_req, AbsTermSums) and the whole-graph relative errors beside it.
+
+The CPU oracle is the checker here: a tool, not product code.
+usage: block_isolate.py [--size 1280] [--nc 3] [--batch 2] [--dcn 1] [--seed 6] [--layers 30,36,...] [--out FILE]"""
+import argparse
+import copy
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'yolo-somi_amd')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def capture(model64, run):
+    """Forward hooks on every top-level layer: inputs and output gradients of one pass, kept as fp32 CPU tensors."""
+    cap, handles = {}, []
+
+    def hook(m, inp, out):
+        x = inp[0]
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        rec = cap[m.i] = dict(x=[t.detach().float() for t in xs], multi_in=isinstance(x, (list, tuple)), dy=None)
+        outs = list(out) if isinstance(out, (list, tuple)) else [out]
+        rec['multi_out'] = isinstance(out, (list, tuple))
+        rec['dy'] = [None] * len(outs)
+        for k, o in enumerate(outs):
+            if o.requires_grad:
+                o.register_hook(lambda g, rec=rec, k=k: rec['dy'].__setitem__(k, g.detach().float()))
+    for m in model64.model:
+        handles.append(m.register_forward_hook(hook))
+    run()
+    for h in handles:
+        h.remove()
+    return cap
+
+
+def oracle_alone(blk, rec, dtype, with_sums=False):
+    """The oracle block on the captured tensors in `dtype`: -> (outputs, input gradients, {param: grad}, sums or None)."""
+    from oracle.somi_ref.testing import AbsTermSums
+    for p in blk.parameters():
+        p.grad = None
+    xs = [t.to(dtype).requires_grad_(True) for t in rec['x']]
+    ctx = AbsTermSums(blk) if with_sums else None
+    if ctx:
+        ctx.__enter__()
+    out = blk(xs if rec['multi_in'] else xs[0])
+    outs = list(out) if isinstance(out, (list, tuple)) else [out]
+    keep = [(o, d.to(dtype)) for o, d in zip(outs, rec['dy']) if d is not None]
+    torch.autograd.backward([o for o, _ in keep], [d for _, d in keep])
+    if ctx:
+        ctx.__exit__(None, None, None)
+    grads = {n: p.grad.detach().clone() for n, p in blk.named_parameters() if p.grad is not None}
+    return [o.detach() for o in outs], [x.grad for x in xs], grads, (ctx.sums if ctx else None)
+
+
+def hip_alone(m, rec):
+    """The HIP block on the same tensors: -> (outputs NCHW / raw, input gradients NCHW or None, {param: grad})."""
+    from somi_amd import blocks as B
+    from somi_amd import ops
+    for p in m.parameters():
+        p.grad = None
+    first = m.i == 0
+    if first:
+        acts = [B.Act(ops.image_to_nhwc4(rec['x'][0].cuda().contiguous(), scale=1.0), 0, 3)]
+    else:
+        acts = [B.Act(nhwc(t).cuda()) for t in rec['x']]
+    out = m(acts if rec['multi_in'] else acts[0])
+    det = isinstance(m, (B.DecoupledDetect, B.Detect))
+    if det:
+        outs = [r.detach().cpu() for r in out]
+        dxs = m.backward([d.cuda() for d in rec['dy']])
+    else:
+        outs = [out.t[..., out.coff:out.coff + out.c].permute(0, 3, 1, 2).cpu()]
+        d = B.Act(nhwc(rec['dy'][0]).cuda())
+        if first:
+            dxs = m.backward(d, need_dx=False)
+        else:
+            dxs = m.backward(d)
+    torch.cuda.synchronize()
+    if dxs is None:
+        dxs = []
+    dxs = dxs if isinstance(dxs, (list, tuple)) else [dxs]
+    dxs = [a.t[..., a.coff:a.coff + a.c].permute(0, 3, 1, 2).cpu() for a in dxs]
+    grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    return outs, dxs, grads
+
+
+def rel(a, b):
+    b = b.double()
+    return (a.double() - b).abs().max().item() / (b.abs().max().item() + 1e-300)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--size', type=int, default=1280)
+    ap.add_argument('--nc', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--dcn', type=int, default=1)
+    ap.add_argument('--seed', type=int, default=6)
+    ap.add_argument('--width', type=float, default=1.0)
+    ap.add_argument('--depth', type=float, default=1.0)
+    ap.add_argument('--layers', default='')
+    ap.add_argument('--out', default='')
+    ap.add_argument('--threads', type=int, default=16)
+    ap.add_argument('--no-hip', action='store_true', help='dry run of the oracle side on a box without a GPU')
+    a = ap.parse_args()
+    from oracle.somi_ref import Model as OModel
+    from oracle.somi_ref.loss import ComputeLoss as OLoss
+    from oracle.somi_ref.testing import SOMI_ANCHORS, conditioned_errors, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
+    from somi_amd.loss import ComputeLoss
+    from somi_amd.model import Model
+    torch.set_num_threads(a.threads)
+    fh = open(a.out, 'w') if a.out else None
+
+    def say(*s):
+        line = ' '.join(str(v) for v in s)
+        print(line, flush=True)
+        if fh:
+            fh.write(line + '\n')
+            fh.flush()
+    t0 = time.time()
+    cfg = somi_cfg(a.width, a.depth, nc=a.nc, anchors=SOMI_ANCHORS, dcn=bool(a.dcn))
+    ref = fill_state(OModel(cfg), a.seed)
+    mine = Model(cfg)
+    mine.load_state_dict(ref.state_dict())
+    ref.hyp = mine.hyp = dict(HYP_VISDRONE)
+    ref64 = copy.deepcopy(ref).double()
+    imgs, targets = synthetic_batch(a.batch, a.size, nc=a.nc, seed=14)
+    ref.train(), ref64.train()
+    full_hip = {}
+    if not a.no_hip:                                             # whole-graph passes: HIP, fp64 (captured), fp32 CPU
+        mine = mine.cuda().train()
+        lm, _ = ComputeLoss(mine)(mine(imgs.cuda()), targets.cuda())
+        lm.backward()
+        torch.cuda.synchronize()
+        full_hip = {n: p.grad.detach().cpu() for n, p in mine.named_parameters() if p.grad is not None}
+        say(f'# whole-graph HIP pass done, loss {lm.item():.6f}  [{time.time() - t0:.0f}s]')
+
+    def run64():
+        l64, _ = OLoss(ref64)(ref64(imgs.double() / 255), targets.double())
+        l64.backward()
+        say(f'# whole-graph fp64 pass done, loss {l64.item():.6f}  [{time.time() - t0:.0f}s]')
+    cap = capture(ref64, run64)
+    full64 = {n: p.grad.detach().clone() for n, p in ref64.named_parameters() if p.grad is not None}
+    l32, _ = OLoss(ref)(ref(imgs.float() / 255), targets)
+    l32.backward()
+    full32 = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
+    say(f'# whole-graph fp32 CPU pass done, loss {l32.item():.6f}  [{time.time() - t0:.0f}s]')
+    want = [int(v) for v in a.layers.split(',') if v] or [m.i for m in ref64.model if any(True for _ in m.parameters())]
+    say('# layer type | param | isolated: rel_hip rel_cpu32 c_req_hip c_req_cpu32 cond | whole graph: rel_hip rel_cpu32')
+    for i in want:
+        rec = cap[i]
+        if any(d is None for d in rec['dy']):
+            say(f'{i:3d} {ref64.model[i].type}: no output gradient captured, skipped')
+            continue
+        o64, dx64, g64, sums = oracle_alone(ref64.model[i], rec, torch.float64, with_sums=True)
+        o32, dx32, g32, _ = oracle_alone(ref.model[i], rec, torch.float32)
+        oh, dxh, gh = (o32, dx32, g32) if a.no_hip else hip_alone(mine.model[i], rec)
+        typ = ref64.model[i].type
+        e_out = (max(rel(x, y) for x, y in zip(oh, o64)), max(rel(x, y) for x, y in zip(o32, o64)))
+        pairs = [(h, c, w) for h, c, w in zip(dxh, dx32, dx64) if w is not None] if dxh else []
+        e_dx = (max((rel(h, w) for h, c, w in pairs), default=0.0), max((rel(c, w) for h, c, w in pairs), default=0.0))
+        say(f'{i:3d} {typ:<15} OUTPUT rel_hip {e_out[0]:.2e} rel_cpu32 {e_out[1]:.2e} | DX rel_hip {e_dx[0]:.2e} rel_cpu32 {e_dx[1]:.2e}  [{time.time() - t0:.0f}s]')
+        ch = {t[0]: t for t in conditioned_errors(list(gh.items()), g64, sums)}
+        cc = {t[0]: t for t in conditioned_errors(list(g32.items()), g64, sums)}
+        for n in g64:
+            full = f'model.{i}.{n}'
+            rh = rel(gh[n], g64[n]) if n in gh else float('nan')
+            rc = rel(g32[n], g64[n])
+            crh = ch[n][1] if n in ch else float('nan')
+            crc = cc[n][1] if n in cc else float('nan')
+            cond = ch[n][3] if n in ch else float('nan')
+            fhp = rel(full_hip[full], full64[full]) if full in full_hip else float('nan')
+            fcp = rel(full32[full], full64[full])
+            flag = ' <<<' if (rh > 1e-3 and crh > 16) else ''
+            say(f'{i:3d} {typ:<15} {n:<46} {rh:9.2e} {rc:9.2e} {crh:9.1f} {crc:9.1f} {cond:8.1e} | {fhp:9.2e} {fcp:9.2e}{flag}')
+        del o64, dx64, g64, o32, dx32, g32, oh, dxh, gh
+        torch.cuda.empty_cache()
+    say(f'# done [{time.time() - t0:.0f}s]')
+
+
+if __name__ == '__main__':
+    main()

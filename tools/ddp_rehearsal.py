@@ -135,6 +135,21 @@ def main():
         dist.broadcast(ref, src=0)
         assert torch.equal(buf, ref), f'rank {rank}: weights diverged from rank 0'
     assert torch.isfinite(loss).all()
+    # 5. broadcast_buffers (DDP's default, train.py:208-209): step 3 ran on different shards, so the ranks' BatchNorm running statistics have
+    #    drifted apart; the next step must start every rank from rank 0's.  Same batch on every rank -> same weights, same data, same starting
+    #    statistics -> bit-identical statistics afterwards (without the broadcast they would keep their offset).
+    before = tr.optimizer.flat_buffers.detach().clone()
+    ref = before.clone()
+    dist.broadcast(ref, src=0)
+    drift = torch.tensor([0.0 if torch.equal(before, ref) else 1.0])
+    dist.all_reduce(drift)
+    assert drift.item() >= 1.0, 'the ranks were expected to hold different running statistics before the broadcast (the check would be vacuous)'
+    tr.step(*shards[0])
+    torch.cuda.synchronize()
+    after_b = tr.optimizer.flat_buffers.detach().clone()
+    ref = after_b.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(after_b, ref), f'rank {rank}: running statistics differ from rank 0 after a broadcast_buffers step'
     dist.barrier()
     if rank == 0:
         print(f'ddp rehearsal ok: world {world}, {nb} buckets, gradient error {w1:.2f} / accumulate-2 {w2:.2f} x tolerance, '

@@ -34,7 +34,7 @@ for it in range(steps):
         assert torch.isfinite(loss).all(), log[-1]
         if dcn:
             from somi_amd import ops as _ops
-            max_far = max(max_far, _ops.dcn_overflow_taps() or 0)
+            max_far = max(max_far, _ops.dcn_overflow_taps() or 0)               # the last site's call alone (the total below covers every call)
 torch.cuda.synchronize()
 finite = all(bool(torch.isfinite(b).all()) for b in tr.optimizer.flat_params)
 out = {'steps': steps, 'seconds': round(time.time() - t0, 1), 'weights_finite': finite, 'log': log}
@@ -43,4 +43,5 @@ if dcn:
     out['dcn_graph'] = True
     out['far_taps_last_backward'] = ops.dcn_overflow_taps()      # taps that went through fp32 atomics (beyond the window AND the near pass): 0 <=> bit-reproducible
     out['far_taps_max_over_run'] = max_far
+    out['far_taps_total_all_sites_all_steps'] = ops.dcn_overflow_taps(total=True)   # device counter summed over every windowed backward of the run
 print(json.dumps(out))

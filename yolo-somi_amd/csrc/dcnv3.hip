@@ -40,9 +40,9 @@
 //        read-modify-write on pixels it alone owns.  No float atomics: grad_input is run-to-run bit-identical.
 //     Only taps even farther out (the reference test's offsets of +-20 pixels; stride != 1) go to grad_input as fp32 atomics like the
 //     reference's own; they are counted in the workspace's overflow word (0 <=> the launch was bit-reproducible).
-//     B / C / D run over the batch in chunks of images whose staging slab stays below ~128 MB (SOMI_DCN_SLAB_MB): the slab is rewritten
-//     chunk after chunk while it is still resident in the 256 MB Infinity Cache, so most of its write + read traffic never reaches HBM
-//     (round 2 staged the whole batch: 2.95 GB at N32 160x160, 8.9 GB of HBM traffic for 3.0 GB of algorithmic bytes).
+//     B / C / D run over the batch in chunks of images through ONE staging slab capped at SOMI_DCN_SLAB_MB (default 1024 MB: a memory
+//     bound, not a cache trick - slabs of 32 / 128 / 512 MB that would stay in the 256 MB Infinity Cache were measured in round 3 and
+//     gain nothing, B is bound by its LDS build phase and C by its scattered reads; round 2 staged the whole batch, 2.95 GB at N32 160x160).
 //   direct (no workspace, other group widths): one kernel, fp32 atomics into grad_input exactly as the reference does.
 #include "common.h"
 
@@ -1228,20 +1228,37 @@ static size_t win_plan(const DcnArgs &a, GinGeo &q) {
 }
 
 // backward B/C/D; false when it does not apply (group width, LDS budget).  `chunk`: images per pass of B / C / D - the staging slab
-// holds one chunk and is reused by the next, sized to stay resident in the Infinity Cache between B's stores and C's loads.
-static bool gin_plan(const DcnArgs &a, GinGeo &q, size_t &lds, size_t &workspace_bytes, int &chunk, size_t &slab_bytes) {
+// holds one chunk and is reused by the next; it is capped at SOMI_DCN_SLAB_MB (default 1024) purely as a memory bound: running the chunks
+// through a slab small enough to stay in the 256 MB Infinity Cache was measured and gains nothing.
+// Workspace layout: slab | near masks (one word per (image of the chunk, group, tile)) | near_any (one word per chunk) | 256 B whose
+// first word is the far-tap counter - every region a multiple of 256 B, all of it sized HERE, before anything is launched.
+struct GinPlan {
+    size_t lds, slab_bytes, near_bytes, any_bytes, workspace_bytes;
+    int chunk, nchunks;
+};
+static bool gin_plan(const DcnArgs &a, GinGeo &q, GinPlan &pl) {
     if (!win_geo(a, q)) return false;
-    lds = (size_t)GIN_TP * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(RecG) + 4 * sizeof(float) + 4) + GIN_OVF_CAP * sizeof(OvfG) +
-          3 * ((size_t)q.WH * q.WW + 1) * sizeof(int);
-    if (lds > 150 * 1024 || (long)q.tiles_h * q.tiles_w > 65535L * 32) return false;
+    pl.lds = (size_t)GIN_TP * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(RecG) + 4 * sizeof(float) + 4) + GIN_OVF_CAP * sizeof(OvfG) +
+             3 * ((size_t)q.WH * q.WW + 1) * sizeof(int);
+    if (pl.lds > 150 * 1024 || (long)q.tiles_h * q.tiles_w > 65535L * 32) return false;
     static const long cap_mb = [] { const char *e = getenv("SOMI_DCN_SLAB_MB"); const long v = e ? atol(e) : 1024; return v < 1 ? 1 : v; }();
     const size_t per_img = (size_t)a.G * q.tiles_h * q.tiles_w * q.WH * q.WW * a.Gc * sizeof(float);
     long c = (long)(((size_t)cap_mb << 20) / per_img);
-    chunk = c < 1 ? 1 : (c > a.N ? a.N : (int)c);
-    slab_bytes = ((size_t)chunk * per_img + 255) / 256 * 256;
-    const size_t near_bytes = ((size_t)chunk * a.G * q.tiles_h * q.tiles_w * sizeof(unsigned) + 255) / 256 * 256;
-    workspace_bytes = slab_bytes + near_bytes + 256;                       // slab | near masks | the overflow counter
+    pl.chunk = c < 1 ? 1 : (c > a.N ? a.N : (int)c);
+    pl.nchunks = (a.N + pl.chunk - 1) / pl.chunk;
+    pl.slab_bytes = ((size_t)pl.chunk * per_img + 255) / 256 * 256;
+    pl.near_bytes = ((size_t)pl.chunk * a.G * q.tiles_h * q.tiles_w * sizeof(unsigned) + 255) / 256 * 256;
+    pl.any_bytes = ((size_t)pl.nchunks * sizeof(unsigned) + 255) / 256 * 256;
+    pl.workspace_bytes = pl.slab_bytes + pl.near_bytes + pl.any_bytes + 256;
     return true;
+}
+
+// the list-form B kernel: more than 64 KB of dynamic LDS needs the attribute, whatever the group width
+template <int GC>
+static void launch_gin(const dim3 &grid, size_t glds, hipStream_t s, const DcnArgs &c, const GinGeo &q) {
+    if (glds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+    hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<GC>), grid, dim3(256), glds, s, c, q);
 }
 
 static int fill_args(DcnArgs &a, int N, int H, int W, int G, int Gc, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
@@ -1322,9 +1339,8 @@ extern "C" size_t somi_dcnv3_backward_workspace_bytes(int N, int H, int W, int G
                   sizeof(Rec) + 3 * sizeof(float)))
         return 0;
     GinGeo q{};
-    size_t lds = 0, bytes = 0, slab = 0;
-    int chunk = 0;
-    return gin_plan(a, q, lds, bytes, chunk, slab) ? bytes : 0;
+    GinPlan pl{};
+    return gin_plan(a, q, pl) ? pl.workspace_bytes : 0;
 }
 
 extern "C" int somi_dcnv3_backward_strided_f32(const float *input, const float *offset, const float *mask, long offset_stride, long mask_stride,
@@ -1346,11 +1362,12 @@ extern "C" int somi_dcnv3_backward_strided_f32(const float *input, const float *
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)a.TP * G * a.K * (sizeof(Rec) + 3 * sizeof(float));
     GinGeo q{};
-    size_t glds = 0, gbytes = 0, slab = 0;
-    int chunk = 0;
-    const bool windowed = workspace && gin_plan(a, q, glds, gbytes, chunk, slab) && workspace_bytes >= gbytes && aligned16(workspace) &&
+    GinPlan pl{};
+    const bool windowed = workspace && gin_plan(a, q, pl) && workspace_bytes >= pl.workspace_bytes && aligned16(workspace) &&
                           aligned16(grad_input) && aligned16(grad_output);
     if (windowed) {
+        const size_t glds = pl.lds, slab = pl.slab_bytes;
+        const int chunk = pl.chunk;
         // A: grad_offset / grad_mask (float4 gathers, no atomics), the whole batch
         GinGeo qa{};
         const size_t wlds = aligned16(input) ? win_plan(a, qa) : 0;
@@ -1359,11 +1376,12 @@ extern "C" int somi_dcnv3_backward_strided_f32(const float *input, const float *
         // B: grad_input windows, C: combine, D: the near taps - chunk of images after chunk through one staging slab
         char *wsb = static_cast<char *>(workspace);
         q.staging = reinterpret_cast<float *>(wsb);
-        q.overflow = reinterpret_cast<unsigned *>(wsb + gbytes - 256);
+        unsigned *const any_words = reinterpret_cast<unsigned *>(wsb + slab + pl.near_bytes);          // one near_any word per chunk
+        q.overflow = reinterpret_cast<unsigned *>(wsb + pl.workspace_bytes - 256);
         // the near pass needs stride 1 (source tile t then sits over destination tile t + const) and 8-aligned tiles of the INPUT image
         static const bool near_on = [] { const char *e = getenv("SOMI_DCN_NEAR"); return !(e && e[0] == '0'); }();
         q.near = (near_on && stride_h == 1 && stride_w == 1) ? reinterpret_cast<unsigned *>(wsb + slab) : nullptr;
-        (void)hipMemsetAsync(q.overflow, 0, 256, s);                  // the far-tap counter and the per-chunk near_any words behind it
+        (void)hipMemsetAsync(any_words, 0, pl.any_bytes + 256, s);    // the per-chunk near_any words and the far-tap counter behind them
         // B on the matrix cores for 32-wide groups when its LDS image fits (SOMI_DCN_GIN=exact keeps the list sums for comparisons)
         const char *gsel = getenv("SOMI_DCN_GIN");
         const size_t ncell_ = (size_t)q.WH * q.WW, recb = (size_t)GIN_TP * a.K * sizeof(RecM), gotb = (size_t)Gc * GMM_LD * sizeof(float);
@@ -1388,23 +1406,15 @@ extern "C" int somi_dcnv3_backward_strided_f32(const float *input, const float *
             const dim3 grid(q.tiles_h * q.tiles_w, c.N, G);
             long ditems = (long)((H + 7) / 8) * ((W + 7) / 8) * c.N * G;
             const dim3 dgrid((unsigned)(ditems > 4096 ? 4096 : ditems));   // persistent: exits at once unless a tile of the chunk flagged near taps
-            SOMI_REQUIRE(n0 / chunk < 60, SOMI_EINVAL, "dcnv3 backward: more than 60 chunks of images (raise SOMI_DCN_SLAB_MB)");
-            q.near_any = q.overflow + 1 + n0 / chunk;
+            q.near_any = any_words + n0 / chunk;
             long blocks = ((long)c.N * H * W * (a.C / 4) + 255) / 256;
             const dim3 cgrid((unsigned)(blocks > 16384 ? 16384 : blocks));
             // D follows C (it adds to pixels C has just combined); the list-form macro launches B only, C and D come below
             if (mfma) SOMI_GMM_LAUNCH(32);
-            else if (Gc == 8) hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<8>), grid, dim3(256), glds, s, c, q);
-            else if (Gc == 16) hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<16>), grid, dim3(256), glds, s, c, q);
-            else if (Gc == 32) {
-                if (glds > 64 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
-                hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<32>), grid, dim3(256), glds, s, c, q);
-            } else {
-                if (glds > 64 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
-                hipLaunchKernelGGL((dcnv3_bwd_gin_kernel<64>), grid, dim3(256), glds, s, c, q);
-            }
+            else if (Gc == 8) launch_gin<8>(grid, glds, s, c, q);
+            else if (Gc == 16) launch_gin<16>(grid, glds, s, c, q);
+            else if (Gc == 32) launch_gin<32>(grid, glds, s, c, q);
+            else launch_gin<64>(grid, glds, s, c, q);
             hipLaunchKernelGGL(dcnv3_bwd_combine_kernel, cgrid, dim3(256), 0, s, c, q);
             if (q.near) {
                 switch (Gc) {

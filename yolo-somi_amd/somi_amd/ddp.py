@@ -101,6 +101,22 @@ class GradBuckets:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.handles = []
 
+    def broadcast_buffers(self, buf, src=0):
+        """DDP's `broadcast_buffers` (train.py:208-209 wraps the model with the default broadcast_buffers=True): before every forward the
+        module buffers - here ONE flat tensor holding every BatchNorm running mean / variance - are overwritten with rank `src`'s, so the
+        running statistics every rank updates in that forward start from the same values and rank != 0 evaluates with rank 0's statistics.
+        One collective on the side stream; the compute stream waits for it (the forward reads and updates the buffers)."""
+        if self.dist is None or buf.numel() == 0 or (self.dist.get_world_size() == 1 and not SINGLE_RANK_REHEARSAL):
+            return
+        if self.use_streams:
+            ev = torch.cuda.Event()
+            ev.record()                                           # the previous step's updates of the buffers are complete on the compute stream
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.dist.broadcast(buf, src=src, async_op=True).wait()
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            self.dist.broadcast(buf, src=src)
 
     def overlap_stats(self):
         """After a step run with `timing = True` (and a device synchronise): (overlap_frac, exchange_ms, buckets) - the share of the

@@ -130,19 +130,45 @@ def dcnv3_forward_raw(input, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group
 
 
 DCN_LAST_WORKSPACE = None
-_DCN_WS = {}                                                     # device -> the windowed backward's workspace (grow-only; ~130 MB: the capped staging slab)
+_DCN_WS = {}                                                     # device -> the windowed backward's workspace (grow-only: the staging slab, <= SOMI_DCN_SLAB_MB = 1 GiB by default, + near masks)
+_DCN_FAR = {}                                                    # device -> int64 device counter: far taps of EVERY windowed backward since the last reset
 
 
-def dcn_overflow_taps():
-    """FAR sampling taps of the last windowed DCNv3 backward - those that went to grad_input as fp32 atomics because they landed more than
-    two tiles from their own (0 <=> that backward was bit-reproducible).  Host sync; diagnostics / tests."""
+def dcn_overflow_taps(total=False):
+    """FAR sampling taps of the windowed DCNv3 backward - those that went to grad_input as fp32 atomics because they landed more than
+    two tiles from their own (0 <=> bit-reproducible).  Default: the last call only.  total=True: summed over every call on every device
+    since reset_dcn_overflow_taps() - a graph has several DCNv3 sites sharing one workspace whose counter word each call zeroes again, so
+    "no float atomic ran in this step" is a statement about the total.  Host sync; diagnostics / tests."""
+    if total:
+        return int(sum(int(t.item()) for t in _DCN_FAR.values()))
     ws = DCN_LAST_WORKSPACE
     return None if ws is None else int(ws[-256:-252].view(torch.int32).item())
 
 
+def reset_dcn_overflow_taps():
+    for t in _DCN_FAR.values():
+        t.zero_()
+
+
+def _dcn_count_far(ws):
+    """Adds the call's far-tap word to the device's running total (one tiny stream-ordered add, no sync)."""
+    tot = _DCN_FAR.get(ws.device)
+    if tot is None:
+        tot = _DCN_FAR[ws.device] = torch.zeros(1, dtype=torch.int64, device=ws.device)
+    tot.add_(ws[-256:-252].view(torch.int32))
+
+
+def free_workspaces():
+    """Releases the per-device DCNv3 backward workspace (up to SOMI_DCN_SLAB_MB + near masks; it is otherwise kept for the life of the
+    process and only grows).  The next windowed backward allocates it again."""
+    global DCN_LAST_WORKSPACE
+    DCN_LAST_WORKSPACE = None
+    _DCN_WS.clear()
+
+
 def _dcn_workspace(nbytes, dev):
-    """The staging slab of the windowed backward is capped by the library (SOMI_DCN_SLAB_MB, 128 MB by default) and reused chunk after
-    chunk, so one buffer per device serves every call (round 2 allocated up to 2.95 GB per call and kept it alive in a global)."""
+    """One buffer per device serves every windowed backward: the library caps the staging slab (SOMI_DCN_SLAB_MB, 1024 by default - a memory
+    bound, see dcnv3.hip) and walks the batch through it in chunks of images (round 2 allocated up to 2.95 GB per call and kept it in a global)."""
     ws = _DCN_WS.get(dev)
     if ws is None or ws.numel() < nbytes:
         ws = _DCN_WS[dev] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -182,6 +208,8 @@ def dcnv3_backward_raw(input, offset, mask, grad_output, kh, kw, sh, sw, ph, pw,
         C_ = group * group_channels
         Ho, Wo = grad_output.shape[1], grad_output.shape[2]
         PROFILE.append(('dcnv3_bwd_kernel', 4.0 * N * Ho * Wo * (4 * C_ + 6 * group * kh * kw), e0, e1, (N, H, W, C_, group, kh, sh, 11)))
+    if ws is not None:
+        _dcn_count_far(ws)
     return gi, go, gm
 
 
@@ -232,6 +260,8 @@ def dcnv3_backward_merged(input, om, grad_output, kh, kw, sh, sw, ph, pw, dh, dw
         C_ = group * group_channels
         Ho, Wo = grad_output.shape[1], grad_output.shape[2]
         PROFILE.append(('dcnv3_bwd_kernel', 4.0 * N * Ho * Wo * (4 * C_ + 6 * GK), e0, e1, (N, H, W, C_, group, kh, sh, 11)))
+    if ws is not None:
+        _dcn_count_far(ws)
     return gi, d_om
 
 

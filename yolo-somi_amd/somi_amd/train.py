@@ -62,7 +62,8 @@ def scheduler_step(optimizer, epoch, lf):
 
 
 class TrainStep:
-    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True, sync_bn=False, amp=None, multi_scale=False, imgsz=640):
+    def __init__(self, model, hyp, batch_size, dist=None, nbs=64, bucket_mb=48, accumulate=1, adam=True, sync_bn=False, amp=None, multi_scale=False, imgsz=640,
+                 broadcast_buffers=True):
         """accumulate: optimizer step every `accumulate` batches (train.py:121,252,272: max(round(nbs / total_batch), 1) in the
         reference loop; gradients simply keep accumulating in the flat buffers in between).  Default 1: every batch.
         sync_bn: --sync-bn (train.py:165-167, SyncBatchNorm.convert_sync_batchnorm): every BatchNorm layer takes its training
@@ -72,7 +73,10 @@ class TrainStep:
         through the bf16 matrix instructions with fp32 accumulation (ops.CONV_PREC).  Tensors, BatchNorm statistics, the loss, the
         optimizer and the EMA stay fp32, so no GradScaler is needed (bf16 has fp32's exponent range).
         multi_scale: `--multi-scale` (train.py:257-262): every batch is resized (bilinear, align_corners=False) to a random size in
-        [0.5, 1.5] imgsz on the stride grid before the forward pass (Python's `random`, as the reference draws it)."""
+        [0.5, 1.5] imgsz on the stride grid before the forward pass (Python's `random`, as the reference draws it).
+        broadcast_buffers: N > 1 only - DDP's default (train.py:208-209): rank 0's BatchNorm running statistics overwrite every rank's before
+        each forward (one flat-buffer broadcast on the side stream, ddp.GradBuckets.broadcast_buffers).  False: the statistics are made equal
+        once at construction and then follow each rank's own shard (rank 0's are the ones EMA / checkpoints use either way)."""
         if not next(model.parameters()).is_cuda:
             raise RuntimeError('TrainStep runs on the MI355X only (no CPU fallback)')
         self.model, self.dist = model, dist
@@ -91,6 +95,7 @@ class TrainStep:
         self.optimizer = build_optimizer(model, hyp, batch_size * self.world, nbs=nbs, ema=True, adam=adam)
         self.compute_loss = ComputeLoss(model)
         self.accumulate, self._since_step = max(int(accumulate), 1), 0
+        self.broadcast_buffers = bool(broadcast_buffers)
         self.buckets = None
         if self.world > 1 or (dist is not None and SINGLE_RANK_REHEARSAL):
             self.buckets = GradBuckets(self.optimizer.flat_grads, layer_offsets(model, self.optimizer), dist=dist,
@@ -98,9 +103,8 @@ class TrainStep:
             model.__dict__['_grad_hook'] = self.buckets.layer_done
             for buf in self.optimizer.flat_params:                # one set of initial weights (DDP broadcasts from rank 0)
                 dist.broadcast(buf, src=0)
-            # ... and of initial buffers (BatchNorm running statistics): DDP's broadcast_buffers (train.py:208) keeps them equal to
-            # rank 0's before every forward; here they are made equal once and then stay rank-local (batch statistics of the
-            # rank's own shard) - rank 0's are the ones the EMA / checkpoints / validation use, as in the reference
+            # ... and of initial buffers (BatchNorm running statistics); step() repeats this before every forward when
+            # broadcast_buffers is on (DDP's default, train.py:208) - rank 0's are the ones the EMA / checkpoints / validation use
             if self.optimizer.flat_buffers.numel():
                 dist.broadcast(self.optimizer.flat_buffers, src=0)
             self.optimizer.reset_ema()
@@ -113,6 +117,8 @@ class TrainStep:
         if self.buckets:
             self.buckets.reset()
             self.buckets.enabled = stepping                       # local accumulation only on the others (DDP's no_sync)
+            if self.broadcast_buffers:
+                self.buckets.broadcast_buffers(self.optimizer.flat_buffers)
         from . import ops
         ops.SYNC_BN, ops.SYNC_BN_GROUP = self.sync_bn, self.sync_bn_group
         ops.CONV_PREC = self.amp
