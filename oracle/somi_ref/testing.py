@@ -179,16 +179,20 @@ class AbsTermSums:
     biases of ODConv2d_3rd, the BiFPN fusion weights.  A parameter of any other kind is simply absent from `sums`.
     """
 
-    def __init__(self, model):
+    def __init__(self, model, sums=True, squares=True):
+        """sums / squares: which of S = sum |terms| and sum terms^2 to measure (each costs one extra weight-gradient convolution per conv
+        layer in fp64: a caller that needs only `sums` (conditioned_errors, fp64_anchored_errors) or only `rss` (noise_scaled_errors) says so)."""
         self.model, self.sums, self.sq, self._handles = model, {}, {}, []
+        self.want_s, self.want_q = bool(sums), bool(squares)
         self._names = {id(p): n for n, p in model.named_parameters()}
 
     def _add(self, p, s, q2=None):
         """s: sum |terms|; q2: sum terms^2 (optional) - both shaped like the parameter (or reshapeable to it)."""
         n = self._names.get(id(p))
         if n is not None:
-            s = s.detach().reshape(p.shape)
-            self.sums[n] = self.sums[n] + s if n in self.sums else s
+            if s is not None:
+                s = s.detach().reshape(p.shape)
+                self.sums[n] = self.sums[n] + s if n in self.sums else s
             if q2 is not None:
                 q2 = q2.detach().reshape(p.shape)
                 self.sq[n] = self.sq[n] + q2 if n in self.sq else q2
@@ -213,8 +217,9 @@ class AbsTermSums:
 
         def conv(m, inp, dy):
             x = inp[0]
-            self._add(m.weight, torch.nn.grad.conv2d_weight(x.abs(), m.weight.shape, dy.abs(), m.stride, m.padding, m.dilation, m.groups),
-                      torch.nn.grad.conv2d_weight(x * x, m.weight.shape, dy * dy, m.stride, m.padding, m.dilation, m.groups))
+            self._add(m.weight,
+                      torch.nn.grad.conv2d_weight(x.abs(), m.weight.shape, dy.abs(), m.stride, m.padding, m.dilation, m.groups) if self.want_s else None,
+                      torch.nn.grad.conv2d_weight(x * x, m.weight.shape, dy * dy, m.stride, m.padding, m.dilation, m.groups) if self.want_q else None)
             if m.bias is not None:
                 self._add(m.bias, dy.abs().sum((0, 2, 3)), (dy * dy).sum((0, 2, 3)))
 
@@ -265,10 +270,10 @@ class AbsTermSums:
                 s, s2 = torch.zeros_like(m.weight), torch.zeros_like(m.weight)
                 for b in range(B):
                     xb, db = x[b:b + 1], dy[b:b + 1]
-                    sb = torch.nn.grad.conv2d_weight(xb.abs(), per, db.abs(), m.stride, m.padding, m.dilation, m.groups)
-                    qb = torch.nn.grad.conv2d_weight(xb * xb, per, db * db, m.stride, m.padding, m.dilation, m.groups)
-                    s += attn[b].abs() * sb[None]
-                    s2 += attn[b] ** 2 * qb[None]
+                    if self.want_s:
+                        s += attn[b].abs() * torch.nn.grad.conv2d_weight(xb.abs(), per, db.abs(), m.stride, m.padding, m.dilation, m.groups)[None]
+                    if self.want_q:
+                        s2 += attn[b] ** 2 * torch.nn.grad.conv2d_weight(xb * xb, per, db * db, m.stride, m.padding, m.dilation, m.groups)[None]
                 self._add(m.weight, s, s2)
                 if m.bias is not None:
                     w = a_w.abs() if a_w is not None else torch.ones(B, m.K, dtype=dy.dtype)
@@ -341,4 +346,30 @@ def noise_scaled_errors(named_grads, named_ref64, rss, against=None):
         other = g64 if against is None else against[n].detach().cpu()
         d = (g.detach().cpu().double() - other.double()).abs().max().item()
         out.append((n, d / ((g64.double().abs() + q.double()).max().item() + 1e-300), d / (g64.abs().max().item() + 1e-300)))
+    return out
+
+
+def fp64_anchored_errors(named_grads, named_cpu32, named_ref64, sums, rel=1e-3, k_cpu=2.0, c0=16.0, eps=2.0 ** -24):
+    """The gradient bar every training-parity test shares, anchored on the fp64 oracle (test infrastructure).
+
+    For every parameter with an fp64 reference gradient g64, an fp32 CPU oracle gradient and a measured S = sum |terms| (AbsTermSums):
+        (name, ratio, e, e_cpu, scale)       scale = max |g64|,  e = max |g - g64|,  e_cpu = max |g_cpu32 - g64|,
+        ratio = max over elements of  |g - g64|_el / ( max(rel * scale, k_cpu * e_cpu) + c0 * eps * S_el )
+    ratio <= 1 passes: BASELINE's flat `rel` (1e-3) of the gradient's scale; where the fp32 CPU restatement of the SAME computation is itself
+    farther than that from fp64 (deep chaotic graphs, the floor() discontinuity of DCNv3's offset gradient) `k_cpu` times the CPU path's own
+    distance - a quantity that does not depend on the implementation under test (k_cpu = 0: the flat bar alone); plus a FIXED `c0` fp32
+    roundings of the gradient's own terms, which only matters for sums of cancelling terms (S >> |g|: biases in front of a normalisation,
+    the 7x7 attention conv) where no relative bar means anything.  named_cpu32 may be None with k_cpu = 0."""
+    cpu = dict(named_cpu32) if named_cpu32 is not None else {}
+    out = []
+    for n, g in named_grads:
+        g64, s = named_ref64.get(n), sums.get(n)
+        if g64 is None or s is None:
+            continue
+        g64 = g64.double()
+        d = (g.detach().cpu().double() - g64).abs()
+        scale = g64.abs().max().item()
+        e_cpu = (cpu[n].detach().double() - g64).abs().max().item() if n in cpu else 0.0
+        allow = max(rel * scale, k_cpu * e_cpu) + c0 * eps * s.double() + 1e-300
+        out.append((n, (d / allow).max().item(), d.max().item(), e_cpu, scale))
     return out

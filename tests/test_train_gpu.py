@@ -172,7 +172,7 @@ def _run_block_train(mine, ref, x, seed, what, cin):
     _grads_close(mine, ref, what)
 
 
-@pytest.mark.parametrize('c1,c2,n,shortcut', [(32, 32, 2, True), (48, 32, 1, False)])
+@pytest.mark.parametrize('c1,c2,n,shortcut', [(32, 32, 2, True), (48, 32, 1, False), (32, 32, 3, False), (64, 32, 3, True)])
 def test_c2fcbam_train_forward_backward(c1, c2, n, shortcut):
     from oracle.somi_ref import blocks as OB
     from oracle.somi_ref.testing import fill_state
@@ -264,167 +264,89 @@ def _train_cfg(odconv):
     return cfg
 
 
-def _perturbed_twin(cfg, state, run, n_twins=3):
-    """The HIP path again with every weight moved by at most one fp32 rounding (x (1 +- 2^-23), random signs), `n_twins` times with different
-    signs: `run(model)` must do forward + loss + backward.  -> [{name: gradient}, ...].  How far these gradients are from the unperturbed
-    run's is the parameter's measured condition with respect to rounding-sized input changes - what no arithmetic, fp32 or other, can
-    undercut.  One twin is ONE draw of a heavy-tailed response (the same code with a different summation order in one conv tile moved the
-    median twin distance at 1280x1280 from 3.6e-2 to 1.6e-2), so the check takes the largest of several per parameter."""
-    from somi_amd.model import Model
-    out = []
-    for t in range(n_twins):
-        twin = Model(cfg)
-        twin.load_state_dict(state)
-        g = torch.Generator().manual_seed(99 + t)
-        with torch.no_grad():
-            for p in twin.parameters():
-                p.mul_(1.0 + (torch.randint(0, 2, p.shape, generator=g).to(p.dtype) * 2 - 1) * 2.0 ** -23)
-        twin = twin.cuda().train()
-        run(twin)
-        out.append({n: p.grad.detach().cpu() for n, p in twin.named_parameters() if p.grad is not None})
-        del twin
-        torch.cuda.empty_cache()
-    return out
+def _anchored_check(named_hip, named_cpu32, g64, sums, what, k_cpu=2.0):
+    """Every parameter gradient against the fp64 oracle under the shared bar (oracle.somi_ref.testing.fp64_anchored_errors): BASELINE's flat 1e-3
+    of the gradient's scale - or, where the fp32 CPU oracle itself is farther than that from fp64, k_cpu x the CPU path's own distance - plus a
+    FIXED 16 fp32 roundings of the gradient's own terms (matters for cancelling sums only).  Nothing in the bar depends on the HIP path."""
+    from oracle.somi_ref.testing import fp64_anchored_errors
+    named_hip = list(named_hip)
+    res = fp64_anchored_errors(named_hip, named_cpu32, g64, sums, k_cpu=k_cpu)
+    missing = set(g64) - {t[0] for t in res}
+    assert not missing and len(named_hip) == len(g64), f'{what}: parameters without a gradient / a measured term scale: {sorted(missing)[:6]}'
+    bad = [(n, f'x{r:.1f}', f'hip {e:.2e}', f'cpu32 {ec:.2e}', f'scale {sc:.2e}') for n, r, e, ec, sc in res if not r <= 1.0]
+    worst = max(res, key=lambda t: t[1])
+    print(f'{what}: {len(res)} parameters, worst {worst[0]} at {worst[1]:.2f} of the bar (hip {worst[2]:.2e}, fp32 cpu {worst[3]:.2e}, scale {worst[4]:.2e})')
+    assert not bad, f'{what}: {len(bad)} parameter gradients beyond max(1e-3 scale, {k_cpu} x fp32 CPU error) + 16 roundings of their terms: {bad[:8]}'
 
 
-def _conditioned_gradient_check(mine, ref32, ref64, cond, what, twin_grads, k_pop=4.0, k_each=12.0):
-    """The full-size gradient bar: conditioning-aware, calibrated on the fp32 CPU path, no name patterns.
-
-    A parameter gradient is a sum of terms, g = sum_t a_t b_t.  The fp64 oracle pass measures, per gradient element, Q = sqrt(sum_t (a_t b_t)^2)
-    (oracle.somi_ref.testing.AbsTermSums): the scale of what independent relative perturbations u of the terms - the accumulated fp32
-    rounding of every layer upstream, amplified by the depth of the graph - do to the sum (about u * Q; correlated ones up to u * |g|).
-    So an error is judged as   r(p) = max |g - g64| / max (|g64| + Q)   - directly comparable to u across well-conditioned parameters
-    (Q <= |g|) and sums of cancelling terms (the 7x7 spatial-attention convs: Q = 10 ... 40 |g| at 320x320, which is why their plain relative
-    error reads 0.3 ... 2 in EITHER fp32 path).  u itself is measured: the fp32 CPU oracle's own r on the same inputs.
-    Q sees the cancellation inside the last sum only.  What the layers UPSTREAM do to a rounding - batch statistics over 2 ... 32 values in the
-    ODConv attention and on the 4x4 maps divide by a spread that can be smaller than sqrt(eps), max-pools and ReLUs switch - is measured
-    by perturbation: the HIP path runs again with every weight moved by one fp32 rounding (_perturbed_twin, three sign patterns), and s(p) = the
-    largest distance of those runs from the unperturbed one in the same units is that parameter's response to a rounding-sized change of its inputs.  (Round 3: changing only
-    the summation order of the BatchNorm partial sums, 128- to 32-pixel chunks, moved the count of parameters beyond 12 u from 14 to 16 in the
-    128x128 case - all 16 inside one ODConv block whose attention norm sees 2 samples - which a fixed count allowance cannot be told from
-    an error.  Measured with one twin: the HIP path is as far from its own one-rounding twin as from fp64 - median s 2.3e-3 / q90 4.7e-3
-    against r 1.3e-3 / 3.7e-3 at 128x128, 3.6e-2 / 7.1e-2 against 3.5e-2 / 6.8e-2 at 1280x1280.  s(p) from ONE twin is a single draw: after an
-    unrelated change of one conv tile's summation order the same test drew a median of 1.6e-2 and one of 734 parameters stood at 7.8 x its own
-    draw - so s(p) is the largest of three twins and the per-parameter factor is 12, not the 6 a single lucky pair of runs suggested.)
-    The bar:
-      * population: median of r(HIP) within k_pop x the fp32 CPU path's, 90th percentile within k_pop x max(u, the 90th percentile of s),
-      * every parameter: r(HIP) <= k_each x max(u, the CPU path's own r on that parameter, s(p)),
-      * no O(1) error anywhere (r <= 0.5) whatever s says.
-    An indexing / layout mistake moves a well-conditioned gradient by O(|g|): r ~ 0.5, against u ~ 1e-4 ... 2e-2 - caught at any depth; on a
-    cancelling sum it moves it by O(Q) - caught as well.  (Layer-isolated tests hold the same kernels to 1e-3 without upstream noise.)"""
-    from oracle.somi_ref.testing import noise_scaled_errors
-    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
-    for n, p in mine.named_parameters():
-        assert (p.grad is not None) == (n in g64), f'{what}: {n} gradient presence differs from the oracle'
-    rss = cond.rss
-    mine_g = [(n, p.grad) for n, p in mine.named_parameters() if p.grad is not None]
-    hip = noise_scaled_errors(mine_g, g64, rss)
-    cpu = {t[0]: t[1] for t in noise_scaled_errors([(n, p.grad) for n, p in ref32.named_parameters() if p.grad is not None], g64, rss)}
-    own = {}
-    for tw in twin_grads:                                         # per parameter: the largest response over the twins
-        for n, r, _ in noise_scaled_errors(mine_g, g64, rss, against=tw):
-            own[n] = max(own.get(n, 0.0), r)
-    assert len(hip) == len(g64) == len(own), f'{what}: {len(g64) - len(hip)} parameters without a measured term scale'
-    rh, rc = torch.tensor([t[1] for t in hip]), torch.tensor([cpu[t[0]] for t in hip])
-    rs = torch.tensor([own[t[0]] for t in hip])
-    u = max(float(rc.quantile(0.9)), 64 * 2.0 ** -24)             # floor: a few fp32 roundings (isolated, shallow graphs)
-    bar = {n: max(u, cpu[n], own[n]) for n, _, _ in hip}
-    worst = sorted(hip, key=lambda t: -t[1] / bar[t[0]])[:5]
-    print(f'{what}: noise-scaled error r  HIP median {float(rh.median()):.2e} q90 {float(rh.quantile(0.9)):.2e} max {float(rh.max()):.2e} | '
-          f'fp32 CPU median {float(rc.median()):.2e} q90 {float(rc.quantile(0.9)):.2e} max {float(rc.max()):.2e} | HIP vs its one-rounding twin '
-          f'median {float(rs.median()):.2e} q90 {float(rs.quantile(0.9)):.2e} max {float(rs.max()):.2e} | worst vs bar: '
-          + ', '.join(f'{n} x{r / bar[n]:.1f} (s {own[n]:.1e})' for n, r, _ in worst))
-    bad = [(n, f'r {r:.2e}', f'cpu {cpu[n]:.2e}', f'twin {own[n]:.2e}', f'rel {rel:.2e}') for n, r, rel in hip if r > k_each * bar[n]]
-    assert not bad, (f'{what}: {len(bad)} parameters beyond {k_each} x max(u = {u:.2e}, the fp32 CPU path\'s error, the response to one rounding) '
-                     f'(in units of |g| + Q): {bad[:8]}')
-    gross = [(n, f'r {r:.2e}') for n, r, _ in hip if r > 0.5]
-    assert not gross, f'{what}: O(1) gradient errors: {gross[:8]}'
-    assert rh.median() <= k_pop * max(float(rc.median()), 16 * 2.0 ** -24), (float(rh.median()), float(rc.median()))
-    assert rh.quantile(0.9) <= k_pop * max(u, float(rs.quantile(0.9))), (float(rh.quantile(0.9)), u, float(rs.quantile(0.9)))
+def _well_conditioned(model, gamma=0.25):
+    """fill_state's BatchNorm scales are U(0.5, 1.5): with them the 38-layer graph is CHAOTIC - the fp32 CPU oracle's own gradients sit 2e-2 ...
+    5e-2 (median, relative) from its fp64 run at any map size, a rounding is amplified ~10^6 x, and no per-parameter bar below O(1) means
+    anything.  Scaling every BatchNorm gamma by 0.25 (pre-activations of +-0.3: SiLU in its near-linear range, contractive layers) puts the
+    same graph in the regime a trained network lives in: fp32 CPU median 4e-6, 99 % of the parameters below 2e-4 of fp64 (measured, 320x320,
+    batch 4).  Conv weights need no change - BatchNorm divides their scale out."""
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.mul_(gamma)
+    return model
 
 
-def test_cbam_block_backward_isolated_at_320():
-    """Layer-isolated check at the map size where the full-size attention gradients are ill-conditioned: a C2fCBAM block with
-    one 128-channel CBAM bottleneck on 2 x 320 x 320, inputs and the output gradient drawn in fp32 (so fp64 oracle and HIP see the same
-    values - no upstream fp32 noise), against the fp64 oracle.  Everything well-conditioned holds 1e-3 relative; the cancelling sums
-    (the 7x7 spatial-attention conv's bias and weights: 204 800 terms of both signs) are held to a FIXED 16 fp32 roundings of their own
-    terms - an indexing error in spatial_attn_bwd / cbam_bwd at large maps would be ~1e6 of those units."""
-    from oracle.somi_ref import blocks as OB
-    from oracle.somi_ref.testing import AbsTermSums, conditioned_errors, fill_state
-    from somi_amd import blocks as MB
-    torch.set_num_threads(16)
-    g = torch.Generator().manual_seed(5)
-    ref = fill_state(OB.C2fCBAM(256, 256, 1, True), 6)
-    OB.initialize_weights(ref)
-    mine = MB.C2fCBAM(256, 256, 1, True)
-    mine.load_state_dict(ref.state_dict())
-    for m in mine.modules():
-        if isinstance(m, nn.BatchNorm2d):
-            m.eps, m.momentum = 1e-3, 0.03
-    x = torch.randn(2, 256, 320, 320, generator=g)
-    dy = torch.randn(2, 256, 320, 320, generator=g)
-    ref64 = ref.double().train()
-    x64 = x.double().requires_grad_(True)
-    with AbsTermSums(ref64) as cond:
-        y64 = ref64(x64)
-        y64.backward(dy.double())
-    mine = mine.cuda().train()
-    out = mine(MB.Act(nhwc(x).cuda()))
-    rel_close(out.t[..., out.coff:out.coff + out.c], nhwc(y64.detach()), what='C2fCBAM @320 forward')
-    dx = mine.backward(MB.Act(nhwc(dy).cuda()))
-    rel_close(dx.t[..., :256], nhwc(x64.grad), what='C2fCBAM @320 dx')
-    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
-    res = conditioned_errors([(n, p.grad) for n, p in mine.named_parameters() if p.grad is not None], g64, cond.sums)
-    assert len(res) == len(g64)
-    print('C2fCBAM @320 isolated: ' + ', '.join(f'{n.split(".", 1)[-1]} rel {r:.1e} cond {c:.0e} c {u:.1f}' for n, u, r, c in res if 'attention' in n))
-    bad = [(n, round(u, 1), f'{r:.2e}', f'{c:.1e}') for n, u, r, c in res if u > 16.0]
-    assert not bad, f'beyond 1e-3 relative + 16 * 2^-24 * sum|terms|: {bad}'
-
-
-def test_full_width_model_train_step_gradients():
-    """The real yolov5l-SOMI widths (77.5 M parameters; head convs 256->177->98 stored as 192 / 128 channels, 1024-wide SPPF,
-    per-sample ODConv weights of 512->256) through loss.backward() at 128x128, batch 2, against the fp64 oracle.  At this depth with
-    batch statistics over as few as 32 values the fp32 CPU oracle itself is up to 1.4e-2 away from its own fp64 run, so a plain
-    relative bar is meaningless; the bar is the conditioning-aware one of _conditioned_gradient_check (every parameter: 1e-3 relative
-    plus a measured multiple of one fp32 rounding of its own terms, the multiple calibrated on the fp32 CPU path)."""
+@pytest.mark.parametrize('dcn', [False, True])
+def test_full_width_well_conditioned_step_holds_flat_1e3(dcn):
+    """one training step of the real yolov5l-SOMI widths (77.5 M parameters; head convs 256->177->98, 1024-wide SPPF, per-sample
+    ODConv weights) at 320x320, batch 4 (ODConv's squeeze BatchNorm sees 4 samples), on a WELL-CONDITIONED fill (_well_conditioned), against
+    the fp64 oracle.  The premise is asserted, not assumed: the fp32 CPU oracle must itself sit within 2e-4 of fp64 on 99 % of the parameters.
+    Then the HIP path is held to BASELINE's flat 1e-3 on EVERY parameter (k_cpu = 0: no reference to any fp32 path's error) plus a fixed 16
+    roundings of the gradient's own terms for the cancelling sums.  With the DCNv3 sites the offset branch's gradient is discontinuous
+    wherever a sampling point crosses a pixel boundary (floor()), so ANY fp32 evaluation - the CPU oracle's too - is 1e-3 ... 4e-3 from fp64 on
+    those parameters and the layers in front of them: there the bar is max(1e-3, 2 x the CPU oracle's own distance)."""
     import copy
     from oracle.somi_ref import Model as OModel
     from oracle.somi_ref.loss import ComputeLoss as OLoss
     from oracle.somi_ref.testing import SOMI_ANCHORS, AbsTermSums, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
     from somi_amd.loss import ComputeLoss
     from somi_amd.model import Model
-    cfg = somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS)
-    ref = fill_state(OModel(cfg), 2)
+    torch.set_num_threads(16)
+    cfg = somi_cfg(1.0, 1.0, anchors=SOMI_ANCHORS, dcn=dcn)
+    ref = _well_conditioned(fill_state(OModel(cfg), 2))
     mine = Model(cfg)
     mine.load_state_dict(ref.state_dict())
     ref.hyp = mine.hyp = dict(HYP_VISDRONE)
     ref64 = copy.deepcopy(ref).double()
-    state0 = copy.deepcopy(ref.state_dict())
-    imgs, targets = synthetic_batch(2, 128, seed=4)
+    imgs, targets = synthetic_batch(4, 320, seed=14)
     ref.train(), ref64.train()
-    l32, _ = OLoss(ref)(ref(imgs.float() / 255), targets)
-    l32.backward()
+    mine = mine.cuda().train()
+    lm, _ = ComputeLoss(mine)(mine(imgs.cuda()), targets.cuda())
+    lm.backward()
+    torch.cuda.synchronize()
     with AbsTermSums(ref64) as cond:
         l64, _ = OLoss(ref64)(ref64(imgs.double() / 255), targets.double())
         l64.backward()
-    mine = mine.cuda().train()
-    lm, _ = ComputeLoss(mine)(mine(imgs.cuda()), targets.cuda())
-    rel_close(lm, l64.detach().float(), rel=1e-4, what='loss')
-    lm.backward()
-
-    def run(m):
-        m.hyp = dict(HYP_VISDRONE)
-        ComputeLoss(m)(m(imgs.cuda()), targets.cuda())[0].backward()
-    _conditioned_gradient_check(mine, ref, ref64, cond, 'full width @128', _perturbed_twin(cfg, state0, run))
+    l32, _ = OLoss(ref)(ref(imgs.float() / 255), targets)
+    l32.backward()
+    rel_close(lm, l64.detach().float(), rel=1e-5, what='loss')
+    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+    g32 = [(n, p.grad) for n, p in ref.named_parameters() if p.grad is not None]
+    rel_cpu = sorted((g.double() - g64[n]).abs().max().item() / (g64[n].abs().max().item() + 1e-300) for n, g in g32 if cond.sums[n].max() < 1e3 * g64[n].abs().max())
+    q99 = rel_cpu[int(0.99 * len(rel_cpu))]
+    print(f'well-conditioned fill, dcn={dcn}: fp32 CPU oracle vs fp64: median {rel_cpu[len(rel_cpu) // 2]:.2e} q99 {q99:.2e} max {rel_cpu[-1]:.2e} '
+          f'({len(rel_cpu)} parameters that are not cancelling sums)')
+    if not dcn:
+        assert q99 <= 2e-4, f'the premise of this test - a fill on which the fp32 CPU path is within 2e-4 of fp64 - does not hold: q99 {q99:.2e}'
+    _anchored_check(((n, p.grad) for n, p in mine.named_parameters() if p.grad is not None), g32, g64, cond.sums,
+                    f'full width @320 batch 4, well-conditioned, dcn={dcn}', k_cpu=2.0 if dcn else 0.0)
 
 
 @pytest.mark.parametrize('odconv', [False, True])
 def test_whole_model_train_step_gradients(odconv):
-    """loss.backward() through the whole SOMI graph on HIP vs the CPU oracle (torch autograd): loss, every parameter gradient,
-    BN running statistics."""
+    """loss.backward() through the whole SOMI graph on HIP: loss, train outputs and BN running statistics against the fp32 CPU oracle at 1e-3;
+    every parameter gradient against the FP64 oracle under the shared bar: max(BASELINE's 1e-3 of the gradient's scale, 2 x the fp32 CPU
+    oracle's own distance from fp64) + 16 roundings of the gradient's own terms - no absolute floor."""
+    import copy
     from oracle.somi_ref import Model as OModel
     from oracle.somi_ref.loss import ComputeLoss as OLoss
-    from oracle.somi_ref.testing import fill_state, synthetic_batch, HYP_VISDRONE
+    from oracle.somi_ref.testing import AbsTermSums, fill_state, synthetic_batch, HYP_VISDRONE
     from somi_amd.loss import ComputeLoss
     from somi_amd.model import Model
     cfg = _train_cfg(odconv)
@@ -432,11 +354,15 @@ def test_whole_model_train_step_gradients(odconv):
     mine = Model(cfg)
     mine.load_state_dict(ref.state_dict())
     ref.hyp = mine.hyp = dict(HYP_VISDRONE)
+    ref64 = copy.deepcopy(ref).double().train()
     imgs, targets = synthetic_batch(2, 64, seed=1)
     ref.train()
     pr = ref(imgs.float() / 255)
     lr, ir = OLoss(ref)(pr, targets)
     lr.backward()
+    with AbsTermSums(ref64) as cond:
+        l64, _ = OLoss(ref64)(ref64(imgs.double() / 255), targets.double())
+        l64.backward()
     mine = mine.cuda().train()
     pm = mine(imgs.cuda())
     for a, b in zip(pm, pr):
@@ -444,16 +370,9 @@ def test_whole_model_train_step_gradients(odconv):
     lm, im = ComputeLoss(mine)(pm, targets.cuda())
     rel_close(lm, lr, rel=1e-4, what='loss')
     lm.backward()
-    bad = []
-    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
-        if q.grad is None:
-            continue
-        assert p.grad is not None, n
-        err = (p.grad.cpu().double() - q.grad.double()).abs().max().item()
-        scale = q.grad.double().abs().max().item() + 1e-9
-        if err > 2e-3 * scale + 2e-6:       # atol: sums of many cancelling fp32 terms (e.g. the 7x7 attention bias) are order-sensitive
-            bad.append((n, err, scale))
-    assert not bad, bad[:8]
+    _anchored_check(((n, p.grad) for n, p in mine.named_parameters() if p.grad is not None),
+                    [(n, p.grad) for n, p in ref.named_parameters() if p.grad is not None],
+                    {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}, cond.sums, f'small SOMI graph, odconv={odconv}')
     for (n, p), (_, q) in zip(mine.named_buffers(), ref.named_buffers()):
         if 'running' in n:
             rel_close(p, q, what=n)
@@ -889,17 +808,20 @@ def test_training_step_is_bit_reproducible(graph):
             assert torch.equal(a[key][gi], b[key][gi]), f'{key} of ' + first_difference(a[key][gi], b[key][gi], st)
 
 
-def test_uavdt_1280_nc3_training_step_gradients():
-    """BASELINE configs[3] per-GPU shape: full-width SOMI WITH its DCNv3 sites (160^2 and 320^2 here), nc=3 (UAVDT), 1280x1280 - grids
-    320/160/80/40 - one training step at batch 2 (the squeeze BN of ODConv needs more than one sample): loss against the fp64 CPU oracle
-    at 1e-4, train-mode outputs within 4x of the fp32 CPU oracle's own distance from fp64 (38 layers deep, both fp32 paths sit 1e-3 ...
-    3e-3 of the output range from fp64), and every parameter gradient under the conditioning-aware bar of _conditioned_gradient_check -
-    no parameter is exempt by name: the CBAM attention gradients that are sums of 10^5 cancelling terms pass because the measured
-    root-sum-square of their terms is 10 ... 40 times the gradient, or they fail.  (Measured round 3, tools/grad_condition.py: at this depth
-    and map size BOTH fp32 paths are percent-level away from fp64 - fp32 CPU median 1.3e-2 / q90 2.2e-2 in those units, HIP 3.5e-2 / 7.0e-2:
-    the MFMA accumulates each output as one fp32 fmaf chain over K, MKLDNN in blocked partial sums - and the worst HIP parameter sits at
-    9.5 x the CPU path's q90.)"""
+# layers of the 1280x1280 DCN graph that are re-run ALONE on the tensors captured in the whole-graph fp64 pass: the
+# blocks whose parameters stood out in round 3's full-size run - 30 and 36 (C2fCBAM, n = 3, 160^2 / 40^2), 27 (C2fCBAM n = 3 at 320^2), the SEAM
+# blocks 22 / 26 (160^2 / 320^2), the DCNv3 sites 11 / 13 (320^2 / 160^2) - and the block types that had no full-shape isolated test: ODConv
+# 64 -> 128 stride 2 at 640 -> 320 (layer 1) and the decoupled head 256 -> 177 -> 98 at 320^2 ... 40^2 (layer 37)
+ISOLATED_1280 = (1, 11, 13, 22, 26, 27, 30, 36, 37)
+
+
+@pytest.fixture(scope='module')
+def uavdt1280():
+    """BASELINE configs[3] per-GPU shape - full-width SOMI WITH its DCNv3 sites, nc 3, 1280x1280 (grids 320 / 160 / 80 / 40), batch 2 - one
+    training step on the HIP path, on the fp64 CPU oracle (measuring Q = sqrt(sum terms^2) of every parameter gradient and capturing the inputs /
+    output gradients of the ISOLATED_1280 layers) and on the fp32 CPU oracle.  Shared by the tests below; ~140 s of CPU work."""
     import copy
+    from isolate import capture
     from oracle.somi_ref import Model as OModel
     from oracle.somi_ref.loss import ComputeLoss as OLoss
     from oracle.somi_ref.testing import SOMI_ANCHORS, AbsTermSums, fill_state, somi_cfg, synthetic_batch, HYP_VISDRONE
@@ -912,38 +834,101 @@ def test_uavdt_1280_nc3_training_step_gradients():
     mine.load_state_dict(ref.state_dict())
     ref.hyp = mine.hyp = dict(HYP_VISDRONE)
     ref64 = copy.deepcopy(ref).double()
-    state0 = copy.deepcopy(ref.state_dict())
     imgs, targets = synthetic_batch(2, 1280, nc=3, seed=14)
     mine = mine.cuda().train()
     pm = mine(imgs.cuda())
-    lm, im = ComputeLoss(mine)(pm, targets.cuda())
+    lm, _ = ComputeLoss(mine)(pm, targets.cuda())
     lm.backward()
     torch.cuda.synchronize()
-    assert [tuple(p.shape) for p in pm] == [(2, 4, g, g, 8) for g in (320, 160, 80, 40)]
-    ref64.train()
-    with AbsTermSums(ref64) as cond:
-        p64 = ref64(imgs.double() / 255)
-        l64, _ = OLoss(ref64)(p64, targets.double())
-        l64.backward()
-    rel_close(lm, l64.detach().float(), rel=1e-4, what='loss @1280 nc=3')
-    ref.train()
+    st = dict(mine=mine, ref=ref, ref64=ref64, lm=lm.detach().cpu(), pm=[p.detach().cpu() for p in pm],
+              hip=[(n, p.grad.detach().cpu()) for n, p in mine.named_parameters() if p.grad is not None])
+    ref64.train(), ref.train()
+
+    def run64():
+        with AbsTermSums(ref64, sums=False) as cond:
+            p64 = ref64(imgs.double() / 255)
+            l64, _ = OLoss(ref64)(p64, targets.double())
+            l64.backward()
+        st.update(rss=cond.rss, l64=l64.detach(), p64=[p.detach() for p in p64])
+    st['cap'] = capture(ref64, run64, layers=set(ISOLATED_1280))
+    st['g64'] = {n: p.grad.detach().clone() for n, p in ref64.named_parameters() if p.grad is not None}
     p32 = ref(imgs.float() / 255)
     l32, _ = OLoss(ref)(p32, targets)
     l32.backward()
-    for a, b32, b64 in zip(pm, p32, p64):
-        b64 = b64.detach()
-        scale = b64.abs().max().item()
-        e_mine = (a.detach().cpu().double() - b64).abs().max().item() / scale
-        e_o32 = (b32.detach().double() - b64).abs().max().item() / scale
-        assert e_mine <= max(4 * e_o32, 1e-3), f'train outputs @1280: HIP {e_mine:.2e} vs fp32 CPU {e_o32:.2e} (relative to fp64)'
-    del p64, p32
-
-    def run(m):
-        m.hyp = dict(HYP_VISDRONE)
-        ComputeLoss(m)(m(imgs.cuda()), targets.cuda())[0].backward()
-    twin = _perturbed_twin(cfg, state0, run)
+    st.update(p32=[p.detach() for p in p32], cpu=[(n, p.grad.detach().clone()) for n, p in ref.named_parameters() if p.grad is not None])
+    yield st
+    st.clear()
     torch.cuda.empty_cache()
-    _conditioned_gradient_check(mine, ref, ref64, cond, '1280 nc=3 with DCNv3 sites', twin)
+
+
+def test_uavdt_1280_nc3_training_step_gradients(uavdt1280):
+    """The whole-graph step at configs[3]'s per-GPU shape against the fp64 oracle: loss at 1e-4, train-mode outputs within 4x of the fp32 CPU
+    oracle's own distance from fp64, and the POPULATION of parameter gradients.  With fill_state's weights this graph is chaotic (the fp32 CPU
+    oracle itself is a median 1.3e-2, q90 2.2e-2 away from its own fp64 run in units of |g| + Q, Q = the root-sum-square of the gradient's terms
+    measured in the fp64 pass; one fp32 rounding of the weights moves single parameters of the CPU ORACLE by up to tens of those q90 -
+    profiles/r04_twin_distribution_1280.txt), so no per-parameter bar below O(1) means anything HERE; per-parameter guarantees come from the two
+    tests that can give them: every block of this very graph re-run alone on the tensors captured in this pass
+    (test_uavdt_1280_block_isolated_on_captured_tensors) and the well-conditioned full-width step at a flat 1e-3
+    (test_full_width_well_conditioned_step_holds_flat_1e3).  The bar uses nothing measured on the HIP path: median and 90th
+    percentile of r(HIP) within a FIXED 4x of the fp32 CPU oracle's, and no O(1) error anywhere (r <= 0.5).  What the 2.6x between the two
+    fp32 paths is: on identical inputs a HIP conv layer is 1.2e-6 ... 1.5e-6 from fp64 where MKLDNN is 3e-7 (tools/block_isolate.py: the MFMA sums
+    K = 9 Cin terms as ONE fp32 fmaf chain, MKLDNN in blocked partial sums), and the graph amplifies either by the same ~10^5."""
+    from oracle.somi_ref.testing import noise_scaled_errors
+    st = uavdt1280
+    assert [tuple(p.shape) for p in st['pm']] == [(2, 4, g, g, 8) for g in (320, 160, 80, 40)]
+    rel_close(st['lm'], st['l64'].float(), rel=1e-4, what='loss @1280 nc=3')
+    for a, b32, b64 in zip(st['pm'], st['p32'], st['p64']):
+        scale = b64.abs().max().item()
+        e_mine = (a.double() - b64).abs().max().item() / scale
+        e_o32 = (b32.double() - b64).abs().max().item() / scale
+        assert e_mine <= max(4 * e_o32, 1e-3), f'train outputs @1280: HIP {e_mine:.2e} vs fp32 CPU {e_o32:.2e} (relative to fp64)'
+    g64, rss = st['g64'], st['rss']
+    assert {n for n, _ in st['hip']} == set(g64), 'gradient presence differs from the oracle'
+    hip = noise_scaled_errors(st['hip'], g64, rss)
+    cpu = noise_scaled_errors(st['cpu'], g64, rss)
+    assert len(hip) == len(cpu) == len(g64), f'{len(g64) - len(hip)} parameters without a measured term scale'
+    rh, rc = torch.tensor([t[1] for t in hip]), torch.tensor([t[1] for t in cpu])
+    print(f'1280 nc=3 with DCNv3 sites: noise-scaled error r  HIP median {float(rh.median()):.2e} q90 {float(rh.quantile(0.9)):.2e} max {float(rh.max()):.2e} | '
+          f'fp32 CPU median {float(rc.median()):.2e} q90 {float(rc.quantile(0.9)):.2e} max {float(rc.max()):.2e}')
+    gross = [(n, f'r {r:.2e}') for n, r, _ in hip if r > 0.5]
+    assert not gross, f'O(1) gradient errors: {gross[:8]}'
+    assert rh.median() <= 4.0 * float(rc.median()), (float(rh.median()), float(rc.median()))
+    assert rh.quantile(0.9) <= 4.0 * float(rc.quantile(0.9)), (float(rh.quantile(0.9)), float(rc.quantile(0.9)))
+    # every parameter within a FIXED 12 x max(u90, the CPU oracle's own distance there).  Where the 12 comes from (profiles/r04_twin_distribution_1280.txt,
+    # 16 one-rounding twins of the fp32 CPU ORACLE, nothing of the HIP path in it): one fp32 rounding of the weights moves single parameters of the
+    # oracle itself by up to 10.05 u90 (11 of 16 twins move some parameter by >= 7.1 - the same 1.59e-1 each time: a pooling / ReLU switch upstream
+    # of model.30.m.2.cv1 that fp32 evaluations take either way), none of the 16 x 734 responses is beyond 12, and the HIP path's largest
+    # per-parameter distance is 7.7 u90 - 1.5 x that parameter's own largest CPU-twin response
+    u90 = float(rc.quantile(0.9))
+    cpu_r = {t[0]: t[1] for t in cpu}
+    far = [(n, f'r {r:.2e}', f'cpu {cpu_r[n]:.2e}', f'x{r / max(u90, cpu_r[n]):.1f}') for n, r, _ in hip if r > 12.0 * max(u90, cpu_r[n])]
+    assert not far, f'{len(far)} parameters beyond 12 x max(u90 = {u90:.2e}, the fp32 CPU oracle\'s own distance): {far[:8]}'
+
+
+@pytest.mark.parametrize('layer', ISOLATED_1280)
+def test_uavdt_1280_block_isolated_on_captured_tensors(uavdt1280, layer):
+    """Capture-and-isolate: layer `layer` of the 1280x1280 graph alone, on the inputs and output gradients the
+    whole-graph fp64 pass produced for it, rounded to fp32 - the fp64 oracle block and the HIP block see bit-identical tensors and weights, so
+    nothing arrives from upstream.  Output and input gradient at 1e-3 (1e-5 observed); EVERY parameter gradient at BASELINE's flat 1e-3 of its
+    scale plus a fixed 16 fp32 roundings of its own terms.  Only the DCNv3 blocks also run the fp32 CPU oracle block: the offset branch's
+    gradient is discontinuous where a sampling point crosses a pixel boundary, which puts ANY fp32 evaluation 2e-3 ... 7e-3 from fp64 on the
+    offset / depthwise parameters (HIP and MKLDNN agree there to three digits); those get max(1e-3, 2 x the CPU oracle's own distance)."""
+    from isolate import hip_alone, oracle_alone
+    st = uavdt1280
+    rec = st['cap'][layer]
+    assert all(d is not None for d in rec['dy']), 'no output gradient captured'
+    blk64, blk32, mine = st['ref64'].model[layer], st['ref'].model[layer], st['mine'].model[layer]
+    o64, dx64, g64, sums = oracle_alone(blk64, rec, torch.float64, with_sums=True)
+    is_dcn = blk64.type == 'DCNv3_YOLO'
+    g32 = list(oracle_alone(blk32, rec, torch.float32)[2].items()) if is_dcn else None
+    oh, dxh, gh = hip_alone(mine, rec)
+    for got, want in zip(oh, o64):
+        rel_close(got, want, what=f'layer {layer} ({blk64.type}) output')
+    if layer != 0:
+        for got, want in zip(dxh, dx64):
+            # the DCNv3 input gradient inherits the offset branch's discontinuity (both fp32 paths: 8e-3 ... 2e-2 of the largest element)
+            rel_close(got, want, rel=5e-2 if is_dcn else 1e-3, what=f'layer {layer} ({blk64.type}) input gradient')
+    _anchored_check(gh.items(), g32, g64, sums, f'layer {layer} ({blk64.type}) alone on captured tensors', k_cpu=2.0 if is_dcn else 0.0)
 
 
 @pytest.mark.parametrize('amp,loss_rel,grad_med,grad_q90,cos_min', [('bf16x3', 2e-5, 2e-3, 1e-2, 0.99999), ('bf16', 1e-2, None, None, 0.8)])

@@ -1168,13 +1168,20 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
                     if (j >= nk) break;                                  // wave-uniform
                     const f32x4 v1 = u[j * 4], v2 = u[j * 4 + 1], v3 = u[j * 4 + 2], v4 = u[j * 4 + 3];
                     const float lh = f[j][0], lw = f[j][1], m = f[j][2], hh = 1.f - lh, hw = 1.f - lw;
-                    // dcnv3_col2im_bilinear: value, grad_h_weight, grad_w_weight (dcnv3_im2col_cuda.cuh:112-141)
-                    const f32x4 val = (hh * hw) * v1 + (hh * lw) * v2 + (lh * hw) * v3 + (lh * lw) * v4;
-                    const f32x4 ghw = hw * (v3 - v1) + lw * (v4 - v2);
-                    const f32x4 gww = hh * (v2 - v1) + lh * (v4 - v3);
-                    const float gm = group_sum<LG>((tg[0] * val[0] + tg[1] * val[1]) + (tg[2] * val[2] + tg[3] * val[3]));
-                    const float gw = group_sum<LG>(((tg[0] * gww[0] + tg[1] * gww[1]) + (tg[2] * gww[2] + tg[3] * gww[3])) * m);
-                    const float gh = group_sum<LG>(((tg[0] * ghw[0] + tg[1] * ghw[1]) + (tg[2] * ghw[2] + tg[3] * ghw[3])) * m);
+                    // dcnv3_col2im_bilinear: value, grad_h_weight, grad_w_weight (dcnv3_im2col_cuda.cuh:112-141) with the sums over the
+                    // channels taken FIRST: the bilinear coefficients are the same for every channel of the group, so
+                    //   sum_c tg * val = hh (hw d1 + lw d2) + lh (hw d3 + lw d4),  sum_c tg * ghw = (hw d3 + lw d4) - (hw d1 + lw d2),
+                    //   sum_c tg * gww = hh (d2 - d1) + lh (d4 - d3)            with d_i = sum_c tg[c] * v_i[c] over this lane's 4 channels
+                    // - 16 multiply-adds and a dozen scalar operations per point instead of three blended 4-vectors and their dot products
+                    // (round 3: 1.9e8 vector instructions per launch, 2.5x the forward's, for the same LDS reads)
+                    const float d1 = (tg[0] * v1[0] + tg[1] * v1[1]) + (tg[2] * v1[2] + tg[3] * v1[3]);
+                    const float d2 = (tg[0] * v2[0] + tg[1] * v2[1]) + (tg[2] * v2[2] + tg[3] * v2[3]);
+                    const float d3 = (tg[0] * v3[0] + tg[1] * v3[1]) + (tg[2] * v3[2] + tg[3] * v3[3]);
+                    const float d4 = (tg[0] * v4[0] + tg[1] * v4[1]) + (tg[2] * v4[2] + tg[3] * v4[3]);
+                    const float top = hw * d1 + lw * d2, bot = hw * d3 + lw * d4;
+                    const float gm = group_sum<LG>(hh * top + lh * bot);
+                    const float gw = group_sum<LG>((hh * (d2 - d1) + lh * (d4 - d3)) * m);
+                    const float gh = group_sum<LG>((bot - top) * m);
                     if (live && part == 0) {
                         gm_b[k0 + j] = gm;
                         *reinterpret_cast<float2 *>(go_b + (k0 + j) * 2) = make_float2(a.offset_scale * gw, a.offset_scale * gh);
