@@ -383,6 +383,11 @@ int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const flo
 int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
                            const float *sa, const float *dstats, const int32_t *amaxc, float *dca, float *workspace, int B, int HW,
                            int C, somi_stream_t stream);
+/* C + D in one pass over t: as somi_cbam_bwd_chan_f32, and amaxp[b,c] = first pixel index of max_p t[b,p,c] (what somi_pool_argmax_nhwc_f32
+ * computes from a pass of its own).  workspace: 3*B*nchunk*C 4-byte words */
+int somi_cbam_bwd_chan_argmax_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
+                                  const float *sa, const float *dstats, const int32_t *amaxc, float *dca, int32_t *amaxp, float *workspace,
+                                  int B, int HW, int C, somi_stream_t stream);
 /* D: amaxp[b,c] = first pixel index of max_p x[b,p,c]. workspace: 2*B*nchunk*C 4-byte words */
 int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int32_t *amaxp, void *workspace,
                               somi_stream_t stream);

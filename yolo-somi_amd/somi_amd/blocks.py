@@ -38,6 +38,16 @@ def new_act(like, H, W, c):
     return Act(torch.empty(like.shape[0], H, W, pad4(c), device=like.device, dtype=torch.float32), 0, c)
 
 
+def concat_act(like, H, W, c):
+    """The buffer several producers write channel slices of (the reference's torch.cat, never materialised).  Stored at pad4(c) channels like every
+    activation: a total that is >= 64 and not a multiple of 32 (5 x 16 = 80 in a C2fCBAM of hidden width 16, n = 3) gets zero pad channels the
+    consumer conv may read (its weight columns there are zero).  Round 4: the buffers were allocated at exactly c and such a width failed the
+    consumer's channel-range check (found by the n = 3 case of test_c2fcbam_train_forward_backward; no shipped graph has such a width)."""
+    cp = pad4(c)
+    alloc = torch.empty if cp == c else torch.zeros
+    return Act(alloc(like.shape[0], H, W, cp, device=like.device, dtype=torch.float32), 0, c)
+
+
 def autopad(k, p=None, d=1):
     """models/common.py:43-51."""
     if p is not None:
@@ -339,8 +349,10 @@ class ChannelAttentionModule(_Packed):
             self.__dict__['_ctx'] = (x, avg, mx, ca, (W1, b1, W2, b2))
         return ca
 
-    def backward(self, dca, dt):
-        """dca (B,C): gradient w.r.t. the attention vector; adds the pooled-input gradient into dt (Act) in place."""
+    def backward(self, dca, dt, amaxp=None):
+        """dca (B,C): gradient w.r.t. the attention vector; adds the pooled-input gradient into dt (Act) in place.
+        amaxp (B,C) int32: first pixel of every channel's spatial maximum when the caller already has it (the CBAM backward takes it in its own
+        pass over x); else it is found here."""
         x, avg, mx, ca, (W1, b1, W2, b2) = self.__dict__.pop('_ctx')
         l1, l2 = self.shared_MLP[0], self.shared_MLP[2]
         prms = (l1.weight, l1.bias, l2.weight, l2.bias)
@@ -349,7 +361,8 @@ class ChannelAttentionModule(_Packed):
         for prm, (gr, scratch) in zip(prms, g):
             if scratch:
                 _acc_grad(prm, gr)
-        amaxp = ops.pool_argmax(x.t, x.c, x.coff)
+        if amaxp is None:
+            amaxp = ops.pool_argmax(x.t, x.c, x.coff)
         ops.pool_backward_add_(dt.t, dt.coff, x.c, davg, dmax, amaxp)
 
 
@@ -385,14 +398,14 @@ class SpatialAttentionModule(_Packed):
 
     def backward(self, dt2):
         """dt2: gradient tensor w.r.t. x*ca*sa (whole tensor, modified in place into the x-gradient through both products and
-        the spatial branch).  Returns dca (B,C)."""
+        the spatial branch).  Returns dca (B,C) and amaxp (B,C): the pixel of each channel's spatial maximum of x (for the max-pool's gradient)."""
         x, ca, stats, sa, w = self.__dict__.pop('_ctx')
         k = self.cv1.kernel_size[0]
         dw, db = torch.zeros_like(w), torch.zeros(1, device=w.device)
-        dca = ops.cbam_backward(dt2, x.t, x.coff, x.c, ca, sa, stats, w, k, dw, db)
+        dca, amaxp = ops.cbam_backward(dt2, x.t, x.coff, x.c, ca, sa, stats, w, k, dw, db)
         _acc_grad(self.cv1.weight, dw.permute(2, 0, 1).unsqueeze(0))          # [k][k][2] -> (1,2,k,k)
         _acc_grad(self.cv1.bias, db)
-        return dca
+        return dca, amaxp
 
 
 class CBAMBottleneck(nn.Module):
@@ -422,8 +435,8 @@ class CBAMBottleneck(nn.Module):
         C2f gradient buffer that already holds the gradient of the input's other consumers)."""
         x, t = self.__dict__.pop('_ctx')
         d = self.cv2.backward(dout)                               # d(t*ca*sa)
-        dca = self.spatial_attention.backward(d.t)                # d.t now holds the direct part of dt
-        self.channel_attention.backward(dca, d)                   # + pooled paths
+        dca, amaxp = self.spatial_attention.backward(d.t)        # d.t now holds the direct part of dt
+        self.channel_attention.backward(dca, d, amaxp)            # + pooled paths
         c1 = self.cv1.conv.in_channels
         fuse = self.add and pad4(c1) == c1 and dout.coff % 4 == 0  # the shortcut's gradient rides the dgrad epilogue
         self.cv1.backward(d, dx_out=dx_out, accumulate=True, also_add=dout if fuse else None)
@@ -449,7 +462,7 @@ class C2fCBAM(nn.Module):
         if c % 4:
             raise NotImplementedError('C2fCBAM hidden width must be a multiple of 4 on the MI355X path')
         B, H, W, _ = x.shape
-        cat = Act(torch.empty(B, H, W, (2 + n) * c, device=x.t.device, dtype=torch.float32))
+        cat = concat_act(x.t, H, W, (2 + n) * c)
         self.cv1(x, out=cat.slice(0, 2 * c))
         for i, blk in enumerate(self.m):
             blk(cat.slice((1 + i) * c, c), out=cat.slice((2 + i) * c, c))
@@ -477,7 +490,7 @@ class SPPF(nn.Module):
     def forward(self, x):
         c_ = self.cv1.conv.out_channels
         B, H, W, _ = x.shape
-        cat = Act(torch.empty(B, H, W, 4 * c_, device=x.t.device, dtype=torch.float32))
+        cat = concat_act(x.t, H, W, 4 * c_)
         self.cv1(x, out=cat.slice(0, c_))
         ops.sppf_pool_(cat.t, c_, 0)
         if self.training:
@@ -762,19 +775,20 @@ class SEAM(_Packed):
                     W1=f(self.fc[0].weight), W2=f(self.fc[2].weight))
 
     # ------------------------------------------------------------------------------------------ training mode
-    def _bn_train(self, u, bn):
-        """z = BN_batch(GELU(u)) (act before the norm, models/common.py:8455-8457); returns z and the saved statistics."""
+    def _bn_train(self, u, bn, residual=None):
+        """z = BN_batch(GELU(u)) [+ residual] (act before the norm, models/common.py:8455-8457; the Residual wrapper's add :7183 rides the same
+        pass); returns z and the saved statistics."""
         dev, c = u.device, u.shape[3]
         rm, rv = bn.running_mean.detach().clone(), bn.running_var.detach().clone()
         if ops.SYNC_BN is None:
             # two passes over u: the statistics of gelu(u) taken on the fly, then z = gelu(u) * scale + shift (order 1) - gelu(u) is never stored
             # (the backward reads u too); three passes and a tensor less than act -> statistics -> affine
             st = ops.bn_stats(u, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv, act='gelu')
-            z = ops.chan_affine_act(u, c, 0, st[2], st[3], 'gelu', 1, torch.empty_like(u))
+            z = ops.chan_affine_act(u, c, 0, st[2], st[3], 'gelu', 1, torch.empty_like(u), residual=residual)
         else:
             g = ops.chan_affine_act(u, c, 0, torch.ones(c, device=dev), torch.zeros(c, device=dev), 'gelu', 0, torch.empty_like(u))
             st = ops.bn_stats(g, c, 0, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, rm, rv)
-            z = ops.chan_affine_act(g, c, 0, st[2], st[3], 'none', 0, g)
+            z = ops.chan_affine_act(g, c, 0, st[2], st[3], 'none', 0, g, residual=residual)
         with torch.no_grad():
             bn.running_mean.copy_(rm)
             bn.running_var.copy_(rv)
@@ -797,8 +811,7 @@ class SEAM(_Packed):
         u0 = ops.dwconv3x3(x.t, pk['dw0'], pk['b0'])
         y0, s0 = self._bn_train(u0, d[2])
         u1 = ops.dwconv3x3(y0, pk['dw1'], pk['b1'])
-        z1, s1 = self._bn_train(u1, st[0].fn[2])
-        y1 = ops.add_(z1, 0, y0, 0, x.c)
+        y1, s1 = self._bn_train(u1, st[0].fn[2], residual=y0)    # Residual: fn(y0) + y0
         u2 = ops.conv2d_nhwc(y1, pk['pw'], pk['pb'], kh=1, kw=1)
         y2, s2 = self._bn_train(u2, st[3])
         avg, _ = ops.global_pool(y2, want_max=False)
@@ -975,7 +988,7 @@ class C3(nn.Module):
         if c_ % 4:
             raise NotImplementedError('C3 hidden width must be a multiple of 4 on the MI355X path')
         B, H, W, _ = x.shape
-        cat = Act(torch.empty(B, H, W, 2 * c_, device=x.t.device, dtype=torch.float32))
+        cat = concat_act(x.t, H, W, 2 * c_)
         n = len(self.m)
         t = self.cv1(x, out=cat.slice(0, c_) if n == 0 else None)
         for i, blk in enumerate(self.m):
@@ -1055,7 +1068,7 @@ class Concat(nn.Module):
                 raise NotImplementedError('Concat inputs must be channel slices with offsets and widths that are multiples of 4')
             if (a.shape[0], a.shape[1] << a.up, a.shape[2] << a.up) != (B, H, W):
                 raise RuntimeError(f'Sizes of tensors must match except in dimension 1. Got {[tuple(v.shape) for v in xs]}')
-        out = Act(torch.empty(B, H, W, sum(a.c for a in xs), device=xs[0].t.device, dtype=torch.float32))
+        out = concat_act(xs[0].t, H, W, sum(a.c for a in xs))
         off = 0
         for a in xs:
             ops.resample_slice(a.t, a.coff, out.t, off, a.c, up=a.up)

@@ -719,7 +719,8 @@ def add_(a, a_coff, b, b_coff, c, out=None, out_coff=None):
 
 def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7):
     """Steps A-C of train_blocks.hip: turns d(t*ca*sa) (dt2, whole tensor, modified in place) into the part of dt that flows
-    through the two multiplications and the spatial branch; returns dca (B,C).  dw7 / db7 are accumulated."""
+    through the two multiplications and the spatial branch; returns dca (B,C) and amaxp (B,C) int32 - the first pixel of each channel's
+    spatial maximum of t (step D, taken in the same pass).  dw7 / db7 are accumulated."""
     B, H, W, _ = t.shape
     dev = t.device
     L = _lib.lib()
@@ -732,10 +733,11 @@ def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7):
     check(L.somi_spatial_attn_bwd_f32(_ptr(dlogit), _ptr(stats), _ptr(w7), _ptr(dstats), _ptr(dw7), _ptr(db7), _ptr(ws), B, H, W, k,
                                       _stream()), 'spatial_attn_bwd')
     dca = torch.empty(B, c, device=dev, dtype=torch.float32)
-    ws2 = torch.empty(B * L.somi_img_nchunk(H * W) * c, device=dev, dtype=torch.float32)
-    check(L.somi_cbam_bwd_chan_f32(_ptr(dt2), dt2.shape[3], 0, _ptr(t), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dstats), _ptr(amaxc),
-                                   _ptr(dca), _ptr(ws2), B, H * W, c, _stream()), 'cbam_bwd_chan')
-    return dca
+    amaxp = torch.empty(B, c, device=dev, dtype=torch.int32)      # step D rides the same pass over t: where each channel's spatial maximum sits
+    ws2 = torch.empty(3 * B * L.somi_img_nchunk(H * W) * c, device=dev, dtype=torch.float32)
+    check(L.somi_cbam_bwd_chan_argmax_f32(_ptr(dt2), dt2.shape[3], 0, _ptr(t), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dstats), _ptr(amaxc),
+                                          _ptr(dca), _ptr(amaxp), _ptr(ws2), B, H * W, c, _stream()), 'cbam_bwd_chan')
+    return dca, amaxp
 
 
 def pool_argmax(x, c, x_coff=0):
