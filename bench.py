@@ -179,10 +179,11 @@ def pmc_traffic(kernel_name):
 
 
 # the kernels behind the two DCNv3 operator entries that ops.PROFILE times.  The FIRST pattern of an entry is launched exactly once per
-# operator call (forward = that one launch; backward = A once, then B / C / D once per chunk of images through the staging slab)
+# operator call (forward = that one launch; backward = A once, then B once per colour of tiles + the far / near passes - or, slab form, B / C / D
+# once per chunk of images)
 DCN_OP_KERNELS = {'dcnv3_fwd_kernel': (r'dcnv3_win_kernel<\d+,0>|dcnv3_fwd_kernel',),
                   'dcnv3_bwd_kernel': (r'dcnv3_win_kernel<\d+,1>|dcnv3_bwd_om_kernel', r'dcnv3_bwd_gin_(mfma_)?kernel', r'dcnv3_bwd_combine_kernel',
-                                       r'dcnv3_bwd_near_kernel')}
+                                       r'dcnv3_bwd_near_kernel', r'dcnv3_bwd_far_kernel')}
 
 
 def pmc_traffic_op(op):

@@ -359,6 +359,16 @@ int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const
                                   const float *rstd, const float *scale, const float *shift, int act, int order,
                                   int batch_stats, float *dx, int dx_cs, int dx_coff, float *dgamma, float *dbeta, long npix,
                                   int C, float *workspace, somi_stream_t stream);
+/* The same backward (batch statistics) for the conv in front of a CBAM attention pair (models/common.py:339-358, 671-691), with the gradient of
+ * the channel attention's global pools folded in instead of added by a pass of its own (somi_pool_bwd_add_nhwc_f32):
+ *   dz_eff[b,p,c] = dz[b,p,c] + davg[b,c] / HW + [p == amaxp[b,c]] * dmax[b,c];   dz is only read.
+ * davg, dmax (B,C) float, amaxp (B,C) int32 - the first pixel of each channel's spatial maximum.  workspace: 2 * somi_bn_pooled_rows(B, HW) * C
+ * + 3 * round_up(C, 4) floats. */
+int somi_bn_pooled_rows(int B, int HW);
+int somi_bn_act_backward_pooled_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
+                                         const float *rstd, const float *scale, const float *shift, int act, int order, const float *davg,
+                                         const float *dmax, const int32_t *amaxp, float *dx, int dx_cs, int dx_coff, float *dgamma,
+                                         float *dbeta, int B, int HW, int C, float *workspace, somi_stream_t stream);
 /* out = a + b on channel slices (residual connections, gradient accumulation); out may alias a or b */
 int somi_add_nhwc_f32(const float *a, int a_cs, int a_coff, const float *b, int b_cs, int b_coff, float *out, int o_cs,
                       int o_coff, long npix, int C, somi_stream_t stream);

@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--layers', default='')
     ap.add_argument('--out', default='')
     ap.add_argument('--threads', type=int, default=16)
+    ap.add_argument('--gamma', type=float, default=1.0, help='scale every BatchNorm weight (0.25: the well-conditioned fill of the tests)')
     ap.add_argument('--no-hip', action='store_true', help='dry run of the oracle side on a box without a GPU')
     a = ap.parse_args()
     from oracle.somi_ref import Model as OModel
@@ -61,6 +62,11 @@ def main():
     t0 = time.time()
     cfg = somi_cfg(a.width, a.depth, nc=a.nc, anchors=SOMI_ANCHORS, dcn=bool(a.dcn))
     ref = fill_state(OModel(cfg), a.seed)
+    if a.gamma != 1.0:
+        with torch.no_grad():
+            for m_ in ref.modules():
+                if isinstance(m_, torch.nn.BatchNorm2d):
+                    m_.weight.mul_(a.gamma)
     mine = Model(cfg)
     mine.load_state_dict(ref.state_dict())
     ref.hyp = mine.hyp = dict(HYP_VISDRONE)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the windowed DCNv3 backward alone (HIP events) at the two bench sites.  usage: dcn_bwd_probe.py [spread=0.7]
-Environment switches are read once per process by the library: SOMI_DCN_SLAB_MB (staging slab cap), SOMI_DCN_NEAR (0: no near pass)."""
+Environment switches: SOMI_DCN_SLAB=1 (round-3 form of backward B: staging slab + combine pass instead of the coloured direct adds),
+SOMI_DCN_SLAB_MB (that slab's cap), SOMI_DCN_NEAR (0: no near pass)."""
 import json
 import os
 import sys
@@ -32,5 +33,5 @@ for N, H in ((32, 80), (32, 160)):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print(json.dumps({'slab_mb': os.environ.get('SOMI_DCN_SLAB_MB', '128'), 'near': os.environ.get('SOMI_DCN_NEAR', '1'), 'shape': f'N{N} {H}x{H}',
+    print(json.dumps({'form': 'slab + combine' if os.environ.get('SOMI_DCN_SLAB') == '1' else 'coloured (direct adds)', 'near': os.environ.get('SOMI_DCN_NEAR', '1'), 'shape': f'N{N} {H}x{H}',
                       'spread': spread, 'ms': round(ms, 4), 'far_taps': ops.dcn_overflow_taps()}), flush=True)

@@ -35,6 +35,9 @@ def ddp_expected(shadow, batches, world):
         p.grad = None
     crit = ComputeLoss(shadow)
     for imgs, targets in batches:
+        for name, buf in shadow.named_buffers():                 # DDP's broadcast_buffers (default on, train.py:208-209): rank 0's running
+            if buf.dtype.is_floating_point and 'running' in name:    # statistics before every forward - they are the pivot the batch statistics are
+                dist.broadcast(buf, src=0)                           # summed around, so the last bits of the gradients depend on them
         loss, _ = crit(shadow(imgs), targets)
         (loss * world).backward()
         for p in shadow.parameters():

@@ -368,6 +368,7 @@ struct GinGeo {
     unsigned *overflow;          // FAR taps (added with fp32 atomics): 0 <=> bit-reproducible
     unsigned *near;              // [N][G][tiles] masks of the destination tiles that receive a tile's NEAR taps; nullptr: no near pass (stride != 1)
     unsigned *near_any;          // one word per chunk of images: != 0 iff any tile of the chunk has near taps (the near pass exits on 0)
+    int nch, ncw, col_h, col_w;  // COLOURED form of backward B: this launch takes the tiles (col_h + nch * i, col_w + ncw * j) - windows of one colour are disjoint
 };
 
 // A tap at input pixel (h, w) that fell outside its tile's window: its destination tile relative to the tile under the window's centre.
@@ -578,7 +579,14 @@ static_assert(sizeof(RecM) == 24, "step 2 reads the records as 6 dwords");
 
 constexpr int GMM_NT = 512;           // threads: LDS (S is 61 KB) allows two workgroups per CU, so each brings 8 waves for the non-MFMA phases
 
-template <int GC>
+// COLOURED (round 4): no staging slab and no combine pass.  The windows of tiles that are `nch` x `ncw` tiles apart do not overlap (a window of
+// an 8 x 8 tile with a 3 x 3 kernel and 2 px of slack is 15 x 15 input pixels, the tile pitch 8: every second tile both ways), so the tiles are
+// run in nch * ncw launches of one COLOUR each, and a workgroup adds its window's product straight into grad_input with plain read-add-write -
+// no other workgroup of the launch touches those pixels, and the launches of one stream run in order, so the adds to a pixel covered by several
+// windows happen in the fixed order of the colours: deterministic, no atomics.  HBM traffic per call: the window's pixels read + written once
+// per covering tile (2 x 0.74 GB at N32 80x80) instead of slab write + slab read + the combine's read-modify-write of grad_input (2.25 GB), and
+// dcnv3_bwd_combine_kernel (0.19 / 0.27 ms per launch) is gone.  The values a lane will add to are requested BEFORE the matrix product.
+template <int GC, bool COLOURED>
 __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArgs a, const GinGeo q) {
     static_assert(GC == 32, "one 32-channel MFMA row block (64-wide groups: S + go^T exceed the LDS of two workgroups per CU, they take the list form)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -590,8 +598,13 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
     const size_t mid = (size_t)nrec * sizeof(RecM) > (size_t)GC * GMM_LD * 4 ? (size_t)nrec * sizeof(RecM) : (size_t)GC * GMM_LD * 4;
     OvfG *ovf = reinterpret_cast<OvfG *>(reinterpret_cast<char *>(recs) + (mid + 15) / 16 * 16);
     __shared__ int novf;
-    __shared__ unsigned nearmask;
-    const int tile = blockIdx.x, n = blockIdx.y, g = blockIdx.z;
+    __shared__ unsigned nearmask;                                     // bits 0..24: destination tiles of NEAR taps; COLOURED: bit 31 = the tile has FAR taps
+    int tile = blockIdx.x;
+    if constexpr (COLOURED) {                                          // the launch's colour class: tiles (col_h + nch * i, col_w + ncw * j)
+        const int tcw = (q.tiles_w - q.col_w + q.ncw - 1) / q.ncw;
+        tile = (q.col_h + q.nch * ((int)blockIdx.x / tcw)) * q.tiles_w + q.col_w + q.ncw * ((int)blockIdx.x % tcw);
+    }
+    const int n = blockIdx.y, g = blockIdx.z;
     const int th0 = (tile / q.tiles_w) * GIN_TH, tw0 = (tile % q.tiles_w) * GIN_TW;
     const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -680,6 +693,9 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
                 S[(wh * q.WW + ww) * GMM_LD + pl] += cf;                      // plain read-add-write: see the note on column writers above
             } else if (int nb; near_bit(q, wh + win_h0, ww + win_w0, win_h0, win_w0, nb)) {
                 atomicOr(&nearmask, 1u << nb);                                // left for the near pass (dcnv3_bwd_near_kernel)
+            } else if constexpr (COLOURED) {
+                atomicOr(&nearmask, 1u << 31);                                // FAR: dcnv3_bwd_far_kernel adds it after the last colour (an atomic
+                                                                              // here could meet another workgroup's plain read-add-write)
             } else {
                 const int at = atomicAdd(&novf, 1);
                 if (at < GMM_OVF_CAP) ovf[at] = OvfG{(wh + win_h0) * a.W + ww + win_w0, pl, cf};   // a longer list: all of them again in step 5
@@ -717,7 +733,8 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
     //    and MFMA step t pairs k = 8j + t (lanes 0-31) with k = 8j + 4 + t (lanes 32-63) - the same permutation on both operands.
     const int nblk = (ncell + 31) / 32;
     const int frag = (lane & 31) * GMM_LD + (lane >> 5) * 4;
-    float *dst = q.staging + (((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile) * (long)ncell * GC;
+    float *dst = COLOURED ? a.grad_input + (long)n * a.H * a.W * a.C + g * GC
+                        : q.staging + (((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile) * (long)ncell * GC;
     for (int cb = wave; cb < nblk; cb += NT / 64) {
         f32x16 acc[MB];
 #pragma unroll
@@ -726,6 +743,18 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
             for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
         const int crow = cb * 32 + (lane & 31);
         const float *srow = S + (crow < ncell ? crow : ncell - 1) * GMM_LD + (lane >> 5) * 4;     // rows past the window: a valid row, never stored
+        // COLOURED: this lane's cell as an image pixel, and what grad_input holds there now (earlier colours' adds) - requested before the product
+        long gpix = -1;
+        f32x4 cur[MB][4];
+        if constexpr (COLOURED) {
+            const int ch = crow / q.WW, h = win_h0 + ch, w = win_w0 + (crow - ch * q.WW);
+            if (crow < ncell && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) gpix = ((long)h * a.W + w) * a.C;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    cur[mb][qd] = gpix >= 0 ? *reinterpret_cast<const f32x4 *>(dst + gpix + mb * 32 + qd * 8 + (lane >> 5) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int j = 0; j < GIN_TP / 8; ++j) {
             const f32x4 fs = *reinterpret_cast<const f32x4 *>(srow + j * 8);
@@ -738,7 +767,17 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
                 for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg[mb][t], fs[t], acc[mb], 0, 0, 0);
         }
         // D: lane holds cell n = lane % 32 and channels 8*(e/4) + 4*(lane/32) + e%4 of the block
-        if (crow < ncell) {
+        if constexpr (COLOURED) {
+            if (gpix >= 0) {                                          // a cell outside the image received nothing (its coefficients are 0)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const f32x4 v = {acc[mb][qd * 4], acc[mb][qd * 4 + 1], acc[mb][qd * 4 + 2], acc[mb][qd * 4 + 3]};
+                        *reinterpret_cast<f32x4 *>(dst + gpix + mb * 32 + qd * 8 + (lane >> 5) * 4) = cur[mb][qd] + v;
+                    }
+            }
+        } else if (crow < ncell) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -750,10 +789,10 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
     }
     if (tid == 0 && q.near) {
         q.near[((long)n * a.G + g) * (q.tiles_h * q.tiles_w) + tile] = nearmask;
-        if (nearmask) atomicOr(q.near_any, 1u);
+        if (nearmask) atomicOr(q.near_any, ((nearmask & 0x7fffffffu) ? 1u : 0u) | ((nearmask >> 31) ? 2u : 0u));
     }
     // 5. FAR taps: fp32 atomics into grad_input like the reference's own kernel (one channel per lane)
-    if (novf) {
+    if (!COLOURED && novf) {
         constexpr int SLOTS = NT / GC;
         const int c = tid % GC, slot = tid / GC;
         float *gin = a.grad_input + (long)n * a.H * a.W * a.C + g * GC + c;
@@ -820,6 +859,54 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_combine_kernel(const DcnArgs a,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward B, coloured form: the far taps
+// Runs after the last colour.  Persistent grid over (image, group, tile) that returns at once unless some tile flagged FAR taps (bit 31 of its
+// mask word; offsets of +-20 pixels as in the reference's test - no training run produces them).  A flagged tile's sampling records are rebuilt
+// with the arithmetic of make_record and every corner that left the window AND the near pass's reach goes to grad_input as
+// an fp32 atomic, one channel per lane, exactly like the reference's own kernel (dcnv3_im2col_cuda.cuh:116-140); counted in q.overflow.
+template <int GC>
+__global__ __launch_bounds__(256) void dcnv3_bwd_far_kernel(const DcnArgs a, const GinGeo q) {
+    if ((*q.near_any & 2u) == 0u) return;
+    __shared__ unsigned cnt;
+    const int ntile = q.tiles_h * q.tiles_w, nrec = GIN_TP * a.K, tid = threadIdx.x;
+    constexpr int SLOTS = 256 / GC;
+    const int c = tid % GC, slot = tid / GC;
+    for (long item = blockIdx.x; item < (long)a.N * a.G * ntile; item += gridDim.x) {     // the index of the tile's mask word
+        if (!(q.near[item] >> 31)) continue;                                             // workgroup-uniform
+        const int tile = (int)(item % ntile), g = (int)((item / ntile) % a.G), n = (int)(item / ((long)ntile * a.G));
+        const int th0 = (tile / q.tiles_w) * GIN_TH, tw0 = (tile % q.tiles_w) * GIN_TW;
+        const int win_h0 = th0 * a.sh + q.lo_h, win_w0 = tw0 * a.sw + q.lo_w;
+        float *gin = a.grad_input + (long)n * a.H * a.W * a.C + g * GC + c;
+        if (tid == 0) cnt = 0u;
+        __syncthreads();
+        unsigned mine = 0;
+        for (int i = slot; i < nrec; i += SLOTS) {
+            const int pl = i / a.K, k = i % a.K;
+            const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+            if (ho >= a.Ho || wo >= a.Wo) continue;
+            const long pix = ((long)n * a.Ho + ho) * a.Wo + wo;
+            const Rec r = make_record<true>(a, pix, g, k);
+            const int bits = __float_as_int(r.f[3]);
+            const float lh = r.f[0], lw = r.f[1], m = r.f[2], hh = 1.f - lh, hw = 1.f - lw;
+            const float cf4[4] = {hh * hw * m, hh * lw * m, lh * hw * m, lh * lw * m};
+            const float tv = a.grad_output[pix * a.C + g * GC + c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!((bits >> t) & 1) || cf4[t] == 0.f) continue;
+                const int hwp = r.off[t] / a.C, h = hwp / a.W, w = hwp % a.W;
+                if ((unsigned)(h - win_h0) < (unsigned)q.WH && (unsigned)(w - win_w0) < (unsigned)q.WW) continue;   // went through S
+                if (int nb; near_bit(q, h, w, win_h0, win_w0, nb)) continue;                                          // the near pass adds it
+                atomicAdd(gin + (long)hwp * a.C, tv * cf4[t]);
+                if (c == 0) ++mine;
+            }
+        }
+        if (mine) atomicAdd(&cnt, mine);
+        __syncthreads();
+        if (tid == 0 && cnt) atomicAdd(q.overflow, cnt);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward D: the near taps
 // One workgroup per (destination tile of 8x8 input pixels, image, group).  For every source tile within +-2 tiles whose mask names
 // this destination: rebuild the source tile's sampling records (the arithmetic of backward B, so the same floor positions and
@@ -837,7 +924,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_near_kernel(const DcnArgs a, co
     constexpr int NG = 256 / GC;                                      // thread groups; group j owns the cells with cell % NG == j
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = tid % GC, grp = tid / GC;
-    if (*q.near_any == 0u) return;                                    // the usual case: no tile of this chunk has a near tap
+    if ((*q.near_any & 1u) == 0u) return;                             // the usual case: no tile of this chunk has a near tap (bit 1: far taps)
     const int dt_w = (a.W + 7) >> 3, dt_n = ((a.H + 7) >> 3) * dt_w;
     const int ntile = q.tiles_h * q.tiles_w;
     const int cb_h = (q.lo_h + (q.WH >> 1)) >> 3, cb_w = (q.lo_w + (q.WW >> 1)) >> 3;    // source tile t sits in destination tile t + cb
@@ -1240,20 +1327,34 @@ static size_t win_plan(const DcnArgs &a, GinGeo &q) {
 // Workspace layout: slab | near masks (one word per (image of the chunk, group, tile)) | near_any (one word per chunk) | 256 B whose
 // first word is the far-tap counter - every region a multiple of 256 B, all of it sized HERE, before anything is launched.
 struct GinPlan {
-    size_t lds, slab_bytes, near_bytes, any_bytes, workspace_bytes;
+    size_t lds, mlds, slab_bytes, near_bytes, any_bytes, workspace_bytes;
     int chunk, nchunks;
+    bool mfma, coloured;
+    int nch, ncw;
 };
 static bool gin_plan(const DcnArgs &a, GinGeo &q, GinPlan &pl) {
     if (!win_geo(a, q)) return false;
     pl.lds = (size_t)GIN_TP * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(RecG) + 4 * sizeof(float) + 4) + GIN_OVF_CAP * sizeof(OvfG) +
              3 * ((size_t)q.WH * q.WW + 1) * sizeof(int);
     if (pl.lds > 150 * 1024 || (long)q.tiles_h * q.tiles_w > 65535L * 32) return false;
+    // B on the matrix cores for 32-wide groups when its LDS image fits (SOMI_DCN_GIN=exact keeps the list sums for comparisons) ...
+    const char *gsel = getenv("SOMI_DCN_GIN");
+    const size_t ncell_ = (size_t)q.WH * q.WW, recb = (size_t)GIN_TP * a.K * sizeof(RecM), gotb = (size_t)a.Gc * GMM_LD * sizeof(float);
+    pl.mlds = ncell_ * GMM_LD * sizeof(float) + ((recb > gotb ? recb : gotb) + 15) / 16 * 16 + GMM_OVF_CAP * sizeof(OvfG);
+    pl.mfma = a.Gc == 32 && pl.mlds <= 78 * 1024 + 512 && !(gsel && gsel[0] == 'e');
+    // ... and, stride 1 with the near pass on, in its COLOURED form: tiles whose windows cannot overlap run together and add straight into
+    // grad_input - no staging slab, no combine pass.  Up to 2 x 2 colours (a 3 x 3 kernel); SOMI_DCN_SLAB=1 keeps the slab form (A/B runs).
+    static const bool near_on = [] { const char *e = getenv("SOMI_DCN_NEAR"); return !(e && e[0] == '0'); }();
+    const char *slab_env = getenv("SOMI_DCN_SLAB");
+    pl.nch = (q.WH + GIN_TH * a.sh - 1) / (GIN_TH * a.sh);
+    pl.ncw = (q.WW + GIN_TW * a.sw - 1) / (GIN_TW * a.sw);
+    pl.coloured = pl.mfma && near_on && a.sh == 1 && a.sw == 1 && pl.nch * pl.ncw <= 4 && a.N <= 65535 && !(slab_env && slab_env[0] == '1');
     static const long cap_mb = [] { const char *e = getenv("SOMI_DCN_SLAB_MB"); const long v = e ? atol(e) : 1024; return v < 1 ? 1 : v; }();
     const size_t per_img = (size_t)a.G * q.tiles_h * q.tiles_w * q.WH * q.WW * a.Gc * sizeof(float);
     long c = (long)(((size_t)cap_mb << 20) / per_img);
-    pl.chunk = c < 1 ? 1 : (c > a.N ? a.N : (int)c);
+    pl.chunk = pl.coloured ? a.N : (c < 1 ? 1 : (c > a.N ? a.N : (int)c));    // the coloured form has no slab: the whole batch per launch
     pl.nchunks = (a.N + pl.chunk - 1) / pl.chunk;
-    pl.slab_bytes = ((size_t)pl.chunk * per_img + 255) / 256 * 256;
+    pl.slab_bytes = pl.coloured ? 0 : ((size_t)pl.chunk * per_img + 255) / 256 * 256;
     pl.near_bytes = ((size_t)pl.chunk * a.G * q.tiles_h * q.tiles_w * sizeof(unsigned) + 255) / 256 * 256;
     pl.any_bytes = ((size_t)pl.nchunks * sizeof(unsigned) + 255) / 256 * 256;
     pl.workspace_bytes = pl.slab_bytes + pl.near_bytes + pl.any_bytes + 256;
@@ -1389,16 +1490,35 @@ extern "C" int somi_dcnv3_backward_strided_f32(const float *input, const float *
         static const bool near_on = [] { const char *e = getenv("SOMI_DCN_NEAR"); return !(e && e[0] == '0'); }();
         q.near = (near_on && stride_h == 1 && stride_w == 1) ? reinterpret_cast<unsigned *>(wsb + slab) : nullptr;
         (void)hipMemsetAsync(any_words, 0, pl.any_bytes + 256, s);    // the per-chunk near_any words and the far-tap counter behind them
-        // B on the matrix cores for 32-wide groups when its LDS image fits (SOMI_DCN_GIN=exact keeps the list sums for comparisons)
-        const char *gsel = getenv("SOMI_DCN_GIN");
-        const size_t ncell_ = (size_t)q.WH * q.WW, recb = (size_t)GIN_TP * a.K * sizeof(RecM), gotb = (size_t)Gc * GMM_LD * sizeof(float);
-        const size_t mlds = ncell_ * GMM_LD * sizeof(float) + ((recb > gotb ? recb : gotb) + 15) / 16 * 16 + GMM_OVF_CAP * sizeof(OvfG);
-        const bool mfma = Gc == 32 && mlds <= 78 * 1024 + 512 && !(gsel && gsel[0] == 'e');
+        const size_t mlds = pl.mlds;
+        const bool mfma = pl.mfma;
+        if (pl.coloured) {
+            // B coloured: nch x ncw launches of disjoint windows adding straight into grad_input, then the far taps (atomics, a no-op unless a
+            // tile flagged some), then D (the near taps) - no slab, no combine, the whole batch per launch
+            q.staging = nullptr;
+            q.near_any = any_words;
+            q.nch = pl.nch;
+            q.ncw = pl.ncw;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_mfma_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)mlds);
+            for (int chh = 0; chh < pl.nch; ++chh)
+                for (int cww = 0; cww < pl.ncw; ++cww) {
+                    const int th = (q.tiles_h - chh + pl.nch - 1) / pl.nch, tw = (q.tiles_w - cww + pl.ncw - 1) / pl.ncw;
+                    if (th <= 0 || tw <= 0) continue;
+                    q.col_h = chh;
+                    q.col_w = cww;
+                    hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<32, true>), dim3(th * tw, N, G), dim3(GMM_NT), mlds, s, a, q);
+                }
+            const long items = (long)q.tiles_h * q.tiles_w * N * G, ditems = (long)((H + 7) / 8) * ((W + 7) / 8) * N * G;
+            hipLaunchKernelGGL((dcnv3_bwd_far_kernel<32>), dim3((unsigned)(items > 4096 ? 4096 : items)), dim3(256), 0, s, a, q);
+            hipLaunchKernelGGL((dcnv3_bwd_near_kernel<32>), dim3((unsigned)(ditems > 4096 ? 4096 : ditems)), dim3(256), 0, s, a, q);
+            return launch_status("somi_dcnv3_backward_f32 (windowed, coloured)");
+        }
 #define SOMI_GMM_LAUNCH(GC)                                                                                                      \
     do {                                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_mfma_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dcnv3_bwd_gin_mfma_kernel<GC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)mlds);                                                                               \
-        hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC>), grid, dim3(GMM_NT), mlds, s, c, q);                                    \
+        hipLaunchKernelGGL((dcnv3_bwd_gin_mfma_kernel<GC, false>), grid, dim3(GMM_NT), mlds, s, c, q);                             \
     } while (0)
         const size_t in_img = (size_t)H * W * a.C, out_img = (size_t)a.Ho * a.Wo * a.C, opix_img = (size_t)a.Ho * a.Wo;
         for (int n0 = 0; n0 < N; n0 += chunk) {

@@ -11,6 +11,7 @@
 #include "common.h"
 
 namespace somi {
+typedef int i32x4_ __attribute__((ext_vector_type(4)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -389,6 +390,144 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float *dz, int dz_
             one(*reinterpret_cast<const f32x4 *>(dz + p * dz_cs), *reinterpret_cast<const f32x4 *>(x + p * x_cs));
 }
 
+// ------------------------------------------------------------------------------------------------ backward with CBAM's pooled gradients folded in
+// The conv in front of a CBAM attention pair receives  dz_eff[b,p,c] = dz[b,p,c] + davg[b,c] / HW + [p == amaxp[b,c]] * dmax[b,c]:  the gradient
+// through the two multiplications (dz, written by cbam_bwd_chan) plus the global average / max pools' (models/common.py:339-358).  Round 3 added
+// the pooled part in a pass of its own (pool_bwd_add_kernel: read + write of the whole tensor, 2.3 ms per step) and found that folding it into
+// these kernels with their flat pixel walk cost more than the pass (a division and an index load per element).  Here both kernels are IMAGE-
+// ALIGNED instead - blockIdx.y = image, a thread keeps one channel quad of that image - so the pooled terms are four registers loaded once and
+// one compare per element; dz itself is only read.  Same sums as the plain kernels up to their order (chunks of one image instead of chunks
+// of the flat pixel range): deterministic, run-to-run bit-identical.
+template <bool SILU0>
+__global__ __launch_bounds__(256) void bn_act_bwd_stage1_pooled(const float *__restrict__ dz, int dz_cs, int dz_coff, const float *__restrict__ x,
+                                                                int x_cs, int x_coff, const float *__restrict__ scale,
+                                                                const float *__restrict__ shift, const float *__restrict__ mean, int act_rt,
+                                                                int order_rt, int HW, int C, float *__restrict__ p1, float *__restrict__ p2, int chunk,
+                                                                const float *__restrict__ davg, const float *__restrict__ dmax,
+                                                                const int *__restrict__ amaxp) {
+    __shared__ f32x4 l1[256], l2[256];
+    const int act = SILU0 ? (int)SOMI_ACT_SILU : act_rt, order = SILU0 ? 0 : order_rt;
+    const int b = blockIdx.y, C4 = C >> 2;
+    const int q0 = blockIdx.x * chunk, q1 = min(q0 + chunk, HW);
+    const long row = (long)b * gridDim.x + blockIdx.x;
+    const float inv_hw = 1.f / (float)HW;
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        const int c = (cq0 + cq) * 4;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (rr < rows_par) {
+            const f32x4 kavg = *reinterpret_cast<const f32x4 *>(davg + (long)b * C + c) * inv_hw;
+            const f32x4 kmax = *reinterpret_cast<const f32x4 *>(dmax + (long)b * C + c);
+            const i32x4_ am = *reinterpret_cast<const i32x4_ *>(amaxp + (long)b * C + c);
+            const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c), sc = *reinterpret_cast<const f32x4 *>(scale + c),
+                        sh = *reinterpret_cast<const f32x4 *>(shift + c);
+#pragma unroll 4
+            for (int pl = q0 + rr; pl < q1; pl += rows_par) {            // four pixels' loads go out before the first sum
+                const long p = (long)b * HW + pl;
+                f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c) + kavg;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (am[e] == pl) g[e] += kmax[e];
+                f32x4 d, w;
+                if (order == 0) {
+                    const f32x4 u = v * sc + sh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = g[e] * act_grad(u[e], act);
+                    w = v;
+                } else {
+                    d = g;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = act_fwd(v[e], act);
+                }
+                s1 += d;
+                s2 += d * (w - mu);
+            }
+        }
+        l1[threadIdx.x] = s1;
+        l2[threadIdx.x] = s2;
+        __syncthreads();
+        if (threadIdx.x < ncq) {
+            for (int r2 = 1; r2 < rows_par; ++r2) { s1 += l1[r2 * ncq + cq]; s2 += l2[r2 * ncq + cq]; }
+            *reinterpret_cast<f32x4 *>(p1 + row * C + c) = s1;
+            *reinterpret_cast<f32x4 *>(p2 + row * C + c) = s2;
+        }
+        __syncthreads();
+    }
+}
+// grid (gx, B), gx * 256 a multiple of C / 4 (ew_grid_img): a thread keeps one channel quad of image blockIdx.y and walks its pixels EW_U at a time
+template <bool SILU0>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_pooled(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               const float *__restrict__ mean, const float *__restrict__ coefA,
+                                                               const float *__restrict__ coefB, const float *__restrict__ coefC, int act_rt,
+                                                               int order_rt, float *dx, int dx_cs, int dx_coff, int HW, int C,
+                                                               const float *__restrict__ davg, const float *__restrict__ dmax,
+                                                               const int *__restrict__ amaxp) {
+    const int act = SILU0 ? (int)SOMI_ACT_SILU : act_rt, order = SILU0 ? 0 : order_rt;
+    const unsigned C4 = (unsigned)C >> 2, nthreads = gridDim.x * 256u, t = blockIdx.x * 256u + threadIdx.x;
+    const int c = (int)(t % C4) * 4, b = blockIdx.y, pstep = (int)(nthreads / C4);
+    const f32x4 A = *reinterpret_cast<const f32x4 *>(coefA + c), Bc = *reinterpret_cast<const f32x4 *>(coefB + c),
+                Cc = *reinterpret_cast<const f32x4 *>(coefC + c), M = *reinterpret_cast<const f32x4 *>(mean + c),
+                sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+    const f32x4 kavg = *reinterpret_cast<const f32x4 *>(davg + (long)b * C + c) * (1.f / (float)HW);
+    const f32x4 kmax = *reinterpret_cast<const f32x4 *>(dmax + (long)b * C + c);
+    const i32x4_ am = *reinterpret_cast<const i32x4_ *>(amaxp + (long)b * C + c);
+    dz += (long)b * HW * dz_cs + dz_coff + c;
+    x += (long)b * HW * x_cs + x_coff + c;
+    dx += (long)b * HW * dx_cs + dx_coff + c;
+    auto one = [&](f32x4 g, const f32x4 v, int pl) {
+        g += kavg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (am[e] == pl) g[e] += kmax[e];
+        f32x4 r;
+        if (order == 0) {
+            const f32x4 u = v * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = A[e] * (g[e] * act_grad(u[e], act)) + Bc[e] * (v[e] - M[e]) + Cc[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (A[e] * g[e] + Bc[e] * (act_fwd(v[e], act) - M[e]) + Cc[e]) * act_grad(v[e], act);
+        }
+        return r;
+    };
+    int p = (int)(t / C4);
+    for (; p + (EW_U - 1) * pstep < HW; p += EW_U * pstep) {
+        f32x4 g[EW_U], v[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            g[u] = *reinterpret_cast<const f32x4 *>(dz + (long)(p + u * pstep) * dz_cs);
+            v[u] = *reinterpret_cast<const f32x4 *>(x + (long)(p + u * pstep) * x_cs);
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) *reinterpret_cast<f32x4 *>(dx + (long)(p + u * pstep) * dx_cs) = one(g[u], v[u], p + u * pstep);
+    }
+    for (; p < HW; p += pstep)
+        *reinterpret_cast<f32x4 *>(dx + (long)p * dx_cs) =
+            one(*reinterpret_cast<const f32x4 *>(dz + (long)p * dz_cs), *reinterpret_cast<const f32x4 *>(x + (long)p * x_cs), p);
+}
+// pixels of one image per stage-1 workgroup of the pooled form: the batch's partial rows stay at <= 1024 like red_chunk's
+static inline int red_chunk_img(int B, int HW) {
+    const int per = B >= 1024 ? 1 : 1024 / B;
+    int c = (HW + per - 1) / per;
+    c = (c + 31) / 32 * 32;
+    return c < 32 ? 32 : c;
+}
+// workgroups per image of an image-aligned sweep: one item per thread up to `cap` workgroups over the whole batch, thread count a multiple of C/4
+static inline int ew_grid_img(int B, int HW, int C, int cap) {
+    const int C4 = C / 4;
+    int a = C4, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const long mult = C4 / a;
+    long g = ((long)HW * C4 + 255) / 256, per = cap / (B > 0 ? B : 1);
+    if (per < 1) per = 1;
+    g = g < 1 ? 1 : (g > per ? per : g);
+    return (int)((g + mult - 1) / mult * mult);
+}
+
 // per-channel sum over pixels of a tensor (bias gradients): out[c] += sum_p x[p,c]
 __global__ __launch_bounds__(256) void chan_sum_stage1(const float *__restrict__ x, int cs, int coff, long npix, int C, float *__restrict__ p1,
                                                        float *__restrict__ p2, int chunk) {
@@ -547,6 +686,44 @@ extern "C" int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_
                        dgamma, dbeta);
     launch_bwd_apply(dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, npix, C, s);
     return launch_status("somi_bn_act_backward_nhwc_f32");
+}
+
+extern "C" int somi_bn_pooled_rows(int B, int HW) {
+    if (B <= 0 || HW <= 0) return 0;
+    const int chunk = red_chunk_img(B, HW);
+    return B * ((HW + chunk - 1) / chunk);
+}
+
+extern "C" int somi_bn_act_backward_pooled_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
+                                                    const float *rstd, const float *scale, const float *shift, int act, int order,
+                                                    const float *davg, const float *dmax, const int32_t *amaxp, float *dx, int dx_cs, int dx_coff,
+                                                    float *dgamma, float *dbeta, int B, int HW, int C, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(slice_ok(dz, dz_cs, dz_coff, C) && slice_ok(x, x_cs, x_coff, C) && slice_ok(dx, dx_cs, dx_coff, C) && mean && rstd && scale &&
+                     shift && workspace && B > 0 && HW > 0 && C % 4 == 0 && (order == 0 || order == 1), SOMI_EINVAL,
+                 "bn act backward (pooled): bad arguments");
+    SOMI_REQUIRE(davg && dmax && amaxp && aligned16(davg) && aligned16(dmax) && aligned16(amaxp) && aligned16(mean) && aligned16(scale) && aligned16(shift),
+                 SOMI_EINVAL, "bn act backward (pooled): davg / dmax / amaxp (B,C) and the per-channel vectors must be 16 B aligned");
+    SOMI_REQUIRE(B <= 65535 && (long)B * HW < (1L << 31), SOMI_EINVAL, "bn act backward (pooled): batch beyond the grid's y range");
+    const int chunk = red_chunk_img(B, HW), nimg = (HW + chunk - 1) / chunk, rows = B * nimg;
+    const size_t cpad = ((size_t)C + 3) / 4 * 4;
+    float *p1 = workspace, *p2 = p1 + (size_t)rows * C, *cA = p2 + (size_t)rows * C, *cB = cA + cpad, *cC = cB + cpad;
+    hipStream_t s = (hipStream_t)stream;
+    const bool silu0 = act == SOMI_ACT_SILU && order == 0;
+    if (silu0)
+        hipLaunchKernelGGL(bn_act_bwd_stage1_pooled<true>, dim3(nimg, B), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act,
+                           order, HW, C, p1, p2, chunk, davg, dmax, amaxp);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_stage1_pooled<false>, dim3(nimg, B), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff, scale, shift, mean, act,
+                           order, HW, C, p1, p2, chunk, davg, dmax, amaxp);
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, p1, p2, rows, C, (long)B * HW, mean, rstd, scale, 1, cA, cB, cC,
+                       dgamma, dbeta);
+    if (silu0)
+        hipLaunchKernelGGL(bn_act_bwd_apply_pooled<true>, dim3(ew_grid_img(B, HW, C, WG_APPLY), B), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs, x_coff,
+                           scale, shift, mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, HW, C, davg, dmax, amaxp);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_pooled<false>, dim3(ew_grid_img(B, HW, C, WG_APPLY_RT), B), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs,
+                           x_coff, scale, shift, mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, HW, C, davg, dmax, amaxp);
+    return launch_status("somi_bn_act_backward_pooled_nhwc_f32");
 }
 
 extern "C" int somi_bn_local_sums_f64(const float *x, int x_cs, int x_coff, long npix, int C, const float *pivot, const float *part_sum,

@@ -110,6 +110,8 @@ SIGNATURES = {
     'somi_bn_act_backward_apply_sync_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, P, P, I, P, I, I, P, P, C.c_long, I, P, S]),
     'somi_chan_affine_act_nhwc_f32': (I, [P, I, I, P, P, I, I, P, I, I, C.c_long, I, P, I, I, S]),
     'somi_bn_act_backward_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, P, I, I, P, P, C.c_long, I, P, S]),
+    'somi_bn_pooled_rows': (I, [I, I]),
+    'somi_bn_act_backward_pooled_nhwc_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, P, P, P, P, I, I, P, P, I, I, I, P, S]),
     'somi_add_nhwc_f32': (I, [P, I, I, P, I, I, P, I, I, C.c_long, I, S]),
     'somi_chan_sum_nhwc_f32': (I, [P, I, I, C.c_long, I, P, P, S]),
     'somi_img_nchunk': (I, [I]),

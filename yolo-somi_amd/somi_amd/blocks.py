@@ -225,10 +225,12 @@ class Conv(_Packed):
         self.__dict__['_ctx'] = (x, y, mean, rstd, scale, shift, pk)
         return Act(out.t, out.coff, c2)
 
-    def backward(self, dz, dx_out=None, accumulate=False, need_dx=True, also_add=None):
+    def backward(self, dz, dx_out=None, accumulate=False, need_dx=True, also_add=None, pooled=None):
         """dz: gradient w.r.t. this block's output (Act).  Returns the gradient w.r.t. the input as an Act (written into
         dx_out if given, added to it if accumulate; `also_add` is a further Act added in the same pass - a shortcut's
-        gradient).  Parameter gradients are accumulated into .grad (reference layout)."""
+        gradient).  Parameter gradients are accumulated into .grad (reference layout).
+        pooled: (davg, dmax, amaxp) of a channel attention that pooled this block's output (ops.bn_act_backward): its gradient joins dz inside
+        the BatchNorm backward kernels."""
         x, y, mean, rstd, scale, shift, pk = self.__dict__.pop('_ctx')
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         c1, c2, cp = self.conv.in_channels, self.conv.out_channels, pad4(self.conv.out_channels)
@@ -240,10 +242,10 @@ class Conv(_Packed):
         gw, gb = self.bn.weight.grad, self.bn.bias.grad
         direct = cp == c2 and gw is not None and gb is not None and gw.is_contiguous() and gb.is_contiguous() and gw.device == dev
         if direct:                                                # the kernel accumulates straight into the gradient buffers
-            ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, gw, gb)
+            ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, gw, gb, pooled=pooled)
         else:
             dgam, dbet = torch.zeros(cp, device=dev), torch.zeros(cp, device=dev)
-            ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, dgam, dbet)
+            ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, dgam, dbet, pooled=pooled)
             _acc_grad(self.bn.weight, dgam[:c2])
             _acc_grad(self.bn.bias, dbet[:c2])
         B, H, W, _ = x.shape
@@ -349,8 +351,9 @@ class ChannelAttentionModule(_Packed):
             self.__dict__['_ctx'] = (x, avg, mx, ca, (W1, b1, W2, b2))
         return ca
 
-    def backward(self, dca, dt, amaxp=None):
-        """dca (B,C): gradient w.r.t. the attention vector; adds the pooled-input gradient into dt (Act) in place.
+    def backward(self, dca, dt, amaxp=None, defer=False):
+        """dca (B,C): gradient w.r.t. the attention vector; adds the pooled-input gradient into dt (Act) in place - or, defer=True, returns
+        (davg, dmax, amaxp) for the producer's BatchNorm backward to fold in (Conv.backward(pooled=...)) and leaves dt alone.
         amaxp (B,C) int32: first pixel of every channel's spatial maximum when the caller already has it (the CBAM backward takes it in its own
         pass over x); else it is found here."""
         x, avg, mx, ca, (W1, b1, W2, b2) = self.__dict__.pop('_ctx')
@@ -363,6 +366,8 @@ class ChannelAttentionModule(_Packed):
                 _acc_grad(prm, gr)
         if amaxp is None:
             amaxp = ops.pool_argmax(x.t, x.c, x.coff)
+        if defer:
+            return davg, dmax, amaxp
         ops.pool_backward_add_(dt.t, dt.coff, x.c, davg, dmax, amaxp)
 
 
@@ -436,10 +441,10 @@ class CBAMBottleneck(nn.Module):
         x, t = self.__dict__.pop('_ctx')
         d = self.cv2.backward(dout)                               # d(t*ca*sa)
         dca, amaxp = self.spatial_attention.backward(d.t)        # d.t now holds the direct part of dt
-        self.channel_attention.backward(dca, d, amaxp)            # + pooled paths
+        pooled = self.channel_attention.backward(dca, d, amaxp, defer=True)   # the pooled paths join d inside cv1's BatchNorm backward
         c1 = self.cv1.conv.in_channels
         fuse = self.add and pad4(c1) == c1 and dout.coff % 4 == 0  # the shortcut's gradient rides the dgrad epilogue
-        self.cv1.backward(d, dx_out=dx_out, accumulate=True, also_add=dout if fuse else None)
+        self.cv1.backward(d, dx_out=dx_out, accumulate=True, also_add=dout if fuse else None, pooled=pooled)
         if self.add and not fuse:
             ops.add_(dx_out.t, dx_out.coff, dout.t, dout.coff, x.c)
         return dx_out

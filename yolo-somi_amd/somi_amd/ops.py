@@ -24,6 +24,7 @@ _CONV_WS = {}
 # claim is made on), 1 bf16 operands, 2 bf16x3 split (somi_conv_desc.prec).  train.TrainStep(amp=...) / bench.py --amp set it.
 CONV_PREC = 0
 PREC = {None: 0, 'f32': 0, 'bf16': 1, 'bf16x3': 2}
+BN_POOLED = os.environ.get('SOMI_BN_POOLED', '1') != '0'    # 0: CBAM's pooled gradients are added by a pass of their own (round-3 form; A/B runs)
 
 
 def _conv_workspace(d, dev):
@@ -678,8 +679,23 @@ def pack_dgrad_weights(w_packed, cout, taps, cin):
 
 
 def bn_act_backward(dz, dz_coff, x, x_coff, c, mean, rstd, scale, shift, act, order, batch_stats, dx, dx_coff=0, dgamma=None,
-                    dbeta=None):
+                    dbeta=None, pooled=None):
+    """pooled = (davg, dmax, amaxp), each (B, c): the gradient of a channel attention's global average / max pools over this tensor, i.e.
+    dz_eff = dz + davg / HW + [pixel == amaxp] * dmax.  The image-aligned kernels take it on the fly (dz is only read); under sync-BN - whose
+    reduce / apply entries have no such form - it is added to dz in place by a pass of its own first."""
     n = _npix(x)
+    if pooled is not None:
+        davg, dmax, amaxp = pooled
+        if BN_POOLED and SYNC_BN is None and batch_stats and davg.shape[1] == c and x.dim() == 4:
+            B, HW = x.shape[0], x.shape[1] * x.shape[2]
+            L = _lib.lib()
+            ws = torch.empty(2 * L.somi_bn_pooled_rows(B, HW) * c + 3 * ((c + 3) // 4 * 4), device=x.device, dtype=torch.float32)
+            check(L.somi_bn_act_backward_pooled_nhwc_f32(_ptr(_f32c(dz)), dz.shape[3], dz_coff, _ptr(_f32c(x)), x.shape[3], x_coff, _ptr(mean),
+                                                         _ptr(rstd), _ptr(scale), _ptr(shift), ACT[act], order, _ptr(davg), _ptr(dmax),
+                                                         _ptr(amaxp), _ptr(_f32c(dx)), dx.shape[3], dx_coff, _ptr(dgamma), _ptr(dbeta), B, HW, c,
+                                                         _ptr(ws), _stream()), 'bn_act_backward_pooled')
+            return dx
+        pool_backward_add_(dz, dz_coff, davg.shape[1], davg, dmax, amaxp)
     if SYNC_BN is not None and batch_stats:
         L = _lib.lib()
         dzc, xc, dxc = _f32c(dz), _f32c(x), _f32c(dx)
