@@ -31,18 +31,22 @@ for sub in ('fetch', 'write', 'sq'):
     for f in glob.glob(f'{d}/{sub}/**/*_counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             acc[r['Kernel_Name'][:80]][r['Counter_Name']].append(float(r['Counter_Value']))
+            if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':            # wall time of the same dispatches: sustained clock = GUI cycles / 8 XCDs / time
+                acc[r['Kernel_Name'][:80]]['_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 print('# PMC passes (separate runs, counters only): mean per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB;')
 print('# hbm_read_MB applies the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read).')
+print('# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8); GHz = GRBM_GUI_ACTIVE / 8 / wall time of the dispatches (sq pass).')
 print(f'{"kernel":82s} {"n":>5s} {"hbm_read_MB":>12s} {"hbm_write_MB":>12s} {"mfma_busy":>10s} {"GHz":>6s}')
 order = sorted(acc.items(), key=lambda kv: -sum(kv[1].get('SQ_VALU_MFMA_BUSY_CYCLES', [0])) - sum(kv[1].get('FETCH_SIZE', [0])))
-for k, c in order[:14]:
+for k, c in order[:16]:
     n = len(c.get('FETCH_SIZE', c.get('WRITE_SIZE', [0])))
     rd = 2 * sum(c.get('FETCH_SIZE', [0])) / max(n, 1) * 1024 / 1e6
     wr = sum(c.get('WRITE_SIZE', [0])) / max(len(c.get('WRITE_SIZE', [0])), 1) * 1024 / 1e6
-    busy = ''
+    busy = ghz = ''
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and sum(c['GRBM_GUI_ACTIVE']) > 0:
         busy = f'{sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(c["GRBM_GUI_ACTIVE"]) / 8 * 1024):.3f}'
-    print(f'{k:82s} {n:5d} {rd:12.1f} {wr:12.1f} {busy:>10s}')
+        ghz = f'{sum(c["GRBM_GUI_ACTIVE"]) / 8 / max(sum(c["_ns"]), 1.0):.2f}'
+    print(f'{k:82s} {n:5d} {rd:12.1f} {wr:12.1f} {busy:>10s} {ghz:>6s}')
 
 if len(sys.argv) > 2:
     import json
