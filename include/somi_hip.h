@@ -384,6 +384,12 @@ int somi_img_nchunk(int HW);
 /* A: dlogit[p] = (sum_c dt2*t*ca) * sa*(1-sa), amaxc[p] = argmax_c(t*ca) */
 int somi_cbam_bwd_pixel_f32(const float *dt2, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
                             const float *sa, float *dlogit, int32_t *amaxc, int B, int HW, int C, somi_stream_t stream);
+/* A + D: as somi_cbam_bwd_pixel_f32, and amaxp[b,c] = first pixel index p with t[b,p,c] == t_max[b,c], where t_max (B,C) is the spatial maximum the
+ * forward pooled from the same tensor (somi_global_pool_nhwc_f32's out_max) - the arg-max of the channel attention's max-pool without the pass
+ * over t that somi_pool_argmax_nhwc_f32 takes (integer min over the matching pixels: order-independent). */
+int somi_cbam_bwd_pixel_argmax_f32(const float *dt2, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
+                                   const float *sa, const float *t_max, float *dlogit, int32_t *amaxc, int32_t *amaxp, int B, int HW, int C,
+                                   somi_stream_t stream);
 /* B: gradient of sigmoid's argument through the k x k conv: dstats (B,H,W,2); dw [k][k][2] and dbias ACCUMULATED.
  * workspace: ceil(B*H*W/1024) * (2*k*k+1) floats */
 int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const float *w, float *dstats, float *dw_accumulate,
@@ -393,11 +399,6 @@ int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const flo
 int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
                            const float *sa, const float *dstats, const int32_t *amaxc, float *dca, float *workspace, int B, int HW,
                            int C, somi_stream_t stream);
-/* C + D in one pass over t: as somi_cbam_bwd_chan_f32, and amaxp[b,c] = first pixel index of max_p t[b,p,c] (what somi_pool_argmax_nhwc_f32
- * computes from a pass of its own).  workspace: 3*B*nchunk*C 4-byte words */
-int somi_cbam_bwd_chan_argmax_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
-                                  const float *sa, const float *dstats, const int32_t *amaxc, float *dca, int32_t *amaxp, float *workspace,
-                                  int B, int HW, int C, somi_stream_t stream);
 /* D: amaxp[b,c] = first pixel index of max_p x[b,p,c]. workspace: 2*B*nchunk*C 4-byte words */
 int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int32_t *amaxp, void *workspace,
                               somi_stream_t stream);

@@ -91,10 +91,10 @@ def main():
     log = {'cbam': [], 'mlp': [], 'pool': [], 'bn_pooled': []}
     real_cbam, real_mlp, real_pool, real_bn = ops.cbam_backward, ops.attn_mlp_backward, ops.pool_backward_add_, ops.bn_act_backward
 
-    def cbam(dt2, t, t_coff, c_, ca, sa, stats, w7, k_, dw7, db7):
+    def cbam(dt2, t, t_coff, c_, ca, sa, stats, w7, k_, dw7, db7, t_max=None):
         before = dt2.clone()
         ins = dict(ca=ca.clone(), sa=sa.clone(), stats=stats.clone(), w7=w7.clone())
-        out = real_cbam(dt2, t, t_coff, c_, ca, sa, stats, w7, k_, dw7, db7)
+        out = real_cbam(dt2, t, t_coff, c_, ca, sa, stats, w7, k_, dw7, db7, t_max=t_max)
         # the same chain with torch ops on the device, from the very tensors the kernels were given
         import torch.nn.functional as F
         v = t * ca[:, None, None, :]

@@ -25,7 +25,8 @@ static inline int ew_grid(long items) {
 // ------------------------------------------------------------------------------------------------ A
 __global__ __launch_bounds__(256) void cbam_bwd_pixel_kernel(const float *__restrict__ dt2, int d_cs, int d_coff, const float *__restrict__ t,
                                                              int t_cs, int t_coff, const float *__restrict__ ca, const float *__restrict__ sa,
-                                                             float *__restrict__ dlogit, int *__restrict__ amaxc, int B, int HW, int C) {
+                                                             float *__restrict__ dlogit, int *__restrict__ amaxc, int B, int HW, int C,
+                                                             const float *__restrict__ mxv, int *__restrict__ amaxp) {
     // LG lanes per pixel: the smallest power of two that covers the C / 4 channel quads (64 channels: 16 lanes, four pixels per wave and trip -
     // a whole wave per pixel left 48 lanes idle there and one 256-byte row in flight per wave)
     int LG = 64;
@@ -39,8 +40,19 @@ __global__ __launch_bounds__(256) void cbam_bwd_pixel_kernel(const float *__rest
         float s = 0.f, m = -__builtin_huge_valf();
         int mi = 0x7fffffff;
         for (int c = sl * 4; c < C; c += LG * 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + c) * *reinterpret_cast<const f32x4 *>(cr + c);
+            const f32x4 tq = *reinterpret_cast<const f32x4 *>(tr + c);
+            const f32x4 v = tq * *reinterpret_cast<const f32x4 *>(cr + c);
             const f32x4 g = *reinterpret_cast<const f32x4 *>(dr + c);
+            if (mxv) {
+                // step D without a pass of its own: mxv[b][c] is the channel's spatial maximum the forward pooled from these very values, so
+                // the pixels that hold it are found by an exact compare; the FIRST of them (torch's rule) by an integer min - a handful
+                // of atomics per (image, channel), order-independent.  (Tracking a running arg-max inside kernel C instead was measured:
+                // 59 -> 90 us per launch for that bandwidth-bound kernel, more than the 25 us pass it replaced.)
+                const f32x4 mq = *reinterpret_cast<const f32x4 *>(mxv + b * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (tq[e] == mq[e]) atomicMin(amaxp + b * C + c + e, (int)(p - b * HW));
+            }
             s += (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -188,17 +200,11 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_final(const float
 
 // ------------------------------------------------------------------------------------------------ C
 // grid (nchunk, B): lanes over channel quads, rows over the chunk's pixels; writes dt in place of dt2 and the partial dca sums
-// AMAX: also step D - the chunk's maximum of t per channel and the first pixel that holds it (pmax / pidx, folded by pool_argmax_stage2):
-// this kernel reads all of t anyway, so the separate pass of pool_argmax_stage1 over t disappears (round 4)
-template <bool AMAX>
 __global__ __launch_bounds__(256) void cbam_bwd_chan_kernel(float *__restrict__ dt2, int d_cs, int d_coff, const float *__restrict__ t, int t_cs,
                                                             int t_coff, const float *__restrict__ ca, const float *__restrict__ sa,
                                                             const float *__restrict__ dstats, const int *__restrict__ amaxc,
-                                                            float *__restrict__ part, int HW, int C, int nchunk, float *__restrict__ pmax,
-                                                            int *__restrict__ pidx) {
+                                                            float *__restrict__ part, int HW, int C, int nchunk) {
     __shared__ f32x4 l1[256];
-    __shared__ float lm[AMAX ? 256 : 1][4];
-    __shared__ int li[AMAX ? 256 : 1][4];
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int C4 = C >> 2;
     const int p0 = chunk * IMG_CHUNK, p1 = min(p0 + IMG_CHUNK, HW);
@@ -209,19 +215,9 @@ __global__ __launch_bounds__(256) void cbam_bwd_chan_kernel(float *__restrict__ 
         const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
         const int c = (cq0 + cq) * 4;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
-        float mx[4];
-        int mxi[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { mx[e] = -__builtin_huge_valf(); mxi[e] = 0x7fffffff; }
         if (rr < rows_par) {
             const f32x4 cav = *reinterpret_cast<const f32x4 *>(ca + (long)b * C + c);
             auto one = [&](long p, const f32x4 tv, f32x4 g, const float2 ds, int am, float sav) {
-                if constexpr (AMAX) {                                    // pixels arrive in ascending order: '>' keeps the first maximum
-                    const int pl_ = (int)(p - (long)b * HW);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tv[e] > mx[e]) { mx[e] = tv[e]; mxi[e] = pl_; }
-                }
                 g = g * sav + ds.x * inv_c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -254,26 +250,10 @@ __global__ __launch_bounds__(256) void cbam_bwd_chan_kernel(float *__restrict__ 
             }
         }
         l1[threadIdx.x] = s1;
-        if constexpr (AMAX) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { lm[threadIdx.x][e] = mx[e]; li[threadIdx.x][e] = mxi[e]; }
-        }
         __syncthreads();
         if (threadIdx.x < ncq) {
             for (int r2 = 1; r2 < rows_par; ++r2) s1 += l1[r2 * ncq + cq];
             *reinterpret_cast<f32x4 *>(part + ((long)b * nchunk + chunk) * C + c) = s1;
-            if constexpr (AMAX) {                                        // rows interleave pixels: merge by (value, lowest pixel index)
-                for (int r2 = 1; r2 < rows_par; ++r2)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float om = lm[r2 * ncq + cq][e];
-                        const int oi = li[r2 * ncq + cq][e];
-                        if (om > mx[e] || (om == mx[e] && oi < mxi[e])) { mx[e] = om; mxi[e] = oi; }
-                    }
-                const long o = ((long)b * nchunk + chunk) * C + c;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { pmax[o + e] = mx[e]; pidx[o + e] = mxi[e]; }
-            }
         }
         __syncthreads();
     }
@@ -542,8 +522,20 @@ extern "C" int somi_cbam_bwd_pixel_f32(const float *dt2, int d_cs, int d_coff, c
     SOMI_REQUIRE(sl_ok(dt2, d_cs, d_coff, C) && sl_ok(t, t_cs, t_coff, C) && ca && sa && dlogit && amaxc && B > 0 && HW > 0 && C % 4 == 0 &&
                      aligned16(ca), SOMI_EINVAL, "cbam bwd pixel: bad arguments");
     hipLaunchKernelGGL(cbam_bwd_pixel_kernel, dim3(ew_grid((long)B * HW * 64)), dim3(256), 0, (hipStream_t)stream, dt2, d_cs, d_coff, t, t_cs,
-                       t_coff, ca, sa, dlogit, amaxc, B, HW, C);
+                       t_coff, ca, sa, dlogit, amaxc, B, HW, C, nullptr, nullptr);
     return launch_status("somi_cbam_bwd_pixel_f32");
+}
+
+extern "C" int somi_cbam_bwd_pixel_argmax_f32(const float *dt2, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
+                                              const float *sa, const float *t_max, float *dlogit, int32_t *amaxc, int32_t *amaxp, int B, int HW,
+                                              int C, somi_stream_t stream) {
+    SOMI_REQUIRE(sl_ok(dt2, d_cs, d_coff, C) && sl_ok(t, t_cs, t_coff, C) && ca && sa && dlogit && amaxc && t_max && amaxp && B > 0 && HW > 0 &&
+                     C % 4 == 0 && aligned16(ca) && aligned16(t_max), SOMI_EINVAL, "cbam bwd pixel + argmax: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(amaxp, 0x7f, (size_t)B * C * sizeof(int32_t), s);          // 0x7f7f7f7f: above every pixel index, the integer min's identity here
+    hipLaunchKernelGGL(cbam_bwd_pixel_kernel, dim3(ew_grid((long)B * HW * 64)), dim3(256), 0, s, dt2, d_cs, d_coff, t, t_cs, t_coff, ca, sa, dlogit,
+                       amaxc, B, HW, C, t_max, amaxp);
+    return launch_status("somi_cbam_bwd_pixel_argmax_f32");
 }
 
 extern "C" int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const float *w, float *dstats, float *dw_accumulate,
@@ -575,27 +567,10 @@ extern "C" int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, co
                      HW > 0 && C % 4 == 0 && aligned16(ca) && aligned16(workspace), SOMI_EINVAL, "cbam bwd chan: bad arguments");
     const int nchunk = somi_img_nchunk(HW);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cbam_bwd_chan_kernel<false>, dim3(nchunk, B), dim3(256), 0, s, dt2_inout, d_cs, d_coff, t, t_cs, t_coff, ca, sa, dstats, amaxc,
-                       workspace, HW, C, nchunk, nullptr, nullptr);
+    hipLaunchKernelGGL(cbam_bwd_chan_kernel, dim3(nchunk, B), dim3(256), 0, s, dt2_inout, d_cs, d_coff, t, t_cs, t_coff, ca, sa, dstats, amaxc,
+                       workspace, HW, C, nchunk);
     hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, workspace, nchunk, C, B, dca);
     return launch_status("somi_cbam_bwd_chan_f32");
-}
-
-extern "C" int somi_cbam_bwd_chan_argmax_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
-                                             const float *sa, const float *dstats, const int32_t *amaxc, float *dca, int32_t *amaxp,
-                                             float *workspace, int B, int HW, int C, somi_stream_t stream) {
-    SOMI_REQUIRE(sl_ok(dt2_inout, d_cs, d_coff, C) && sl_ok(t, t_cs, t_coff, C) && ca && sa && dstats && amaxc && dca && amaxp && workspace && B > 0 &&
-                     HW > 0 && C % 4 == 0 && aligned16(ca) && aligned16(workspace), SOMI_EINVAL, "cbam bwd chan + argmax: bad arguments");
-    const int nchunk = somi_img_nchunk(HW);
-    hipStream_t s = (hipStream_t)stream;
-    const size_t n = (size_t)B * nchunk * C;                       // workspace: dca partials | chunk maxima | chunk arg-maxima
-    float *pm = workspace + n;
-    int *pi = reinterpret_cast<int *>(pm + n);
-    hipLaunchKernelGGL(cbam_bwd_chan_kernel<true>, dim3(nchunk, B), dim3(256), 0, s, dt2_inout, d_cs, d_coff, t, t_cs, t_coff, ca, sa, dstats, amaxc,
-                       workspace, HW, C, nchunk, pm, pi);
-    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, workspace, nchunk, C, B, dca);
-    hipLaunchKernelGGL(pool_argmax_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, pm, pi, nchunk, C, B, amaxp);
-    return launch_status("somi_cbam_bwd_chan_argmax_f32");
 }
 
 extern "C" int somi_pool_argmax_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int32_t *amaxp, void *workspace,

@@ -116,9 +116,9 @@ SIGNATURES = {
     'somi_chan_sum_nhwc_f32': (I, [P, I, I, C.c_long, I, P, P, S]),
     'somi_img_nchunk': (I, [I]),
     'somi_cbam_bwd_pixel_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, S]),
+    'somi_cbam_bwd_pixel_argmax_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, I, I, I, S]),
     'somi_spatial_attn_bwd_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, S]),
     'somi_cbam_bwd_chan_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, I, I, I, S]),
-    'somi_cbam_bwd_chan_argmax_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, I, S]),
     'somi_pool_argmax_nhwc_f32': (I, [P, I, I, I, I, I, P, P, S]),
     'somi_attn_mlp_bwd_workspace_floats': (Z, [I, I, I]),
     'somi_attn_mlp_bwd_f32': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),

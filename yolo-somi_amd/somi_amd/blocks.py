@@ -401,13 +401,14 @@ class SpatialAttentionModule(_Packed):
         self.__dict__['_ctx'] = (x, ca, stats, sa, w)
         return Act(out, 0, x.c)
 
-    def backward(self, dt2):
+    def backward(self, dt2, t_max=None):
         """dt2: gradient tensor w.r.t. x*ca*sa (whole tensor, modified in place into the x-gradient through both products and
-        the spatial branch).  Returns dca (B,C) and amaxp (B,C): the pixel of each channel's spatial maximum of x (for the max-pool's gradient)."""
+        the spatial branch).  Returns dca (B,C) and - with t_max (B,C), the spatial maximum of x the channel attention pooled - amaxp (B,C): the
+        first pixel holding each channel's maximum (for the max-pool's gradient), else None."""
         x, ca, stats, sa, w = self.__dict__.pop('_ctx')
         k = self.cv1.kernel_size[0]
         dw, db = torch.zeros_like(w), torch.zeros(1, device=w.device)
-        dca, amaxp = ops.cbam_backward(dt2, x.t, x.coff, x.c, ca, sa, stats, w, k, dw, db)
+        dca, amaxp = ops.cbam_backward(dt2, x.t, x.coff, x.c, ca, sa, stats, w, k, dw, db, t_max=t_max)
         _acc_grad(self.cv1.weight, dw.permute(2, 0, 1).unsqueeze(0))          # [k][k][2] -> (1,2,k,k)
         _acc_grad(self.cv1.bias, db)
         return dca, amaxp
@@ -440,7 +441,8 @@ class CBAMBottleneck(nn.Module):
         C2f gradient buffer that already holds the gradient of the input's other consumers)."""
         x, t = self.__dict__.pop('_ctx')
         d = self.cv2.backward(dout)                               # d(t*ca*sa)
-        dca, amaxp = self.spatial_attention.backward(d.t)        # d.t now holds the direct part of dt
+        # d.t then holds the direct part of dt; the channel attention's pooled maximum lets the same pass find its arg-max pixels
+        dca, amaxp = self.spatial_attention.backward(d.t, t_max=self.channel_attention.__dict__['_ctx'][2])
         pooled = self.channel_attention.backward(dca, d, amaxp, defer=True)   # the pooled paths join d inside cv1's BatchNorm backward
         c1 = self.cv1.conv.in_channels
         fuse = self.add and pad4(c1) == c1 and dout.coff % 4 == 0  # the shortcut's gradient rides the dgrad epilogue

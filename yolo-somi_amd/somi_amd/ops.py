@@ -733,26 +733,32 @@ def add_(a, a_coff, b, b_coff, c, out=None, out_coff=None):
     return out
 
 
-def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7):
+def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7, t_max=None):
     """Steps A-C of train_blocks.hip: turns d(t*ca*sa) (dt2, whole tensor, modified in place) into the part of dt that flows
-    through the two multiplications and the spatial branch; returns dca (B,C) and amaxp (B,C) int32 - the first pixel of each channel's
-    spatial maximum of t (step D, taken in the same pass).  dw7 / db7 are accumulated."""
+    through the two multiplications and the spatial branch; returns dca (B,C) and, when t_max (B,C) - the spatial maximum of t the forward pooled -
+    is given, amaxp (B,C) int32: the first pixel that holds each channel's maximum (step D, found by value inside step A's pass), else None.
+    dw7 / db7 are accumulated."""
     B, H, W, _ = t.shape
     dev = t.device
     L = _lib.lib()
     dlogit = torch.empty(B, H, W, device=dev, dtype=torch.float32)
     amaxc = torch.empty(B, H, W, device=dev, dtype=torch.int32)
-    check(L.somi_cbam_bwd_pixel_f32(_ptr(_f32c(dt2)), dt2.shape[3], 0, _ptr(_f32c(t)), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dlogit),
-                                    _ptr(amaxc), B, H * W, c, _stream()), 'cbam_bwd_pixel')
+    amaxp = None
+    if t_max is not None:
+        amaxp = torch.empty(B, c, device=dev, dtype=torch.int32)
+        check(L.somi_cbam_bwd_pixel_argmax_f32(_ptr(_f32c(dt2)), dt2.shape[3], 0, _ptr(_f32c(t)), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(t_max),
+                                               _ptr(dlogit), _ptr(amaxc), _ptr(amaxp), B, H * W, c, _stream()), 'cbam_bwd_pixel')
+    else:
+        check(L.somi_cbam_bwd_pixel_f32(_ptr(_f32c(dt2)), dt2.shape[3], 0, _ptr(_f32c(t)), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dlogit),
+                                        _ptr(amaxc), B, H * W, c, _stream()), 'cbam_bwd_pixel')
     dstats = torch.empty(B, H, W, 2, device=dev, dtype=torch.float32)
     ws = torch.empty(((B * H * W + 1023) // 1024) * (2 * k * k + 1), device=dev, dtype=torch.float32)
     check(L.somi_spatial_attn_bwd_f32(_ptr(dlogit), _ptr(stats), _ptr(w7), _ptr(dstats), _ptr(dw7), _ptr(db7), _ptr(ws), B, H, W, k,
                                       _stream()), 'spatial_attn_bwd')
     dca = torch.empty(B, c, device=dev, dtype=torch.float32)
-    amaxp = torch.empty(B, c, device=dev, dtype=torch.int32)      # step D rides the same pass over t: where each channel's spatial maximum sits
-    ws2 = torch.empty(3 * B * L.somi_img_nchunk(H * W) * c, device=dev, dtype=torch.float32)
-    check(L.somi_cbam_bwd_chan_argmax_f32(_ptr(dt2), dt2.shape[3], 0, _ptr(t), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dstats), _ptr(amaxc),
-                                          _ptr(dca), _ptr(amaxp), _ptr(ws2), B, H * W, c, _stream()), 'cbam_bwd_chan')
+    ws2 = torch.empty(B * L.somi_img_nchunk(H * W) * c, device=dev, dtype=torch.float32)
+    check(L.somi_cbam_bwd_chan_f32(_ptr(dt2), dt2.shape[3], 0, _ptr(t), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dstats), _ptr(amaxc),
+                                   _ptr(dca), _ptr(ws2), B, H * W, c, _stream()), 'cbam_bwd_chan')
     return dca, amaxp
 
 
