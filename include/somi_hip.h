@@ -254,6 +254,13 @@ int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const 
 int somi_pool_nchunk(int HW);
 int somi_global_pool_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, float *out_avg,
                               float *out_max, float *workspace, somi_stream_t stream);
+/* z = silu(x * scale + shift) (the Conv block's BatchNorm + SiLU, as somi_chan_affine_act_nhwc_f32 with act = SILU, order = 0) AND the global
+ * average / max pools of z per (image, channel) in the same pass - what a channel attention right behind the block would otherwise re-read z for
+ * (models/common.py:339-358).  C / 4 must divide 256 or be a multiple of it (somi_affine_silu_pool_rows returns 0 otherwise: use the two
+ * separate entries).  workspace: 2 * B * somi_affine_silu_pool_rows(B, HW, C) * C floats. */
+int somi_affine_silu_pool_rows(int B, int HW, int C);
+int somi_affine_silu_pool_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, float *z, int z_cs, int z_coff,
+                                   int B, int HW, int C, float *out_avg, float *out_max, float *workspace, somi_stream_t stream);
 
 /* Tiny per-sample MLP heads (host picks the recipe):
  *  mode 0 (CBAM channel attention, models/common.py:355-358):

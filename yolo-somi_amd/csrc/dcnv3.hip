@@ -1060,6 +1060,7 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
     float *win = reinterpret_cast<float *>(smem);
     f32x4 *rf = reinterpret_cast<f32x4 *>(win + (size_t)(ncell + q.WW + 2) * GC);
     int *code = reinterpret_cast<int *>(rf + nrec);
+    float *ob = reinterpret_cast<float *>(code + nrec);             // MODE 1: the tile's [pixel][K] mask and [pixel][2K] offset gradients, stored together at the end
     // (image, tile, group) with the group fastest: the G workgroups of a tile read neighbouring bytes, and an XCD's L2 sees one
     // contiguous run of tiles (their halos overlap)
     const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -1220,8 +1221,6 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
             *reinterpret_cast<f32x4 *>(a.output + opix0 * a.C + g * GC + (lpix * a.C + part * 4)) = acc;
         } else {
             const f32x4 tg = live ? *reinterpret_cast<const f32x4 *>(a.grad_output + opix0 * a.C + g * GC + (lpix * a.C + part * 4)) : zero;
-            float *gm_b = a.grad_mask + opix0 * a.msk_ps + g * a.K + lpix * mps;
-            float *go_b = a.grad_offset + opix0 * a.off_ps + g * a.K * 2 + lpix * ops;
             for (int k0 = 0; k0 < a.K; k0 += 3) {
                 const int nk = min(3, a.K - k0);
                 int cd[3];
@@ -1269,12 +1268,29 @@ __global__ __launch_bounds__(256) void dcnv3_win_kernel(const DcnArgs a, const G
                     const float gm = group_sum<LG>(hh * top + lh * bot);
                     const float gw = group_sum<LG>((hh * (d2 - d1) + lh * (d4 - d3)) * m);
                     const float gh = group_sum<LG>((bot - top) * m);
-                    if (live && part == 0) {
-                        gm_b[k0 + j] = gm;
-                        *reinterpret_cast<float2 *>(go_b + (k0 + j) * 2) = make_float2(a.offset_scale * gw, a.offset_scale * gh);
+                    if (live && part == 0) {                              // staged: one lane of eight would otherwise issue 27 four- and eight-byte stores per pixel
+                        ob[plc * a.K + k0 + j] = gm;
+                        *reinterpret_cast<float2 *>(ob + GIN_TP * a.K + (plc * a.K + k0 + j) * 2) = make_float2(a.offset_scale * gw, a.offset_scale * gh);
                     }
                 }
             }
+        }
+    }
+    if constexpr (MODE == 1) {
+        // 4. the staged gradients leave as runs: consecutive lanes write consecutive floats of a pixel's K masks / 2K offsets (36 / 72 contiguous
+        //    bytes at K = 9; round 3 wrote them from one lane of eight as they were produced: 3.7e6 store instructions of 8 scattered lanes each
+        //    per launch at N32 80x80 - the store path, not the arithmetic, was what held this kernel at 2.5x the forward's time)
+        __syncthreads();
+        float *gm_t = a.grad_mask + opix0 * a.msk_ps + g * a.K, *go_t = a.grad_offset + opix0 * a.off_ps + g * a.K * 2;
+        for (int i = threadIdx.x; i < GIN_TP * a.K; i += 256) {
+            const int pl = i / a.K, k = i - pl * a.K;
+            const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+            if (ho < a.Ho && wo < a.Wo) gm_t[(ho * a.Wo + wo) * mps + k] = ob[i];
+        }
+        for (int i = threadIdx.x; i < GIN_TP * a.K * 2; i += 256) {
+            const int pl = i / (a.K * 2), k2 = i - pl * a.K * 2;
+            const int ho = th0 + pl / GIN_TW, wo = tw0 + pl % GIN_TW;
+            if (ho < a.Ho && wo < a.Wo) go_t[(ho * a.Wo + wo) * ops + k2] = ob[GIN_TP * a.K + i];
         }
     }
 }
@@ -1308,11 +1324,12 @@ static bool win_geo(const DcnArgs &a, GinGeo &q) {
 }
 
 // the gathering kernels (forward, backward A): LDS bytes, or 0 when the window does not fit / the grid does not index
-static size_t win_plan(const DcnArgs &a, GinGeo &q) {
+static size_t win_plan(const DcnArgs &a, GinGeo &q, int mode = 0) {
     if (!win_geo(a, q)) return 0;
     const char *e = getenv("SOMI_DCN_DIRECT");                    // read per call: tools flip it to time the two forms side by side
     if (e && e[0] == '1') return 0;
-    const size_t lds = ((size_t)q.WH * q.WW + q.WW + 2) * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(f32x4) + sizeof(int));
+    const size_t lds = ((size_t)q.WH * q.WW + q.WW + 2) * a.Gc * sizeof(float) + (size_t)GIN_TP * a.K * (sizeof(f32x4) + sizeof(int)) +
+                       (mode == 1 ? (size_t)GIN_TP * a.K * 3 * sizeof(float) : 0);      // backward A stages its outputs
     if (lds > 64 * 1024 || (long)a.N * a.G * q.tiles_h * q.tiles_w >= (1L << 31)) return 0;
     if ((long)a.Ho * a.Wo * a.off_ps >= (1L << 31) || (long)a.Ho * a.Wo * a.msk_ps >= (1L << 31) || (long)a.Ho * a.Wo * a.C >= (1L << 31)) return 0;      // 32-bit indices inside one image
     if (GIN_TP * a.kw + 256 >= 65536 / a.kw || q.WH * q.WW >= 65536 / q.WW) return 0;                             // the reciprocal divisions
@@ -1478,7 +1495,7 @@ extern "C" int somi_dcnv3_backward_strided_f32(const float *input, const float *
         const int chunk = pl.chunk;
         // A: grad_offset / grad_mask (float4 gathers, no atomics), the whole batch
         GinGeo qa{};
-        const size_t wlds = aligned16(input) ? win_plan(a, qa) : 0;
+        const size_t wlds = aligned16(input) ? win_plan(a, qa, 1) : 0;
         if (wlds) launch_win<1>(a, qa, wlds, s);
         else hipLaunchKernelGGL(dcnv3_bwd_om_kernel, dim3(a.ntile), dim3(256), (size_t)a.TP * G * a.K * sizeof(Rec), s, a);
         // B: grad_input windows, C: combine, D: the near taps - chunk of images after chunk through one staging slab

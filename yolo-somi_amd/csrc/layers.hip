@@ -249,6 +249,64 @@ __global__ __launch_bounds__(256) void global_pool_stage2(const float *__restric
     if (out_max) out_max[i] = m;
 }
 
+// ------------------------------------------------------------------------------------------------ affine + activation + global pools in one pass
+// z = act(x * scale + shift)  AND  the per-(image, channel) sum and maximum of z (the channel attention's GAP / GMP, models/common.py:339-358)
+// in the pass that writes z - global_pool_stage1's read of the tensor it would pool disappears (round 4).  Image-aligned: blockIdx.y = image,
+// a thread keeps one channel quad of that image (gridDim.x * 256 is a multiple of C / 4, and C / 4 divides 256 or is a multiple of it: the host
+// checks) and walks its pixels four at a time; the threads of a workgroup that share a quad are combined through LDS in a fixed order, one
+// partial row per workgroup (or per group of workgroups covering all quads); global_pool_stage2 folds the rows.  SiLU after the norm only
+// (the conv block's case); same arithmetic as chan_affine_act_kernel.
+__global__ __launch_bounds__(256) void affine_silu_pool_kernel(const float *__restrict__ x, int x_cs, int x_coff, const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, float *__restrict__ z, int z_cs, int z_coff,
+                                                               int HW, int C, float *__restrict__ part_sum, float *__restrict__ part_max,
+                                                               int rows) {
+    __shared__ f32x4 ls[256], lm[256];
+    const unsigned C4 = (unsigned)C >> 2, nthreads = gridDim.x * 256u, t = blockIdx.x * 256u + threadIdx.x;
+    const int c = (int)(t % C4) * 4, b = blockIdx.y, pstep = (int)(nthreads / C4);
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+    const float *xb = x + (long)b * HW * x_cs + x_coff + c;
+    float *zb = z + (long)b * HW * z_cs + z_coff + c;
+    const float ninf = -__builtin_huge_valf();
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {ninf, ninf, ninf, ninf};
+    auto one = [&](f32x4 v) {
+        v = v * sc + sh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<SOMI_ACT_SILU>(v[e]);
+        s += v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        return v;
+    };
+    int p = (int)(t / C4);
+    for (; p + 3 * pstep < HW; p += 4 * pstep) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(xb + (long)(p + u * pstep) * x_cs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4 *>(zb + (long)(p + u * pstep) * z_cs) = one(v[u]);
+    }
+    for (; p < HW; p += pstep) *reinterpret_cast<f32x4 *>(zb + (long)p * z_cs) = one(*reinterpret_cast<const f32x4 *>(xb + (long)p * x_cs));
+    // combine the threads of this workgroup that hold the same quad (C4 < 256: threads tid, tid + C4, ...), ascending thread order
+    int row = blockIdx.x;
+    if (C4 < 256u) {
+        ls[threadIdx.x] = s;
+        lm[threadIdx.x] = m;
+        __syncthreads();
+        if (threadIdx.x >= C4) return;
+        for (unsigned o = threadIdx.x + C4; o < 256u; o += C4) {
+            s += ls[o];
+            const f32x4 w = lm[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], w[e]);
+        }
+    } else {
+        row = (int)(blockIdx.x / (C4 / 256u));                         // C4 / 256 consecutive workgroups cover all quads once
+    }
+    const long o = ((long)b * rows + row) * C + c;
+    *reinterpret_cast<f32x4 *>(part_sum + o) = s;
+    *reinterpret_cast<f32x4 *>(part_max + o) = m;
+}
+
 // ------------------------------------------------------------------------------------------------ attention MLPs
 // one workgroup per sample; C <= 1024, mid <= 64
 __global__ __launch_bounds__(256) void attn_mlp_kernel(int mode, const float *__restrict__ avg, const float *__restrict__ mx,
@@ -733,6 +791,39 @@ extern "C" int somi_global_pool_nhwc_f32(const float *x, int x_cs, int x_coff, i
     hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, (hipStream_t)stream, ps, pm, nchunk, C, B,
                        1.0f / (float)HW, out_avg, out_max);
     return launch_status("somi_global_pool_nhwc_f32");
+}
+
+// workgroups per image of affine_silu_pool_kernel (0: the shape is not covered - C / 4 must divide 256 or be a multiple of it) and its partial rows
+static inline int asp_grid(int B, int HW, int C, int *rows) {
+    const int C4 = C / 4;
+    if (C % 4 || C4 <= 0 || !((256 % C4 == 0) || (C4 % 256 == 0))) return 0;
+    const int mult = C4 <= 256 ? 1 : C4 / 256;                       // workgroups that cover every quad once
+    long g = ((long)HW * C4 + 255) / 256, per = (5 * 256) / (B > 0 ? B : 1);   // ~ one resident round of the chip over the whole batch
+    if (per < 1) per = 1;
+    g = g < 1 ? 1 : (g > per ? per : g);
+    g = (g + mult - 1) / mult * mult;
+    *rows = (int)(g / mult);
+    return (int)g;
+}
+extern "C" int somi_affine_silu_pool_rows(int B, int HW, int C) {
+    int rows = 0;
+    return asp_grid(B, HW, C, &rows) ? rows : 0;
+}
+extern "C" int somi_affine_silu_pool_nhwc_f32(const float *x, int x_cs, int x_coff, const float *scale, const float *shift, float *z, int z_cs,
+                                              int z_coff, int B, int HW, int C, float *out_avg, float *out_max, float *workspace,
+                                              somi_stream_t stream) {
+    int rows = 0;
+    const int gx = asp_grid(B, HW, C, &rows);
+    SOMI_REQUIRE(x && z && scale && shift && out_avg && out_max && workspace && B > 0 && B <= 65535 && HW > 0 && gx > 0, SOMI_EINVAL,
+                 "affine + silu + pool: bad arguments (C / 4 must divide 256 or be a multiple of it)");
+    SOMI_REQUIRE(x_cs % 4 == 0 && x_coff % 4 == 0 && z_cs % 4 == 0 && z_coff % 4 == 0 && x_coff + C <= x_cs && z_coff + C <= z_cs && aligned16(x) &&
+                     aligned16(z) && aligned16(scale) && aligned16(shift) && aligned16(workspace), SOMI_EINVAL,
+                 "affine + silu + pool: strides / offsets %% 4 and 16 B alignment");
+    float *ps = workspace, *pm = workspace + (size_t)B * rows * C;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(affine_silu_pool_kernel, dim3(gx, B), dim3(256), 0, s, x, x_cs, x_coff, scale, shift, z, z_cs, z_coff, HW, C, ps, pm, rows);
+    hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, ps, pm, rows, C, B, 1.0f / (float)HW, out_avg, out_max);
+    return launch_status("somi_affine_silu_pool_nhwc_f32");
 }
 
 extern "C" int somi_attn_mlp_f32(int mode, const float *avg, const float *mx, const float *W1, const float *b1,

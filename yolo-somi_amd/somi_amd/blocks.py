@@ -188,8 +188,10 @@ class Conv(_Packed):
         return _pack_wb(*_fold_conv_bn(self.conv, getattr(self, 'bn', None)), dev)
 
     # ------------------------------------------------------------------------------------------ training mode
-    def _forward_train(self, x, out, residual):
-        """y = conv(x) (raw) -> batch statistics -> z = act(y*scale+shift) [+ residual]; keeps what backward needs."""
+    def _forward_train(self, x, out, residual, pool=None):
+        """y = conv(x) (raw) -> batch statistics -> z = act(y*scale+shift) [+ residual]; keeps what backward needs.
+        pool: a dict - when the shape allows, the pass that writes z also takes its global average / max pools per (image, channel) and leaves
+        them as pool['avg'], pool['max'] (a channel attention behind this block then needs no pass of its own over z)."""
         pk = self._packed(x.t.device)                            # rebuilt after every optimizer step (Model.invalidate)
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         c2, cp = self.conv.out_channels, pad4(self.conv.out_channels)
@@ -216,7 +218,12 @@ class Conv(_Packed):
         elif c2 % 4:
             raise NotImplementedError('writing into a channel slice needs c2 % 4 == 0')
         cw = cp if out.coff == 0 and out.t.shape[3] == cp else c2
-        if residual is not None and cw != c2:
+        pooled = None
+        if pool is not None and residual is None and cw == c2 and isinstance(self.act, nn.SiLU):
+            pooled = ops.affine_silu_pool(y, c2, 0, scale, shift, out.t, out.coff)
+        if pooled is not None:
+            pool['avg'], pool['max'] = pooled
+        elif residual is not None and cw != c2:
             ops.chan_affine_act(y, cw, 0, scale, shift, _act_name(self.act), 0, out.t, out.coff)
             ops.add_(out.t, out.coff, residual.t, residual.coff, c2)
         else:
@@ -265,9 +272,9 @@ class Conv(_Packed):
                               acc2_coff=0 if also_add is None else also_add.coff)
         return dx_out
 
-    def forward(self, x, out=None, residual=None, a_chan=None, a_pix=None):
+    def forward(self, x, out=None, residual=None, a_chan=None, a_pix=None, pool=None):
         if self.training:
-            return self._forward_train(x, out, residual)
+            return self._forward_train(x, out, residual, pool)
         wp, bp = self._packed(x.t.device)
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         c2 = self.conv.out_channels
@@ -341,11 +348,12 @@ class ChannelAttentionModule(_Packed):
         l1, l2 = self.shared_MLP[0], self.shared_MLP[2]
         return tuple(t.detach().float().contiguous().to(dev) for t in (l1.weight, l1.bias, l2.weight, l2.bias))
 
-    def forward(self, x):
+    def forward(self, x, pooled=None):
+        """pooled: (avg, max) of x per (image, channel) when the producer of x already took them (Conv(..., pool=))."""
         if self.training:
             self.invalidate()
         W1, b1, W2, b2 = self._packed(x.t.device)
-        avg, mx = ops.global_pool(x.t, c=x.c, x_coff=x.coff)
+        avg, mx = pooled if pooled is not None else ops.global_pool(x.t, c=x.c, x_coff=x.coff)
         ca = ops.attn_mlp(0, avg, mx, W1, b1, W2, b2)
         if self.training:
             self.__dict__['_ctx'] = (x, avg, mx, ca, (W1, b1, W2, b2))
@@ -429,8 +437,9 @@ class CBAMBottleneck(nn.Module):
         self.spatial_attention = SpatialAttentionModule(kernel_size)
 
     def forward(self, x, out=None):
-        t = self.cv1(x)
-        ca = self.channel_attention(t)
+        pool = {} if self.training else None
+        t = self.cv1(x, pool=pool)                                # training: the BatchNorm + SiLU pass also takes the attention's global pools
+        ca = self.channel_attention(t, pooled=(pool['avg'], pool['max']) if pool else None)
         t2 = self.spatial_attention(t, ca)
         if self.training:
             self.__dict__['_ctx'] = (x, t)

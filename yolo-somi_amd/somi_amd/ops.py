@@ -338,6 +338,22 @@ def global_pool(x, c=None, x_coff=0, want_max=True):
     return avg, mx
 
 
+def affine_silu_pool(x, c, x_coff, scale, shift, out, out_coff=0):
+    """out = silu(x * scale + shift) and the global average / max pools of it per (image, channel) in one pass; -> (avg, max) (B, c), or None when
+    the kernel does not cover the width (c / 4 must divide 256 or be a multiple of it) - the caller then runs the two separate passes."""
+    B, H, W, _ = x.shape
+    L = _lib.lib()
+    rows = L.somi_affine_silu_pool_rows(B, H * W, c)
+    if rows <= 0:
+        return None
+    ws = torch.empty(2 * B * rows * c, device=x.device, dtype=torch.float32)
+    avg = torch.empty(B, c, device=x.device, dtype=torch.float32)
+    mx = torch.empty(B, c, device=x.device, dtype=torch.float32)
+    check(L.somi_affine_silu_pool_nhwc_f32(_ptr(_f32c(x)), x.shape[3], x_coff, _ptr(scale), _ptr(shift), _ptr(_f32c(out)), out.shape[3], out_coff, B, H * W, c,
+                                           _ptr(avg), _ptr(mx), _ptr(ws), _stream()), 'affine_silu_pool')
+    return avg, mx
+
+
 def attn_mlp(mode, avg, mx, W1, b1, W2, b2):
     B, Cc = avg.shape
     out = torch.empty_like(avg)
