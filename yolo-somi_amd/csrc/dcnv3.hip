@@ -577,6 +577,7 @@ struct RecM {                           // one sampling point: window coordinate
 };
 static_assert(sizeof(RecM) == 24, "step 2 reads the records as 6 dwords");
 
+constexpr int GMM_MAX_CELLS = 320;    // window cells the coloured form tracks (15 x 15 = 225 at K = 9, R = 2)
 constexpr int GMM_NT = 512;           // threads: LDS (S is 61 KB) allows two workgroups per CU, so each brings 8 waves for the non-MFMA phases
 
 // COLOURED (round 4): no staging slab and no combine pass.  The windows of tiles that are `nch` x `ncw` tiles apart do not overlap (a window of
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
     OvfG *ovf = reinterpret_cast<OvfG *>(reinterpret_cast<char *>(recs) + (mid + 15) / 16 * 16);
     __shared__ int novf;
     __shared__ unsigned nearmask;                                     // bits 0..24: destination tiles of NEAR taps; COLOURED: bit 31 = the tile has FAR taps
+    __shared__ int touched[GMM_MAX_CELLS];                            // COLOURED: cell received a coefficient - the others are neither read nor written
     int tile = blockIdx.x;
     if constexpr (COLOURED) {                                          // the launch's colour class: tiles (col_h + nch * i, col_w + ncw * j)
         const int tcw = (q.tiles_w - q.col_w + q.ncw - 1) / q.ncw;
@@ -641,6 +643,8 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
         }
     }
     for (int i = tid; i < ncell * GMM_LD / 4; i += NT) reinterpret_cast<f32x4 *>(S)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (COLOURED)
+        for (int i = tid; i < GMM_MAX_CELLS; i += NT) touched[i] = 0;
     if (tid == 0) { novf = 0; nearmask = 0u; }
     // 1. records
     for (int i = tid, j = 0; i < nrec; i += NT, ++j) {
@@ -691,6 +695,7 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
             const int wh = wh0 + dy, ww = ww0 + dx;
             if ((unsigned)wh < (unsigned)q.WH && (unsigned)ww < (unsigned)q.WW) {
                 S[(wh * q.WW + ww) * GMM_LD + pl] += cf;                      // plain read-add-write: see the note on column writers above
+                if constexpr (COLOURED) touched[wh * q.WW + ww] = 1;          // (every writer stores the same value)
             } else if (int nb; near_bit(q, wh + win_h0, ww + win_w0, win_h0, win_w0, nb)) {
                 atomicOr(&nearmask, 1u << nb);                                // left for the near pass (dcnv3_bwd_near_kernel)
             } else if constexpr (COLOURED) {
@@ -748,7 +753,9 @@ __global__ __launch_bounds__(GMM_NT) void dcnv3_bwd_gin_mfma_kernel(const DcnArg
         f32x4 cur[MB][4];
         if constexpr (COLOURED) {
             const int ch = crow / q.WW, h = win_h0 + ch, w = win_w0 + (crow - ch * q.WW);
-            if (crow < ncell && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) gpix = ((long)h * a.W + w) * a.C;
+            // a cell no sampling point reached (the slack ring around the kernel footprint, at small offsets: 40 % of the window) adds exact
+            // zeros: skipping it saves its read AND its write
+            if (crow < ncell && touched[crow] && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) gpix = ((long)h * a.W + w) * a.C;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1365,7 +1372,8 @@ static bool gin_plan(const DcnArgs &a, GinGeo &q, GinPlan &pl) {
     const char *slab_env = getenv("SOMI_DCN_SLAB");
     pl.nch = (q.WH + GIN_TH * a.sh - 1) / (GIN_TH * a.sh);
     pl.ncw = (q.WW + GIN_TW * a.sw - 1) / (GIN_TW * a.sw);
-    pl.coloured = pl.mfma && near_on && a.sh == 1 && a.sw == 1 && pl.nch * pl.ncw <= 4 && a.N <= 65535 && !(slab_env && slab_env[0] == '1');
+    pl.coloured = pl.mfma && near_on && a.sh == 1 && a.sw == 1 && pl.nch * pl.ncw <= 4 && a.N <= 65535 && q.WH * q.WW <= GMM_MAX_CELLS &&
+                  !(slab_env && slab_env[0] == '1');
     static const long cap_mb = [] { const char *e = getenv("SOMI_DCN_SLAB_MB"); const long v = e ? atol(e) : 1024; return v < 1 ? 1 : v; }();
     const size_t per_img = (size_t)a.G * q.tiles_h * q.tiles_w * q.WH * q.WW * a.Gc * sizeof(float);
     long c = (long)(((size_t)cap_mb << 20) / per_img);
