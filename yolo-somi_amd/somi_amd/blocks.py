@@ -437,7 +437,7 @@ class CBAMBottleneck(nn.Module):
         self.spatial_attention = SpatialAttentionModule(kernel_size)
 
     def forward(self, x, out=None):
-        pool = {} if self.training else None
+        pool = {} if (self.training and ops.FUSE_POOL) else None
         t = self.cv1(x, pool=pool)                                # training: the BatchNorm + SiLU pass also takes the attention's global pools
         ca = self.channel_attention(t, pooled=(pool['avg'], pool['max']) if pool else None)
         t2 = self.spatial_attention(t, ca)
@@ -451,7 +451,7 @@ class CBAMBottleneck(nn.Module):
         x, t = self.__dict__.pop('_ctx')
         d = self.cv2.backward(dout)                               # d(t*ca*sa)
         # d.t then holds the direct part of dt; the channel attention's pooled maximum lets the same pass find its arg-max pixels
-        dca, amaxp = self.spatial_attention.backward(d.t, t_max=self.channel_attention.__dict__['_ctx'][2])
+        dca, amaxp = self.spatial_attention.backward(d.t, t_max=self.channel_attention.__dict__['_ctx'][2] if ops.AMAX_BY_VALUE else None)
         pooled = self.channel_attention.backward(dca, d, amaxp, defer=True)   # the pooled paths join d inside cv1's BatchNorm backward
         c1 = self.cv1.conv.in_channels
         fuse = self.add and pad4(c1) == c1 and dout.coff % 4 == 0  # the shortcut's gradient rides the dgrad epilogue

@@ -24,6 +24,8 @@ _CONV_WS = {}
 # claim is made on), 1 bf16 operands, 2 bf16x3 split (somi_conv_desc.prec).  train.TrainStep(amp=...) / bench.py --amp set it.
 CONV_PREC = 0
 PREC = {None: 0, 'f32': 0, 'bf16': 1, 'bf16x3': 2}
+FUSE_POOL = os.environ.get('SOMI_FUSE_POOL', '1') != '0'      # 0: the channel attention pools its input in a pass of its own (round-3 form; A/B runs)
+AMAX_BY_VALUE = os.environ.get('SOMI_AMAX_BY_VALUE', '1') != '0'   # 0: the max-pool's arg-max from somi_pool_argmax_nhwc_f32's own pass over the tensor
 BN_POOLED = os.environ.get('SOMI_BN_POOLED', '1') != '0'    # 0: CBAM's pooled gradients are added by a pass of their own (round-3 form; A/B runs)
 
 
