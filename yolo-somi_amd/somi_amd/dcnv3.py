@@ -125,6 +125,18 @@ class DCNv3(nn.Module):
             b = torch.cat([b, b.new_zeros(pad)])
         return ops.conv2d_nhwc(x, w.contiguous(), b.contiguous(), kh=1, kw=1, bn_stats=bn_stats if cout % 4 == 0 else None)
 
+    def _stacked_om(self):
+        """The offset and mask Linear layers as ONE weight [2GK offset rows | GK mask rows | zero rows up to a multiple of 32] and bias: 216 -> 224
+        columns at G 8, K 9, so that the data gradient through the stack (reduction over its columns) takes the conv kernel's uniform-tap fast
+        path instead of the generic one (MFMA busy 0.53 there, profiles/r04_conv_pmc.txt); the pad columns of `om` hold zeros."""
+        w = torch.cat([self.offset.weight.detach(), self.mask.weight.detach()]).float()
+        b = torch.cat([self.offset.bias.detach(), self.mask.bias.detach()]).float()
+        pad = -w.shape[0] % 32
+        if pad:
+            w = torch.cat([w, w.new_zeros(pad, w.shape[1])])
+            b = torch.cat([b, b.new_zeros(pad)])
+        return w.contiguous(), b.contiguous()
+
     def _params(self):
         dw, ln = self.dw_conv[0], self.dw_conv[1][1]
         ps = [dw.weight, dw.bias, ln.weight, ln.bias, self.offset.weight, self.offset.bias, self.mask.weight, self.mask.bias,
@@ -158,8 +170,7 @@ class DCNv3(nn.Module):
         if GK % 4 == 0:
             # offset and mask logits share their input: ONE 1x1 GEMM over the stacked weights -> rows [2GK offsets | GK logits]; the softmax
             # runs in place on the logit columns and the operator reads both column ranges where they lie (modules/dcnv3.py:330-334)
-            w_om = torch.cat([self.offset.weight.detach(), self.mask.weight.detach()]).float().contiguous()
-            b_om = torch.cat([self.offset.bias.detach(), self.mask.bias.detach()]).float().contiguous()
+            w_om, b_om = self._stacked_om()
             om = ops.conv2d_nhwc(x1, w_om, b_om, kh=1, kw=1)
             ops.group_softmax_cols_(om, self.group, K, 2 * GK)
             offset = mask = None
@@ -229,10 +240,10 @@ class DCNv3(nn.Module):
                                                  self.pad, self.pad, self.dilation, self.dilation, G, Gc, self.offset_scale, 256)
         dxp = dxp_op if dxp is None else ops.add_(dxp, 0, dxp_op, 0, C)
         ops.group_softmax_backward_cols_(om, d_om, G, K, 2 * G * K)
-        w_om = torch.cat([self.offset.weight.detach(), self.mask.weight.detach()])
+        w_om, _ = self._stacked_om()
         d1, g_wom, g_bom = lin_bwd(x1, w_om, d_om)
-        g_woff, g_wm = g_wom[:2 * G * K], g_wom[2 * G * K:]
-        g_boff, g_bm = g_bom[:2 * G * K], g_bom[2 * G * K:]
+        g_woff, g_wm = g_wom[:2 * G * K], g_wom[2 * G * K:3 * G * K]          # (rows beyond 3GK are the zero pad of the stack)
+        g_boff, g_bm = g_bom[:2 * G * K], g_bom[2 * G * K:3 * G * K]
         dx1 = d1 if dx1 is None else ops.add_(dx1, 0, d1, 0, C)
         ln = self.dw_conv[1][1]
         g_lnw, g_lnb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)

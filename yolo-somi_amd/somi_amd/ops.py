@@ -245,7 +245,9 @@ def dcnv3_backward_merged(input, om, grad_output, kh, kw, sh, sw, ph, pw, dh, dw
     N, H, W, _ = input.shape
     R, GK = om.shape[-1], group * kh * kw
     gi = torch.zeros_like(input)
-    d_om = torch.empty_like(om) if R == 3 * GK else torch.zeros_like(om)
+    d_om = torch.empty_like(om)
+    if R != 3 * GK:
+        d_om[..., 3 * GK:].zero_()                                # the operator writes the first 3GK columns of every row; the pad stays zero
     prof = PROFILE is not None
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
