@@ -369,8 +369,9 @@ int somi_bn_act_backward_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const
 /* The same backward (batch statistics) for the conv in front of a CBAM attention pair (models/common.py:339-358, 671-691), with the gradient of
  * the channel attention's global pools folded in instead of added by a pass of its own (somi_pool_bwd_add_nhwc_f32):
  *   dz_eff[b,p,c] = dz[b,p,c] + davg[b,c] / HW + [p == amaxp[b,c]] * dmax[b,c];   dz is only read.
- * davg, dmax (B,C) float, amaxp (B,C) int32 - the first pixel of each channel's spatial maximum.  workspace: 2 * somi_bn_pooled_rows(B, HW) * C
- * + 3 * round_up(C, 4) floats. */
+ * davg, dmax (B,C) float, amaxp (B,C) int32 - the first pixel of each channel's spatial maximum.  dmax and amaxp may both be NULL (no max-pool:
+ * SEAM's squeeze, models/common.py:8483-8490), and dz may be NULL when the pooled part is the WHOLE incoming gradient (the tensor is read by a
+ * global average pool only: no zero tensor is materialised and read).  workspace: 2 * somi_bn_pooled_rows(B, HW) * C + 3 * round_up(C, 4) floats. */
 int somi_bn_pooled_rows(int B, int HW);
 int somi_bn_act_backward_pooled_nhwc_f32(const float *dz, int dz_cs, int dz_coff, const float *x, int x_cs, int x_coff, const float *mean,
                                          const float *rstd, const float *scale, const float *shift, int act, int order, const float *davg,

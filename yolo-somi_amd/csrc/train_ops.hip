@@ -418,15 +418,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1_pooled(const float *__r
         const int c = (cq0 + cq) * 4;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
         if (rr < rows_par) {
+            // dz == nullptr: the incoming gradient is the pooled part alone (SEAM: only a global average pool reads the tensor); dmax ==
+            // nullptr: no max-pool term
             const f32x4 kavg = *reinterpret_cast<const f32x4 *>(davg + (long)b * C + c) * inv_hw;
-            const f32x4 kmax = *reinterpret_cast<const f32x4 *>(dmax + (long)b * C + c);
-            const i32x4_ am = *reinterpret_cast<const i32x4_ *>(amaxp + (long)b * C + c);
+            const f32x4 kmax = dmax ? *reinterpret_cast<const f32x4 *>(dmax + (long)b * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const i32x4_ am = dmax ? *reinterpret_cast<const i32x4_ *>(amaxp + (long)b * C + c) : i32x4_{-1, -1, -1, -1};
             const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c), sc = *reinterpret_cast<const f32x4 *>(scale + c),
                         sh = *reinterpret_cast<const f32x4 *>(shift + c);
 #pragma unroll 4
             for (int pl = q0 + rr; pl < q1; pl += rows_par) {            // four pixels' loads go out before the first sum
                 const long p = (long)b * HW + pl;
-                f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c) + kavg;
+                f32x4 g = kavg;
+                if (dz) g += *reinterpret_cast<const f32x4 *>(dz + p * dz_cs + dz_coff + c);
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(x + p * x_cs + x_coff + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -473,9 +476,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_pooled(const float *dz, 
                 Cc = *reinterpret_cast<const f32x4 *>(coefC + c), M = *reinterpret_cast<const f32x4 *>(mean + c),
                 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
     const f32x4 kavg = *reinterpret_cast<const f32x4 *>(davg + (long)b * C + c) * (1.f / (float)HW);
-    const f32x4 kmax = *reinterpret_cast<const f32x4 *>(dmax + (long)b * C + c);
-    const i32x4_ am = *reinterpret_cast<const i32x4_ *>(amaxp + (long)b * C + c);
-    dz += (long)b * HW * dz_cs + dz_coff + c;
+    const f32x4 kmax = dmax ? *reinterpret_cast<const f32x4 *>(dmax + (long)b * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const i32x4_ am = dmax ? *reinterpret_cast<const i32x4_ *>(amaxp + (long)b * C + c) : i32x4_{-1, -1, -1, -1};
+    const bool has_dz = dz != nullptr;
+    if (has_dz) dz += (long)b * HW * dz_cs + dz_coff + c;
     x += (long)b * HW * x_cs + x_coff + c;
     dx += (long)b * HW * dx_cs + dx_coff + c;
     auto one = [&](f32x4 g, const f32x4 v, int pl) {
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_pooled(const float *dz, 
         f32x4 g[EW_U], v[EW_U];
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) {
-            g[u] = *reinterpret_cast<const f32x4 *>(dz + (long)(p + u * pstep) * dz_cs);
+            g[u] = has_dz ? *reinterpret_cast<const f32x4 *>(dz + (long)(p + u * pstep) * dz_cs) : f32x4{0.f, 0.f, 0.f, 0.f};
             v[u] = *reinterpret_cast<const f32x4 *>(x + (long)(p + u * pstep) * x_cs);
         }
 #pragma unroll
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_pooled(const float *dz, 
     }
     for (; p < HW; p += pstep)
         *reinterpret_cast<f32x4 *>(dx + (long)p * dx_cs) =
-            one(*reinterpret_cast<const f32x4 *>(dz + (long)p * dz_cs), *reinterpret_cast<const f32x4 *>(x + (long)p * x_cs), p);
+            one(has_dz ? *reinterpret_cast<const f32x4 *>(dz + (long)p * dz_cs) : f32x4{0.f, 0.f, 0.f, 0.f}, *reinterpret_cast<const f32x4 *>(x + (long)p * x_cs), p);
 }
 // pixels of one image per stage-1 workgroup of the pooled form: the batch's partial rows stay at <= 1024 like red_chunk's
 static inline int red_chunk_img(int B, int HW) {
@@ -698,11 +702,12 @@ extern "C" int somi_bn_act_backward_pooled_nhwc_f32(const float *dz, int dz_cs, 
                                                     const float *rstd, const float *scale, const float *shift, int act, int order,
                                                     const float *davg, const float *dmax, const int32_t *amaxp, float *dx, int dx_cs, int dx_coff,
                                                     float *dgamma, float *dbeta, int B, int HW, int C, float *workspace, somi_stream_t stream) {
-    SOMI_REQUIRE(slice_ok(dz, dz_cs, dz_coff, C) && slice_ok(x, x_cs, x_coff, C) && slice_ok(dx, dx_cs, dx_coff, C) && mean && rstd && scale &&
+    SOMI_REQUIRE((!dz || slice_ok(dz, dz_cs, dz_coff, C)) && slice_ok(x, x_cs, x_coff, C) && slice_ok(dx, dx_cs, dx_coff, C) && mean && rstd && scale &&
                      shift && workspace && B > 0 && HW > 0 && C % 4 == 0 && (order == 0 || order == 1), SOMI_EINVAL,
                  "bn act backward (pooled): bad arguments");
-    SOMI_REQUIRE(davg && dmax && amaxp && aligned16(davg) && aligned16(dmax) && aligned16(amaxp) && aligned16(mean) && aligned16(scale) && aligned16(shift),
-                 SOMI_EINVAL, "bn act backward (pooled): davg / dmax / amaxp (B,C) and the per-channel vectors must be 16 B aligned");
+    SOMI_REQUIRE(davg && !dmax == !amaxp && aligned16(davg) && (!dmax || (aligned16(dmax) && aligned16(amaxp))) && aligned16(mean) && aligned16(scale) &&
+                     aligned16(shift),
+                 SOMI_EINVAL, "bn act backward (pooled): davg (and dmax + amaxp, together or not at all) (B,C) and the per-channel vectors must be 16 B aligned");
     SOMI_REQUIRE(B <= 65535 && (long)B * HW < (1L << 31), SOMI_EINVAL, "bn act backward (pooled): batch beyond the grid's y range");
     const int chunk = red_chunk_img(B, HW), nimg = (HW + chunk - 1) / chunk, rows = B * nimg;
     const size_t cpad = ((size_t)C + 3) / 4 * 4;

@@ -811,11 +811,11 @@ class SEAM(_Packed):
             _bump_batches_tracked(bn)
         return z, tuple(st)
 
-    def _bn_backward(self, dz, u, st, bn):
-        """gradient w.r.t. u of BN_batch(GELU(u)) (order 1), parameter gradients accumulated."""
+    def _bn_backward(self, dz, u, st, bn, pooled=None):
+        """gradient w.r.t. u of BN_batch(GELU(u)) (order 1), parameter gradients accumulated.  pooled: ops.bn_act_backward (dz may then be None)."""
         c = u.shape[3]
         dg, db = torch.zeros(c, device=u.device), torch.zeros(c, device=u.device)
-        du = ops.bn_act_backward(dz, 0, u, 0, c, *st, 'gelu', 1, True, torch.empty_like(u), 0, dg, db)
+        du = ops.bn_act_backward(dz, 0, u, 0, c, *st, 'gelu', 1, True, torch.empty_like(u), 0, dg, db, pooled=pooled)
         _acc_grad(bn.weight, dg)
         _acc_grad(bn.bias, db)
         return du
@@ -845,9 +845,9 @@ class SEAM(_Packed):
         davg, _ = ops.attn_mlp_backward(1, dsc, sc, avg, None, pk['W1'], None, pk['W2'], gW1, None, gW2, None)
         _acc_grad(self.fc[0].weight, gW1)
         _acc_grad(self.fc[2].weight, gW2)
-        dy2 = torch.zeros_like(u2)
-        ops.pool_backward_add_(dy2, 0, c, davg)
-        du2 = self._bn_backward(dy2, u2, s2, st[3])
+        # y2 is read by the global average pool only: its gradient is davg / HW at every pixel - handed to the BatchNorm backward as such
+        # (no zero tensor filled, added to and read twice)
+        du2 = self._bn_backward(None, u2, s2, st[3], pooled=(davg, None, None))
         dwp = ops.conv2d_wgrad_nhwc(y1, du2, kh=1, kw=1)
         _acc_grad(st[1].weight, dwp.view(c, c, 1, 1))
         dbp = torch.zeros(c, device=dev)

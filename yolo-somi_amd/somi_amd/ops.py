@@ -702,7 +702,8 @@ def bn_act_backward(dz, dz_coff, x, x_coff, c, mean, rstd, scale, shift, act, or
                     dbeta=None, pooled=None):
     """pooled = (davg, dmax, amaxp), each (B, c): the gradient of a channel attention's global average / max pools over this tensor, i.e.
     dz_eff = dz + davg / HW + [pixel == amaxp] * dmax.  The image-aligned kernels take it on the fly (dz is only read); under sync-BN - whose
-    reduce / apply entries have no such form - it is added to dz in place by a pass of its own first."""
+    reduce / apply entries have no such form - it is added to dz in place by a pass of its own first.  dmax / amaxp may be None (average pool
+    only); dz may be None when nothing else reads the tensor (the pooled part is the whole gradient)."""
     n = _npix(x)
     if pooled is not None:
         davg, dmax, amaxp = pooled
@@ -710,11 +711,14 @@ def bn_act_backward(dz, dz_coff, x, x_coff, c, mean, rstd, scale, shift, act, or
             B, HW = x.shape[0], x.shape[1] * x.shape[2]
             L = _lib.lib()
             ws = torch.empty(2 * L.somi_bn_pooled_rows(B, HW) * c + 3 * ((c + 3) // 4 * 4), device=x.device, dtype=torch.float32)
-            check(L.somi_bn_act_backward_pooled_nhwc_f32(_ptr(_f32c(dz)), dz.shape[3], dz_coff, _ptr(_f32c(x)), x.shape[3], x_coff, _ptr(mean),
+            check(L.somi_bn_act_backward_pooled_nhwc_f32(_ptr(None if dz is None else _f32c(dz)), 0 if dz is None else dz.shape[3], dz_coff,
+                                                         _ptr(_f32c(x)), x.shape[3], x_coff, _ptr(mean),
                                                          _ptr(rstd), _ptr(scale), _ptr(shift), ACT[act], order, _ptr(davg), _ptr(dmax),
                                                          _ptr(amaxp), _ptr(_f32c(dx)), dx.shape[3], dx_coff, _ptr(dgamma), _ptr(dbeta), B, HW, c,
                                                          _ptr(ws), _stream()), 'bn_act_backward_pooled')
             return dx
+        if dz is None:                                            # dz = None: the pooled part is the whole incoming gradient
+            dz, dz_coff = torch.zeros_like(x), x_coff
         pool_backward_add_(dz, dz_coff, davg.shape[1], davg, dmax, amaxp)
     if SYNC_BN is not None and batch_stats:
         L = _lib.lib()
