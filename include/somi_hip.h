@@ -435,11 +435,6 @@ int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, void *workspace, 
 int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *w_dev,
                             float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
                             int W, int C, somi_stream_t stream);
-/* the same with acc_host[i] (or NULL entries): a gradient source i already holds from its other consumers, added while dsrc[i] is written
- * (dsrc[i] may be the same tensor) - the separate add pass of the layer walk disappears */
-int somi_bifpn_bwd_acc_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const float *const *acc_host, const int *up_host,
-                                const float *w_dev, float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B,
-                                int H, int W, int C, somi_stream_t stream);
 size_t somi_dwconv3x3_bwd_workspace_floats(int B, int W, int C);   /* floats of `workspace` below; C/4 must divide 256 */
 int somi_dwconv3x3_bwd_nhwc_f32(const float *dy, const float *x, const float *w, float *dx, const float *dx_accumulate,
                                 float *dw_accumulate, float *dbias_accumulate, float *workspace, int B, int H, int W, int C,

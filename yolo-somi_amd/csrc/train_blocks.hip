@@ -720,7 +720,6 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_gather_kernel(const uint8_t
 struct BifpnBwdArgs {
     const float *src[3];
     float *dsrc[3];
-    const float *acc[3];   // optional: a gradient the source already holds (its other consumers'), added in the same pass (may alias dsrc)
     int up[3];
     const float *w;      // raw fusion parameter (device)
     float eps;
@@ -747,11 +746,7 @@ __global__ __launch_bounds__(256) void bifpn_bwd_kernel(BifpnBwdArgs a, const fl
             const long sp = (b * (H >> u) + (hv >> u)) * (W >> u) + (wv >> u);
             const f32x4 sv = *reinterpret_cast<const f32x4 *>(a.src[i] + sp * C + c);
             acc[i] += (g[0] * sv[0] + g[1] * sv[1]) + (g[2] * sv[2] + g[3] * sv[3]);
-            if (!u) {
-                f32x4 o = g * wn[i];
-                if (a.acc[i]) o += *reinterpret_cast<const f32x4 *>(a.acc[i] + pix * C + c);
-                *reinterpret_cast<f32x4 *>(a.dsrc[i] + pix * C + c) = o;
-            }
+            if (!u) *reinterpret_cast<f32x4 *>(a.dsrc[i] + pix * C + c) = g * wn[i];
         }
     }
     for (int i = 0; i < 3; ++i) {
@@ -762,7 +757,7 @@ __global__ __launch_bounds__(256) void bifpn_bwd_kernel(BifpnBwdArgs a, const fl
     __syncthreads();
     if (threadIdx.x < 3) part[(long)blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
-__global__ __launch_bounds__(256) void bifpn_bwd_up_kernel(const float *__restrict__ dout, float *dsrc, const float *acc, const float *__restrict__ w,
+__global__ __launch_bounds__(256) void bifpn_bwd_up_kernel(const float *__restrict__ dout, float *__restrict__ dsrc, const float *__restrict__ w,
                                                            int n_in, float eps, int which, int B, int Hl, int Wl, int C) {
     float wn3[3];
     bifpn_norm(w, n_in, eps, wn3);
@@ -778,9 +773,7 @@ __global__ __launch_bounds__(256) void bifpn_bwd_up_kernel(const float *__restri
         const f32x4 s = (*reinterpret_cast<const f32x4 *>(dout + base) + *reinterpret_cast<const f32x4 *>(dout + base + C)) +
                         (*reinterpret_cast<const f32x4 *>(dout + base + (long)Wl * 2 * C) +
                          *reinterpret_cast<const f32x4 *>(dout + base + (long)Wl * 2 * C + C));
-        f32x4 o = s * wn;
-        if (acc) o += *reinterpret_cast<const f32x4 *>(acc + pix * C + c);
-        *reinterpret_cast<f32x4 *>(dsrc + pix * C + c) = o;
+        *reinterpret_cast<f32x4 *>(dsrc + pix * C + c) = s * wn;
     }
 }
 // dw_k += dwn_k / S - (sum_i dwn_i w_i / S^2) * swish'(w_k),  S = sum swish(w) + eps   (models/common.py:3696)
@@ -939,16 +932,15 @@ extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, void *
     return launch_status("somi_sppf_pool_bwd_nhwc_f32");
 }
 
-static int bifpn_bwd_launch(const float *const *src_host, float *const *dsrc_host, const float *const *acc_host, const int *up_host,
-                            const float *w_dev, float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H, int W,
-                            int C, somi_stream_t stream) {
+extern "C" int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *w_dev,
+                                       float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
+                                       int W, int C, somi_stream_t stream) {
     SOMI_REQUIRE(src_host && dsrc_host && up_host && w_dev && dout && dw_accumulate && workspace && (n_in == 2 || n_in == 3) &&
                      C % 4 == 0, SOMI_EINVAL, "bifpn bwd: bad arguments");
     BifpnBwdArgs a;
     for (int i = 0; i < 3; ++i) {
         a.src[i] = i < n_in ? src_host[i] : nullptr;
         a.dsrc[i] = i < n_in ? dsrc_host[i] : nullptr;
-        a.acc[i] = (i < n_in && acc_host) ? acc_host[i] : nullptr;
         a.up[i] = i < n_in ? up_host[i] : 0;
         SOMI_REQUIRE(i >= n_in || (a.src[i] && a.dsrc[i] && (a.up[i] == 0 || a.up[i] == 1)), SOMI_EINVAL, "bifpn bwd: bad source %d", i);
     }
@@ -960,22 +952,10 @@ static int bifpn_bwd_launch(const float *const *src_host, float *const *dsrc_hos
     hipLaunchKernelGGL(bifpn_bwd_kernel, dim3(nblk), dim3(256), 0, s, a, dout, workspace, B, H, W, C);
     for (int i = 0; i < n_in; ++i)
         if (a.up[i])
-            hipLaunchKernelGGL(bifpn_bwd_up_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, dout, a.dsrc[i], a.acc[i], w_dev, n_in,
-                               eps, i, B, H / 2, W / 2, C);
+            hipLaunchKernelGGL(bifpn_bwd_up_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, dout, a.dsrc[i], w_dev, n_in, eps, i, B,
+                               H / 2, W / 2, C);
     hipLaunchKernelGGL(bifpn_bwd_weight_kernel, dim3(1), dim3(64), 0, s, workspace, nblk, w_dev, n_in, eps, dw_accumulate);
     return launch_status("somi_bifpn_bwd_nhwc_f32");
-}
-
-extern "C" int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *w_dev,
-                                       float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace, int B, int H,
-                                       int W, int C, somi_stream_t stream) {
-    return bifpn_bwd_launch(src_host, dsrc_host, nullptr, up_host, w_dev, eps, n_in, dout, dw_accumulate, workspace, B, H, W, C, stream);
-}
-
-extern "C" int somi_bifpn_bwd_acc_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const float *const *acc_host, const int *up_host,
-                                           const float *w_dev, float eps, int n_in, const float *dout, float *dw_accumulate, float *workspace,
-                                           int B, int H, int W, int C, somi_stream_t stream) {
-    return bifpn_bwd_launch(src_host, dsrc_host, acc_host, up_host, w_dev, eps, n_in, dout, dw_accumulate, workspace, B, H, W, C, stream);
 }
 
 extern "C" size_t somi_dwconv3x3_bwd_workspace_floats(int B, int W, int C) {

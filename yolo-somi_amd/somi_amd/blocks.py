@@ -548,14 +548,11 @@ class BiFPN(_Packed):
             self.__dict__['_ctx'] = xs
         return Act(out, 0, xs[0].c)
 
-    def backward(self, dout, accumulate=None):
-        """Returns the list of input gradients (low-resolution for the virtually upsampled inputs).  accumulate: per input an Act (whole
-        contiguous tensor shaped like that input) that already holds the gradient of the input's other consumers, or None - the returned
-        gradient of such an input IS that tensor, with this layer's share added in the pass that computes it."""
+    def backward(self, dout):
+        """Returns the list of input gradients (low-resolution for the virtually upsampled inputs)."""
         xs = self.__dict__.pop('_ctx')
         dw, scratch = _grad_target(self.weight)
-        acc = None if accumulate is None else [None if a is None else a.t for a in accumulate]
-        ds = ops.bifpn_backward([a.t for a in xs], [a.up for a in xs], self.weight.detach(), dout.t, dw, self.epsilon, accumulate=acc)
+        ds = ops.bifpn_backward([a.t for a in xs], [a.up for a in xs], self.weight.detach(), dout.t, dw, self.epsilon)
         if scratch:
             _acc_grad(self.weight, dw)
         return [Act(d, 0, a.c) for d, a in zip(ds, xs)]

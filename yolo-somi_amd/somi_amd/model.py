@@ -250,22 +250,7 @@ class Model(nn.Module):
             if g is None:
                 raise RuntimeError(f'layer {m.i} ({m.type}) received no gradient')
             srcs = self._sources(m)
-            if isinstance(m, B.BiFPN):
-                # a source that already holds another consumer's gradient (a whole contiguous tensor of the source's own shape) gets this
-                # layer's share added inside the BiFPN backward kernel - no separate add pass.  A virtually upsampled input's gradient belongs
-                # to the Upsample layer in between (same low-resolution shape): it is looked up under that layer's index
-                have = []
-                for src, a in zip(srcs, m.__dict__['_ctx']):
-                    h = grads.get(src)
-                    ok = (ops.BIFPN_ACC and h is not None and h.coff == 0 and h.t.shape[3] == B.pad4(h.c) == a.t.shape[3] and h.t.is_contiguous() and
-                          tuple(h.t.shape) == tuple(a.t.shape))
-                    have.append(h if ok else None)
-                for src, d, h in zip(srcs, m.backward(g, accumulate=have), have):
-                    if h is not None:
-                        grads[src] = d                            # = h's tensor, now the sum
-                    else:
-                        give(src, d)
-            elif isinstance(m, B.Concat):
+            if isinstance(m, (B.BiFPN, B.Concat)):
                 for src, d in zip(srcs, m.backward(g)):
                     give(src, d)
             elif srcs[0] < 0:

@@ -26,7 +26,6 @@ CONV_PREC = 0
 PREC = {None: 0, 'f32': 0, 'bf16': 1, 'bf16x3': 2}
 FUSE_POOL = os.environ.get('SOMI_FUSE_POOL', '1') != '0'      # 0: the channel attention pools its input in a pass of its own (round-3 form; A/B runs)
 AMAX_BY_VALUE = os.environ.get('SOMI_AMAX_BY_VALUE', '1') != '0'   # 0: the max-pool's arg-max from somi_pool_argmax_nhwc_f32's own pass over the tensor
-BIFPN_ACC = os.environ.get('SOMI_BIFPN_ACC', '1') != '0'      # 0: a BiFPN input's gradient is added to its other consumers' by a pass of its own
 BN_POOLED = os.environ.get('SOMI_BN_POOLED', '1') != '0'    # 0: CBAM's pooled gradients are added by a pass of their own (round-3 form; A/B runs)
 
 
@@ -831,23 +830,15 @@ def sppf_pool_backward_(buf, dbuf, c, x_coff=0):
     return dbuf
 
 
-def bifpn_backward(srcs, ups, w_dev, dout, dw, eps=1e-4, accumulate=None):
-    """accumulate: per source a tensor like that source holding the gradient of its OTHER consumers (or None): the source's gradient is then
-    written into that very tensor as its sum with this layer's share (no separate add pass), and that tensor is what is returned for it."""
+def bifpn_backward(srcs, ups, w_dev, dout, dw, eps=1e-4):
     n = len(srcs)
     B, H, W, Cc = dout.shape
-    acc = list(accumulate) if accumulate is not None else [None] * n
-    dsrcs = [a if a is not None else torch.empty_like(s) for s, a in zip(srcs, acc)]
+    dsrcs = [torch.empty_like(s) for s in srcs]
     sp = (C.c_void_p * n)(*[_ptr(_f32c(s)) for s in srcs])
     dp = (C.c_void_p * n)(*[_ptr(d) for d in dsrcs])
     ws = torch.empty(3 * 2048, device=dout.device, dtype=torch.float32)
-    if any(a is not None for a in acc):
-        ap = (C.c_void_p * n)(*[_ptr(a) for a in acc])
-        check(_lib.lib().somi_bifpn_bwd_acc_nhwc_f32(sp, dp, ap, (C.c_int * n)(*ups), _ptr(_f32c(w_dev)), float(eps), n,
-                                                     _ptr(_f32c(dout)), _ptr(dw), _ptr(ws), B, H, W, Cc, _stream()), 'bifpn_bwd')
-    else:
-        check(_lib.lib().somi_bifpn_bwd_nhwc_f32(sp, dp, (C.c_int * n)(*ups), _ptr(_f32c(w_dev)), float(eps), n,
-                                                 _ptr(_f32c(dout)), _ptr(dw), _ptr(ws), B, H, W, Cc, _stream()), 'bifpn_bwd')
+    check(_lib.lib().somi_bifpn_bwd_nhwc_f32(sp, dp, (C.c_int * n)(*ups), _ptr(_f32c(w_dev)), float(eps), n,
+                                             _ptr(_f32c(dout)), _ptr(dw), _ptr(ws), B, H, W, Cc, _stream()), 'bifpn_bwd')
     return dsrcs
 
 
