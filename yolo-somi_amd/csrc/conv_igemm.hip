@@ -72,6 +72,9 @@ struct ConvArgs {
     int dgrad;    // 1: data-gradient geometry (rows = forward-input pixels, source = dy, taps walk backwards, stride parity)
     int cls;      // dgrad on the FAST path: grid.y = stride^2 parity classes, each walks only the taps that reach it
     int sk;       // stream-K: gridDim.x persistent workgroups share tiles_m*tiles_n*nkt units (FAST, no strided classes)
+    int sk_whole; // hybrid: every workgroup first takes sk_whole WHOLE tiles (tile j * gridDim.x + wg), only the tiles behind them are streamed
+    int sk_rem_g; // ... over this many workgroups (<= gridDim.x: pieces shorter than a few K-tiles are not worth a partial store)
+    int sk_grid_main;   // gridDim.x of the main kernel (the fix-up kernel needs it to find the first streamed tile)
     float *ws;    // stream-K partial accumulators: [workgroup][2][BM*BN]
     int ns;       // 0: exact fp32; 1: bf16 operands; 2: bf16x3 split (plain FAST launches of the 8-wave tiles only)
 };
@@ -264,9 +267,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (conv_waves_per_simd<BM, BN
     const int ntile = a.tiles_m * a.tiles_n;
     const bool sk = FAST && a.sk;
     const int wg = sk ? xcd_remap(blockIdx.x, gridDim.x) : 0;
-    const long U = (long)ntile * nkt;
-    long u = sk ? sk_lo(wg, U, gridDim.x) : (long)xcd_remap(blockIdx.x, ntile) * (nkt > 0 ? nkt : 1);
-    const long u_lo = u, u_hi = sk ? sk_lo(wg + 1, U, gridDim.x) : u + (nkt > 0 ? nkt : 1);
+    // hybrid stream-K (round 4): whole rounds of tiles run like the plain schedule - tile j * G + wg, no cut, no partial store - and only the
+    // tiles behind them (fewer than G) are streamed, over sk_rem_g workgroups.  The partials and the fix-up shrink from one seam per workgroup
+    // (64 MiB written + read, 19.4 us x 193 launches per step) to the seams of the last partial round.
+    const int sk_whole = sk ? a.sk_whole : 0, tile_base = sk ? sk_whole * (int)gridDim.x : 0, Gr = sk ? a.sk_rem_g : 1;
+    const long U = (long)(ntile - tile_base) * nkt;                  // streamed units
+    long u = sk ? sk_lo(min(wg, Gr), U, Gr) : (long)xcd_remap(blockIdx.x, ntile) * (nkt > 0 ? nkt : 1);
+    const long u_lo = u, u_hi = sk ? sk_lo(min(wg + 1, Gr), U, Gr) : u + (nkt > 0 ? nkt : 1);
+    int whole_left = sk_whole;
 
     // A thread owns LDS chunk slot (tid & 7) of rows row0 + RPP*i; the slot holds k-chunk slot ^ ((row >> 1) & 7), and (row >> 1) & 7 is
     // the same for all of a thread's rows (RPP, BM are multiples of 16), so the swizzle is one XOR on the thread's fetch column.
@@ -287,11 +295,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (conv_waves_per_simd<BM, BN
 #pragma unroll
     for (int j = 0; j < 4; ++j) fo[j] = ((2 * j + (lane >> 5)) ^ ((lane >> 1) & 7)) << 2;
 
-    while (u < u_hi) {
-        const int tile = (int)(u / (nkt > 0 ? nkt : 1));
-        const int kt0 = nkt > 0 ? (int)(u % nkt) : 0;
-        const int kt1 = sk ? (int)min((long)nkt, kt0 + (u_hi - u)) : nkt;
-        u += sk ? kt1 - kt0 : (nkt > 0 ? nkt : 1);
+    while (whole_left > 0 || u < u_hi) {
+        int tile, kt0, kt1;
+        const bool whole = whole_left > 0;
+        if (whole) {                                                  // a whole tile of this workgroup's rounds
+            tile = (sk_whole - whole_left) * (int)gridDim.x + wg;
+            kt0 = 0;
+            kt1 = nkt;
+            --whole_left;
+        } else {
+            tile = tile_base + (int)(u / (nkt > 0 ? nkt : 1));
+            kt0 = nkt > 0 ? (int)(u % nkt) : 0;
+            kt1 = sk ? (int)min((long)nkt, kt0 + (u_hi - u)) : nkt;
+            u += sk ? kt1 - kt0 : (nkt > 0 ? nkt : 1);
+        }
         const int tile_m = tile / a.tiles_n, tile_n = tile % a.tiles_n;   // n fastest: neighbours share the activation rows
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         if (m0 >= Mrows) return;                                          // smaller class than the grid was sized for (never stream-K)
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (conv_waves_per_simd<BM, BN
         } else {
             // a cut tile: raw accumulators to this workgroup's slot (0: the run starts with this piece, 1: it ends with it),
             // one coalesced float per lane per register
-            const bool first_piece = (long)tile * nkt + kt0 == u_lo;
+            const bool first_piece = (long)(tile - tile_base) * nkt + kt0 == u_lo;
             float *slot = a.ws + ((size_t)wg * 2 + (first_piece ? 0 : 1)) * (BM * BN);
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn)
@@ -596,11 +613,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32, NT = WAVES_M * WAVES_N * 64;
     __shared__ __attribute__((aligned(16))) float lds[TileLds<BM, BN, WAVES_M, WAVES_N>::FLOATS];
     const int nkt = a.K / BK, ntile = a.tiles_m * a.tiles_n;
-    const long U = (long)ntile * nkt;
+    const int tile_base = a.sk_whole * a.sk_grid_main;               // the streamed tiles sit behind the whole rounds; G = sk_rem_g
+    const long U = (long)(ntile - tile_base) * nkt;
     const int g = blockIdx.x + 1;
     const long b = sk_lo(g, U, G);
     if (b % nkt == 0) return;                                         // the boundary coincides with a tile boundary
-    const int tile = (int)(b / nkt);
+    const int tile = (int)(b / nkt);                                  // index among the streamed tiles
     const long t_lo = (long)tile * nkt, t_hi = t_lo + nkt;
     if (sk_lo(g - 1, U, G) > t_lo) return;                            // an earlier boundary inside this tile does the work
     const int tid = threadIdx.x;
@@ -651,7 +669,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM + BN > 320 ? 2 : WAVES_
         if (!s1) break;
     }
     const RowMap rmap = {a.M, a.d.Ho * a.d.Wo, a.d.Wo, 1, 0, 0, 0, false};
-    conv_epilogue<BM, BN, WAVES_M, WAVES_N>(acc, lds, a, rmap, (tile / a.tiles_n) * BM, (tile % a.tiles_n) * BN);
+    const int gt = tile_base + tile;
+    conv_epilogue<BM, BN, WAVES_M, WAVES_N>(acc, lds, a, rmap, (gt / a.tiles_n) * BM, (gt % a.tiles_n) * BN);
 }
 
 struct TilePlan {
@@ -732,10 +751,25 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
     // fix-up then cost more than the MFMA work of the piece)
     static const int min_kt = getenv("SOMI_SK_MIN_KT") ? atoi(getenv("SOMI_SK_MIN_KT")) : 8;
     int sk_grid = BM + BN > 320 ? SK_GRID / 2 : (WAVES_M * WAVES_N == 8 && BM + BN <= 192 && fast && three_per_cu(5, a.d) ? SK_GRID * 3 / 2 : SK_GRID);
+    int fix_grid = 0;
+    args.sk_whole = 0;
+    args.sk_rem_g = args.sk_grid_main = 1;
     if (sk) {
-        const long U = (long)args.tiles_m * args.tiles_n * (a.K / BK);
+        const long ntile = (long)args.tiles_m * args.tiles_n, nkt = a.K / BK, U = ntile * nkt;
         if (U / min_kt < sk_grid) sk_grid = (int)(U / min_kt);
         if (sk_grid < 2) sk_grid = 2;
+        // hybrid: whole rounds first, the remainder streamed (SOMI_SK_HYBRID=0: everything streamed, the round-1..3 schedule)
+        static const int hybrid = getenv("SOMI_SK_HYBRID") ? atoi(getenv("SOMI_SK_HYBRID")) : 1;
+        const int whole = hybrid ? (int)(ntile / sk_grid) : 0;
+        const long u_rem = (ntile - (long)whole * sk_grid) * nkt;
+        int gr = sk_grid;
+        static const int rem_min_kt = getenv("SOMI_SK_REM_MIN_KT") ? atoi(getenv("SOMI_SK_REM_MIN_KT")) : 4;
+        if (whole > 0 && u_rem / rem_min_kt < gr) gr = (int)(u_rem / rem_min_kt);   // no streamed piece shorter than this many K-tiles
+        if (gr < 1) gr = 1;
+        args.sk_whole = whole;
+        args.sk_rem_g = gr;
+        args.sk_grid_main = sk_grid;
+        fix_grid = u_rem > 0 ? gr - 1 : 0;                              // one seam per boundary between streamed runs
     }
     const dim3 grid(sk ? sk_grid : args.tiles_m * args.tiles_n, ncls, a.d.per_sample_w ? a.d.B : 1);
     if constexpr (WAVES_M * WAVES_N == 8 && BM + BN <= 320) {
@@ -744,8 +778,8 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
                 hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true, 1>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
             else
                 hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true, 2>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
-            if (sk)
-                hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(sk_grid - 1), dim3(WAVES_M * WAVES_N * 64), 0, s, args, sk_grid);
+            if (sk && fix_grid > 0)
+                hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(fix_grid), dim3(WAVES_M * WAVES_N * 64), 0, s, args, args.sk_rem_g);
             return launch_status("somi_conv2d_nhwc_f32 (bf16)");
         }
     }
@@ -757,8 +791,8 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
     else
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, dim3(WAVES_M * WAVES_N * 64), 0, s, args);
-    if (sk)
-        hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(sk_grid - 1), dim3(WAVES_M * WAVES_N * 64), 0, s, args, sk_grid);
+    if (sk && fix_grid > 0)
+        hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(fix_grid), dim3(WAVES_M * WAVES_N * 64), 0, s, args, args.sk_rem_g);
     return launch_status("somi_conv2d_nhwc_f32");
 }
 
