@@ -267,9 +267,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (conv_waves_per_simd<BM, BN
     const int ntile = a.tiles_m * a.tiles_n;
     const bool sk = FAST && a.sk;
     const int wg = sk ? xcd_remap(blockIdx.x, gridDim.x) : 0;
-    // hybrid stream-K (round 4): whole rounds of tiles run like the plain schedule - tile j * G + wg, no cut, no partial store - and only the
-    // tiles behind them (fewer than G) are streamed, over sk_rem_g workgroups.  The partials and the fix-up shrink from one seam per workgroup
-    // (64 MiB written + read, 19.4 us x 193 launches per step) to the seams of the last partial round.
+    // hybrid stream-K (round 4, an experiment switch: sk_whole = 0 by default): whole rounds of tiles run like the plain schedule - tile
+    // j * G + wg, no cut, no partial store - and only the tiles behind them (fewer than G) are streamed, over sk_rem_g workgroups.  The partials
+    // and the fix-up shrink from one seam per workgroup (64 MiB written + read, 19.4 us x 193 launches per step) to the seams of the last partial
+    // round - and the step does not get faster (launch<>).
     const int sk_whole = sk ? a.sk_whole : 0, tile_base = sk ? sk_whole * (int)gridDim.x : 0, Gr = sk ? a.sk_rem_g : 1;
     const long U = (long)(ntile - tile_base) * nkt;                  // streamed units
     long u = sk ? sk_lo(min(wg, Gr), U, Gr) : (long)xcd_remap(blockIdx.x, ntile) * (nkt > 0 ? nkt : 1);
@@ -758,8 +759,10 @@ static int launch(const ConvArgs &a, bool sk, hipStream_t s) {
         const long ntile = (long)args.tiles_m * args.tiles_n, nkt = a.K / BK, U = ntile * nkt;
         if (U / min_kt < sk_grid) sk_grid = (int)(U / min_kt);
         if (sk_grid < 2) sk_grid = 2;
-        // hybrid: whole rounds first, the remainder streamed (SOMI_SK_HYBRID=0: everything streamed, the round-1..3 schedule)
-        static const int hybrid = getenv("SOMI_SK_HYBRID") ? atoi(getenv("SOMI_SK_HYBRID")) : 1;
+        // hybrid (SOMI_SK_HYBRID=1): whole rounds first, only the remainder streamed.  Measured round 4 (interleaved 40-step runs on one box):
+        // 330.1 - 330.8 ms per step against 329.6 - 329.9 with everything streamed - the fix-up shrinks, but the short remainder pieces and the
+        // lost balance cost as much.  Off by default.
+        static const int hybrid = getenv("SOMI_SK_HYBRID") ? atoi(getenv("SOMI_SK_HYBRID")) : 0;
         const int whole = hybrid ? (int)(ntile / sk_grid) : 0;
         const long u_rem = (ntile - (long)whole * sk_grid) * nkt;
         int gr = sk_grid;
