@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SOMI_ABI_VERSION 13
+#define SOMI_ABI_VERSION 14
 
 #define SOMI_EINVAL   (-1) /* bad shape / stride / alignment */
 #define SOMI_ENOTIMPL (-2) /* configuration outside the SOMI path */
@@ -398,10 +398,26 @@ int somi_cbam_bwd_pixel_f32(const float *dt2, int d_cs, int d_coff, const float 
 int somi_cbam_bwd_pixel_argmax_f32(const float *dt2, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,
                                    const float *sa, const float *t_max, float *dlogit, int32_t *amaxc, int32_t *amaxp, int B, int HW, int C,
                                    somi_stream_t stream);
-/* B: gradient of sigmoid's argument through the k x k conv: dstats (B,H,W,2); dw [k][k][2] and dbias ACCUMULATED.
- * workspace: ceil(B*H*W/1024) * (2*k*k+1) floats */
+/* B: gradient of sigmoid's argument through the k x k conv: dstats (B,H,W,2); dw and dbias ACCUMULATED; dw_chw = 0: dw laid out [k][k][2] like
+ * the forward's packed weight, 1: (2,k,k) - nn.Conv2d(2, 1, k).weight's own layout, so that the parameter's .grad can be the target.
+ * workspace: ceil(B*H*W/512) * (2*k*k+1) floats */
 int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const float *w, float *dstats, float *dw_accumulate,
-                              float *dbias_accumulate, float *workspace, int B, int H, int W, int k, somi_stream_t stream);
+                              float *dbias_accumulate, float *workspace, int B, int H, int W, int k, int dw_chw, somi_stream_t stream);
+/* Step C INSIDE the BatchNorm + SiLU backward of the bottleneck's first conv (models/common.py:671-691: cv1 = Conv -> BN -> SiLU, then t*ca*sa):
+ * d = gradient w.r.t. t*ca*sa, y = cv1's convolution output, t = silu(scale*y + shift) is rebuilt in registers, dt never exists in memory.
+ *   reduce: dca[b,c] = sum_p dt1*t (as step C) and, per (image chunk, channel), the separable batch sums of dt*silu'(u) - kept in `workspace`;
+ *   (the caller then runs somi_attn_mlp_bwd_f32 on dca -> davg, dmax)
+ *   apply:  the BatchNorm backward (batch statistics) of dz = dt + davg/HW + [p == amaxp]*dmax: dx, dgamma / dbeta ACCUMULATED.
+ * Same tensors and `workspace` (somi_cbam_bn_bwd_workspace_floats(B,HW,C) floats) for both calls.  amaxp (B,C): first pixel of each channel's spatial
+ * maximum (somi_cbam_bwd_pixel_argmax_f32); amaxc, dstats: steps A / B. */
+size_t somi_cbam_bn_bwd_workspace_floats(int B, int HW, int C);
+int somi_cbam_bn_bwd_reduce_f32(const float *d, int d_cs, int d_coff, const float *y, int y_cs, int y_coff, const float *scale, const float *shift,
+                                const float *mean, const float *ca, const float *sa, const float *dstats, const int32_t *amaxc,
+                                const int32_t *amaxp, float *dca, float *workspace, int B, int HW, int C, somi_stream_t stream);
+int somi_cbam_bn_bwd_apply_f32(const float *d, int d_cs, int d_coff, const float *y, int y_cs, int y_coff, const float *scale, const float *shift,
+                               const float *mean, const float *rstd, const float *ca, const float *sa, const float *dstats, const int32_t *amaxc,
+                               const int32_t *amaxp, const float *davg, const float *dmax, float *dx, int dx_cs, int dx_coff, float *dgamma,
+                               float *dbeta, float *workspace, int B, int HW, int C, somi_stream_t stream);
 /* C: dt1 = dt2*sa + dstats0/C + [c==amaxc]*dstats1; dca[b,c] = sum_p dt1*t; dt2 <- dt1*ca (in place).
  * workspace: B*nchunk*C floats */
 int somi_cbam_bwd_chan_f32(float *dt2_inout, int d_cs, int d_coff, const float *t, int t_cs, int t_coff, const float *ca,

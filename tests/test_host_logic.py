@@ -4,6 +4,8 @@ refuses to run without a GPU instead of falling back."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -21,7 +23,18 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(L, name), f'{name} is declared in include/somi_hip.h but not exported'
-    assert _lib.lib().somi_abi_version() == _lib.ABI_VERSION == 13
+    assert _lib.lib().somi_abi_version() == _lib.ABI_VERSION == 14
+
+
+def test_one_hip_runtime_in_the_process_whatever_is_imported_first():
+    """The binding loaded BEFORE torch used to map /opt/rocm's libamdhip64 next to the copy torch's wheel carries: two HIP runtimes, and the library's
+    launches failed with "no ROCm-capable device" (seen on the GPU box through `python __graft_entry__.py smoke`, whose build() loads the library
+    first).  _lib.lib() imports torch first; a fresh process that touches the binding before anything else must end up with ONE mapped runtime."""
+    code = ("import sys; sys.path.insert(0, %r); from somi_amd import _lib; _lib.lib(); import torch; "
+            "paths = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}; print(len(paths), sorted(paths))" % os.path.join(ROOT, 'yolo-somi_amd'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == '1', out.stdout
 
 
 def test_struct_layouts_match_header():

@@ -249,6 +249,38 @@ def test_attention_pieces():
     assert torch.equal(wd[..., :16].cpu(), wide[..., :16]) and torch.equal(wd[..., 16 + C:].cpu(), wide[..., 16 + C:])
 
 
+@pytest.mark.parametrize('k', [3, 5, 7])
+@pytest.mark.parametrize('B,H,W', [(3, 37, 29), (2, 8, 8), (1, 70, 65)])
+def test_spatial_attention_backward_against_conv2d_autograd(k, B, H, W):
+    """somi_spatial_attn_bwd_f32 (gradient of the k x k, 2 -> 1 conv under the sigmoid) against F.conv2d's autograd in fp64: data gradient, weight
+    gradient in both layouts ([k][k][2] and nn.Conv2d's (2,k,k)), bias gradient - ACCUMULATED onto non-zero buffers.  Maps whose pixel count is not
+    a multiple of the 512-pixel chunk, chunks that span image boundaries, a batch smaller than one chunk."""
+    from somi_amd import _lib
+    from somi_amd.ops import _ptr, _stream, check
+    d = dev()
+    g = torch.Generator().manual_seed(k * 100 + H)
+    dlogit = torch.randn(B, H, W, generator=g)
+    stats = torch.randn(B, H, W, 2, generator=g)
+    w = torch.randn(1, 2, k, k, generator=g) * 0.2
+    s64 = stats.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = torch.zeros(1, dtype=torch.float64, requires_grad=True)
+    F.conv2d(s64, w64, b64, padding=k // 2).backward(dlogit.double()[:, None])
+    L = _lib.lib()
+    for chw in (0, 1):
+        dw0 = torch.randn(2, k, k, generator=g) if chw else torch.randn(k, k, 2, generator=g)
+        db0 = torch.randn(1, generator=g)
+        dw, db = dw0.to(d), db0.to(d)
+        dstats = torch.empty(B, H, W, 2, device=d)
+        ws = torch.empty(((B * H * W + 511) // 512) * (2 * k * k + 1), device=d)
+        check(L.somi_spatial_attn_bwd_f32(_ptr(dlogit.to(d)), _ptr(stats.to(d)), _ptr(w[0].permute(1, 2, 0).contiguous().to(d)), _ptr(dstats), _ptr(dw),
+                                          _ptr(db), _ptr(ws), B, H, W, k, chw, _stream()), 'spatial_attn_bwd')
+        want_dw = w64.grad[0] if chw else w64.grad[0].permute(1, 2, 0)
+        rel_close(dstats, s64.grad.permute(0, 2, 3, 1), rel=1e-5, what=f'dstats k{k}')
+        rel_close(dw.cpu().double() - dw0.double(), want_dw, rel=2e-5, what=f'dw k{k} chw{chw}')
+        rel_close(db.cpu().double() - db0.double(), b64.grad, rel=2e-5, what=f'dbias k{k}')
+
+
 def test_detect_decode():
     from somi_amd import ops
     d = dev()

@@ -185,6 +185,40 @@ def test_c2fcbam_train_forward_backward(c1, c2, n, shortcut):
     _run_block_train(mine, ref, x, 21, 'C2fCBAM', c1)
 
 
+@pytest.mark.parametrize('c,n,B,H,W', [(64, 2, 3, 37, 29), (256, 1, 2, 20, 20), (16, 1, 5, 45, 31)])
+def test_cbam_step_c_inside_the_batchnorm_backward_equals_the_three_pass_form(c, n, B, H, W, monkeypatch):
+    """somi_cbam_bn_bwd_reduce_f32 / _apply_f32 (step C of the CBAM backward rebuilt in registers inside the first conv's BatchNorm + SiLU backward)
+    against the form it replaces (somi_cbam_bwd_chan_f32 writing dt, then the pooled BatchNorm backward): same block, same tensors, every parameter
+    gradient and the input gradient.  Ragged maps (chunks that end inside an image, arg-max pixels in the last chunk), hidden widths 32 / 128 / 8;
+    both forms are separately held to the oracle by test_c2fcbam_train_forward_backward."""
+    from somi_amd import blocks as MB, ops
+    g = torch.Generator().manual_seed(c + H)
+    blk = MB.C2fCBAM(c, c, n, True)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.5 if p_.dim() < 2 else (2.0 / max(1, p_[0].numel())) ** 0.5))
+        for m in blk.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(0.5 + torch.rand(m.weight.shape, generator=g))
+    blk = blk.cuda().train()
+    x = torch.randn(B, H, W, c, generator=g).cuda()
+    dy = torch.randn(B, H, W, c, generator=g).cuda()
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'CBAM_FUSED_BN', fused)
+        for p_ in blk.parameters():
+            p_.grad = None
+        blk(MB.Act(x.clone()))
+        dx = blk.backward(MB.Act(dy.clone()))
+        torch.cuda.synchronize()
+        res[fused] = {'dx': dx.t[..., :c].clone(), **{n_: p_.grad.clone() for n_, p_ in blk.named_parameters()}}
+    assert set(res[True]) == set(res[False])
+    for k in res[True]:
+        a, b = res[True][k].double(), res[False][k].double()
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+        assert err < 5e-5, f'{k}: fused vs three-pass {err:.2e}'
+
+
 def test_sppf_seam_train_forward_backward():
     from oracle.somi_ref import blocks as OB
     from oracle.somi_ref.testing import fill_state

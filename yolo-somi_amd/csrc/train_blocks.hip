@@ -122,11 +122,14 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_kernel(const floa
     __syncthreads();
     if (threadIdx.x == 0) part[(long)blockIdx.x * (nw + 1) + j] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
-// The same sums, one workgroup per SAW_CHUNK pixels for ALL weights: the chunk's dlogit, its pixel coordinates and the stats rows it can reach
-// (+- pad rows and columns) are staged in LDS once; thread (kernel position, slice) then walks every nsl-th pixel of the chunk for both input
-// channels in fp64, and the slices are added in a fixed order.  (Round 3: the form above - a workgroup per (chunk, weight), 64-bit division per
-// pixel and term - took 121 us per call at 160x160 for 81 M multiply-adds.)
-constexpr int SAW_CHUNK = 2048;
+// The same sums, one workgroup per SAW_CHUNK pixels for ALL weights: the chunk's dlogit, a per-pixel validity mask (bit r: row h + r - pad is inside
+// the image, bit 8 + q: column w + q - pad is) and the stats rows it can reach (+- pad rows and columns) are staged in LDS once; thread (kernel
+// position, slice) then walks every nsl-th pixel of the chunk for both input channels in fp64, and the slices are added in a fixed order.
+// (Round 3: the form above - a workgroup per (chunk, weight), 64-bit division per pixel and term - took 121 us per call at 160x160 for 81 M
+// multiply-adds.  Round 4: chunks of 2048 pixels made ONE workgroup's serial walk (410 pixels per thread, each a chain of dependent LDS reads behind a
+// bounds branch) the launch's duration - 57 us on every map size, 25 workgroups on a 40x40 map; now 512 pixels per workgroup, the reads
+// unconditional (an invalid tap multiplies by zero) and four pixels in flight.)
+constexpr int SAW_CHUNK = 512;
 __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_tile_kernel(const float *__restrict__ dlogit, const float *__restrict__ stats,
                                                                            float *__restrict__ part, int B, int H, int W, int k) {
     extern __shared__ __attribute__((aligned(16))) float saw_lds[];
@@ -135,18 +138,27 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_tile_kernel(const
     const long p0 = (long)blockIdx.x * SAW_CHUNK;
     const int np = (int)min((long)SAW_CHUNK, npix - p0);
     float *sdl = saw_lds;                                              // [SAW_CHUNK] dlogit
-    int *shw = reinterpret_cast<int *>(saw_lds + SAW_CHUNK);           // [SAW_CHUNK] row << 16 | column
+    int *svm = reinterpret_cast<int *>(saw_lds + SAW_CHUNK);           // [SAW_CHUNK] validity bits of the k rows (0..) and k columns (8..)
     float *sst = saw_lds + 2 * SAW_CHUNK;                              // [SAW_CHUNK + 2 halo][2] stats
-    for (int i = tid; i < np; i += 256) {
+    for (int i = tid; i < SAW_CHUNK; i += 256) {
         const long p = p0 + i;
-        sdl[i] = dlogit[p];
-        shw[i] = (int)((p / W) % H) << 16 | (int)(p % W);
+        float g = 0.f;
+        int m = 0;
+        if (i < np) {
+            g = dlogit[p];
+            const int hv = (int)((p / W) % H), wv = (int)(p % W);
+            for (int r = 0; r < k; ++r) {
+                m |= ((unsigned)(hv + r - pad) < (unsigned)H) << r;
+                m |= ((unsigned)(wv + r - pad) < (unsigned)W) << (8 + r);
+            }
+        }
+        sdl[i] = g;                                                    // pixels past the end: dlogit 0, no valid tap
+        svm[i] = m;
     }
-    for (int i = tid; i < np + 2 * halo; i += 256) {
+    for (int i = tid; i < SAW_CHUNK + 2 * halo; i += 256) {
         const long q = p0 - halo + i;
         const float2 v = (q >= 0 && q < npix) ? *reinterpret_cast<const float2 *>(stats + q * 2) : make_float2(0.f, 0.f);
-        sst[i * 2] = v.x;
-        sst[i * 2 + 1] = v.y;
+        *reinterpret_cast<float2 *>(sst + i * 2) = v;
     }
     __syncthreads();
     const int nsl = 256 / kk;                                          // 5 / 10 / 28 slices for k = 7 / 5 / 3
@@ -154,15 +166,34 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_tile_kernel(const
     if (tid < kk * nsl) {
         const int rq = tid % kk, sl = tid / kk, r = rq / k, q = rq % k;
         const int off = (r - pad) * W + (q - pad) + halo;
-        for (int i = sl; i < np; i += nsl) {
-            const int hw = shw[i];
-            const int hi = (hw >> 16) + r - pad, wi = (hw & 0xffff) + q - pad;
-            const double g = (double)sdl[i];
-            if (rq == 0) ab += g;                                      // the bias: each slice's position-0 thread sums its pixels' dlogit
-            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
-                a0 += g * (double)sst[(i + off) * 2];
-                a1 += g * (double)sst[(i + off) * 2 + 1];
+        const int sel = (1 << r) | (1 << (8 + q));
+        const bool first = rq == 0;                                    // the bias: each slice's position-0 thread sums its pixels' dlogit
+        int i = sl;
+        for (; i + 3 * nsl < SAW_CHUNK; i += 4 * nsl) {               // the chunk is padded with zeros, so no tail test on np
+            float g[4];
+            int m[4];
+            float2 st[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = sdl[i + u * nsl];
+                m[u] = svm[i + u * nsl];
+                st[u] = *reinterpret_cast<const float2 *>(sst + (i + u * nsl + off) * 2);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (first) ab += (double)g[u];
+                const double gd = (m[u] & sel) == sel ? (double)g[u] : 0.0;
+                a0 += gd * (double)st[u].x;
+                a1 += gd * (double)st[u].y;
+            }
+        }
+        for (; i < SAW_CHUNK; i += nsl) {
+            const float g = sdl[i];
+            const float2 st = *reinterpret_cast<const float2 *>(sst + (i + off) * 2);
+            if (first) ab += (double)g;
+            const double gd = (svm[i] & sel) == sel ? (double)g : 0.0;
+            a0 += gd * (double)st.x;
+            a1 += gd * (double)st.y;
         }
     }
     __syncthreads();
@@ -184,7 +215,8 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_tile_kernel(const
     }
 }
 // one workgroup per weight: the chunk partials in fp64, fixed order (thread-strided sums, then waves, then the four wave sums)
-__global__ __launch_bounds__(256) void spatial_attn_bwd_weight_final(const float *__restrict__ part, int nblk, int nw, float *dw, float *dbias) {
+__global__ __launch_bounds__(256) void spatial_attn_bwd_weight_final(const float *__restrict__ part, int nblk, int nw, float *dw, float *dbias,
+                                                                     int chw) {
     __shared__ double red[4];
     const int j = blockIdx.x;
     double s = 0.0;
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(256) void spatial_attn_bwd_weight_final(const float
     if (threadIdx.x != 0) return;
     const float v = (float)((red[0] + red[1]) + (red[2] + red[3]));
     if (j == nw) *dbias += v;
-    else dw[j] += v;
+    else dw[chw ? (j & 1) * (nw >> 1) + (j >> 1) : j] += v;      // [k][k][2] (the packed forward layout), or nn.Conv2d's (1,2,k,k)
 }
 
 // ------------------------------------------------------------------------------------------------ C
@@ -539,7 +571,8 @@ extern "C" int somi_cbam_bwd_pixel_argmax_f32(const float *dt2, int d_cs, int d_
 }
 
 extern "C" int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats, const float *w, float *dstats, float *dw_accumulate,
-                                         float *dbias_accumulate, float *workspace, int B, int H, int W, int k, somi_stream_t stream) {
+                                         float *dbias_accumulate, float *workspace, int B, int H, int W, int k, int dw_chw,
+                                         somi_stream_t stream) {
     SOMI_REQUIRE(dlogit && stats && w && dstats && dw_accumulate && dbias_accumulate && workspace && B > 0 && H > 0 && W > 0 &&
                      (k == 3 || k == 5 || k == 7), SOMI_EINVAL, "spatial attn bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -548,7 +581,7 @@ extern "C" int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats
     const int nw = k * k * 2, halo = (k >> 1) * (W + 1);
     const size_t lds = (size_t)(4 * SAW_CHUNK + 4 * halo) * sizeof(float);
     int nblk;
-    if (lds <= 64 * 1024 && H < 32768 && W < 65536) {                // workspace: (npix / 1024 rounded up) rows of nw + 1 floats - half of them used
+    if (lds <= 64 * 1024) {                                           // workspace: (npix / 512 rounded up) rows of nw + 1 floats
         nblk = (int)((npix + SAW_CHUNK - 1) / SAW_CHUNK);
         hipLaunchKernelGGL(spatial_attn_bwd_weight_tile_kernel, dim3(nblk), dim3(256), lds, s, dlogit, stats, workspace, B, H, W, k);
     } else {
@@ -556,7 +589,8 @@ extern "C" int somi_spatial_attn_bwd_f32(const float *dlogit, const float *stats
         nblk = (int)((npix + chunk - 1) / chunk);
         hipLaunchKernelGGL(spatial_attn_bwd_weight_kernel, dim3(nblk, nw + 1), dim3(256), 0, s, dlogit, stats, workspace, B, H, W, k, chunk);
     }
-    hipLaunchKernelGGL(spatial_attn_bwd_weight_final, dim3(nw + 1), dim3(256), 0, s, workspace, nblk, nw, dw_accumulate, dbias_accumulate);
+    hipLaunchKernelGGL(spatial_attn_bwd_weight_final, dim3(nw + 1), dim3(256), 0, s, workspace, nblk, nw, dw_accumulate, dbias_accumulate,
+                       dw_chw);
     return launch_status("somi_spatial_attn_bwd_f32");
 }
 

@@ -513,6 +513,217 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_pooled(const float *dz, 
         *reinterpret_cast<f32x4 *>(dx + (long)p * dx_cs) =
             one(has_dz ? *reinterpret_cast<const f32x4 *>(dz + (long)p * dz_cs) : f32x4{0.f, 0.f, 0.f, 0.f}, *reinterpret_cast<const f32x4 *>(x + (long)p * x_cs), p);
 }
+// ---- CBAM bottleneck: step C of train_blocks.hip (the gradient through x*ca*sa and the spatial branch) INSIDE the first conv's BatchNorm + SiLU
+// backward.  Round 4's sequence was C (read d(t*ca*sa), t; write dt) -> pooled stage 1 (read dt, y) -> pooled apply (read dt, y; write dy): 8 tensor
+// passes.  dt is a per-element function of d, t and a few per-pixel / per-(image, channel) scalars, and t = silu(scale*y + shift) is a function of
+// the y the BatchNorm backward reads anyway - so both BatchNorm kernels take d and y and rebuild dt in registers: 5 passes, no dt tensor, no read of t.
+// The pooled gradients (davg, dmax) of the channel attention depend on dca = sum_p dt1*t, which only this reduction produces; the batch sums are
+// therefore left SEPARABLE per (image chunk, channel): P = sum dt*f, Q = sum f, F = f at the arg-max pixel (f = silu'(u)), each also times (y - mean),
+// and the finalize adds  P + davg/HW * Q + dmax * F  per row once the attention MLP's backward has run.
+struct CbamBnArgs {
+    const float *d;  int d_cs, d_coff;          // gradient w.r.t. t*ca*sa (cv2's input gradient)
+    const float *y;  int y_cs, y_coff;          // cv1's convolution output (before BatchNorm)
+    const float *scale, *shift, *mean;          // BatchNorm as an affine map + the batch mean
+    const float *ca, *sa, *dstats;              // (B,C), (B,HW), (B,HW,2)
+    const int *amaxc, *amaxp;                   // (B,HW) arg-max channel of ca*t per pixel; (B,C) first pixel of t's spatial maximum
+    int HW, C;
+};
+struct CbamDt {                                 // what one element contributes
+    f32x4 dt, f, t, g1;
+};
+__device__ __forceinline__ CbamDt cbam_dt(const f32x4 g, const f32x4 v, const f32x4 sc, const f32x4 sh, const f32x4 cav, float sav, float2 ds, int am,
+                                          int c, float inv_c) {
+    CbamDt r;
+    const f32x4 u = v * sc + sh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float den = 1.0f + expf(-u[e]), s = 1.0f / den;
+        r.t[e] = u[e] / den;                                             // silu(u), as the forward pass wrote it
+        r.f[e] = s * (1.f + u[e] * (1.f - s));                           // silu'(u)
+    }
+    r.g1 = g * sav + ds.x * inv_c;                                       // through *sa, plus the channel-mean branch of the spatial attention
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c + e == am) r.g1[e] += ds.y;                                // ... and its channel-max branch
+    r.dt = r.g1 * cav;                                                   // through *ca
+    return r;
+}
+// grid (nimg, B): image-aligned chunks like bn_act_bwd_stage1_pooled; part = 7 planes of rows x C: dca | P1 | P2 | Q1 | Q2 | F1 | F2
+__global__ __launch_bounds__(256) void cbam_bn_bwd_reduce_kernel(CbamBnArgs a, float *__restrict__ part, int chunk) {
+    __shared__ f32x4 lr[256];
+    const int b = blockIdx.y, C = a.C, HW = a.HW, C4 = C >> 2;
+    const int q0 = blockIdx.x * chunk, q1 = min(q0 + chunk, HW);
+    const long row = (long)b * gridDim.x + blockIdx.x, plane = (long)gridDim.x * gridDim.y * C;
+    const float inv_c = 1.f / (float)C;
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int ncq = min(256, C4 - cq0);
+        const int rows_par = 256 / ncq;
+        const int cq = threadIdx.x % ncq, rr = threadIdx.x / ncq;
+        const int c = (cq0 + cq) * 4;
+        f32x4 acc[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rr < rows_par) {
+            const f32x4 cav = *reinterpret_cast<const f32x4 *>(a.ca + (long)b * C + c), mu = *reinterpret_cast<const f32x4 *>(a.mean + c),
+                        sc = *reinterpret_cast<const f32x4 *>(a.scale + c), sh = *reinterpret_cast<const f32x4 *>(a.shift + c);
+            auto one = [&](int pl, const f32x4 g, const f32x4 v, float sav, float2 ds, int am) {
+                const CbamDt r = cbam_dt(g, v, sc, sh, cav, sav, ds, am, c, inv_c);
+                const f32x4 xc = v - mu, df = r.dt * r.f;
+                acc[0] += r.g1 * r.t;
+                acc[1] += df;
+                acc[2] += df * xc;
+                acc[3] += r.f;
+                acc[4] += r.f * xc;
+            };
+            int pl = q0 + rr;
+            for (; pl + 3 * rows_par < q1; pl += 4 * rows_par) {         // four pixels' loads go out together; sums in pixel order
+                f32x4 g[4], v[4];
+                float2 ds[4];
+                int am[4];
+                float sav[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long p = (long)b * HW + pl + u * rows_par;
+                    g[u] = *reinterpret_cast<const f32x4 *>(a.d + p * a.d_cs + a.d_coff + c);
+                    v[u] = *reinterpret_cast<const f32x4 *>(a.y + p * a.y_cs + a.y_coff + c);
+                    ds[u] = *reinterpret_cast<const float2 *>(a.dstats + p * 2);
+                    am[u] = a.amaxc[p];
+                    sav[u] = a.sa[p];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) one(pl + u * rows_par, g[u], v[u], sav[u], ds[u], am[u]);
+            }
+            for (; pl < q1; pl += rows_par) {
+                const long p = (long)b * HW + pl;
+                one(pl, *reinterpret_cast<const f32x4 *>(a.d + p * a.d_cs + a.d_coff + c), *reinterpret_cast<const f32x4 *>(a.y + p * a.y_cs + a.y_coff + c),
+                    a.sa[p], *reinterpret_cast<const float2 *>(a.dstats + p * 2), a.amaxc[p]);
+            }
+            if (rr == 0) {                                               // F: silu'(u) and silu'(u) (y - mean) at the arg-max pixel, by the chunk that holds it
+                const i32x4_ amp = *reinterpret_cast<const i32x4_ *>(a.amaxp + (long)b * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (amp[e] >= q0 && amp[e] < q1) {
+                        const float v = a.y[((long)b * HW + amp[e]) * a.y_cs + a.y_coff + c + e], u = v * sc[e] + sh[e];
+                        const float sg = 1.0f / (1.0f + expf(-u)), f = sg * (1.f + u * (1.f - sg));
+                        acc[5][e] = f;
+                        acc[6][e] = f * (v - mu[e]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            lr[threadIdx.x] = acc[j];
+            __syncthreads();
+            if (threadIdx.x < ncq) {
+                f32x4 t = acc[j];
+                for (int r2 = 1; r2 < rows_par; ++r2) t += lr[r2 * ncq + cq];
+                *reinterpret_cast<f32x4 *>(part + j * plane + row * C + c) = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+// finalize: rows of image b get that image's pooled terms, then as bn_act_bwd_stage2 (batch statistics)
+__global__ __launch_bounds__(256) void cbam_bn_bwd_stage2(const float *__restrict__ part, int rows, int nimg, int C, int HW, const float *__restrict__ davg,
+                                                          const float *__restrict__ dmax, const float *__restrict__ rstd,
+                                                          const float *__restrict__ scale, float *__restrict__ coefA, float *__restrict__ coefB,
+                                                          float *__restrict__ coefC, float *dgamma, float *dbeta) {
+    __shared__ double l1[256], l2[256];
+    const int cl = threadIdx.x % S2_CH, grp = threadIdx.x / S2_CH;
+    const int c = blockIdx.x * S2_CH + cl;
+    const long plane = (long)rows * C;
+    const float inv_hw = 1.f / (float)HW;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        for (int k = grp; k < rows; k += 4 * S2_GRP) {
+            float v[4][6], ka[4], km[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = k + j * S2_GRP;
+                const bool ok = r < rows;
+                const int b = ok ? r / nimg : 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) v[j][q] = ok ? part[(q + 1) * plane + (long)r * C + c] : 0.f;
+                ka[j] = ok ? davg[(long)b * C + c] * inv_hw : 0.f;
+                km[j] = ok ? dmax[(long)b * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a1 += (double)(v[j][0] + ka[j] * v[j][2] + km[j] * v[j][4]);
+                a2 += (double)(v[j][1] + ka[j] * v[j][3] + km[j] * v[j][5]);
+            }
+        }
+    }
+    l1[threadIdx.x] = a1;
+    l2[threadIdx.x] = a2;
+    __syncthreads();
+    if (grp != 0 || c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < S2_GRP; ++g) { s1 += l1[g * S2_CH + cl]; s2 += l2[g * S2_CH + cl]; }
+    const double rs = rstd[c], sc = scale[c], n = (double)rows / nimg * HW;
+    const double D = rs * s2;
+    coefA[c] = (float)sc;
+    coefB[c] = (float)(-sc * rs * D / n);
+    coefC[c] = (float)(-sc * s1 / n);
+    if (dgamma) dgamma[c] += (float)D;
+    if (dbeta) dbeta[c] += (float)s1;
+}
+// grid (gx, B) as bn_act_bwd_apply_pooled: dy = A * (dt + davg/HW + [p == amaxp] dmax) * silu'(u) + Bc * (y - mean) + Cc, dt rebuilt from d
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void cbam_bn_bwd_apply_kernel(CbamBnArgs a, const float *__restrict__ coefA, const float *__restrict__ coefB,
+                                                                const float *__restrict__ coefC, const float *__restrict__ davg,
+                                                                const float *__restrict__ dmax, float *dx, int dx_cs, int dx_coff) {
+    const int C = a.C, HW = a.HW;
+    const unsigned C4 = (unsigned)C >> 2, nthreads = gridDim.x * 256u, t = blockIdx.x * 256u + threadIdx.x;
+    const int c = (int)(t % C4) * 4, b = blockIdx.y, pstep = (int)(nthreads / C4);
+    const f32x4 A = *reinterpret_cast<const f32x4 *>(coefA + c), Bc = *reinterpret_cast<const f32x4 *>(coefB + c),
+                Cc = *reinterpret_cast<const f32x4 *>(coefC + c), M = *reinterpret_cast<const f32x4 *>(a.mean + c),
+                sc = *reinterpret_cast<const f32x4 *>(a.scale + c), sh = *reinterpret_cast<const f32x4 *>(a.shift + c),
+                cav = *reinterpret_cast<const f32x4 *>(a.ca + (long)b * C + c);
+    const f32x4 kavg = *reinterpret_cast<const f32x4 *>(davg + (long)b * C + c) * (1.f / (float)HW);
+    const f32x4 kmax = *reinterpret_cast<const f32x4 *>(dmax + (long)b * C + c);
+    const i32x4_ amp = *reinterpret_cast<const i32x4_ *>(a.amaxp + (long)b * C + c);
+    const float inv_c = 1.f / (float)C;
+    const float *d = a.d + (long)b * HW * a.d_cs + a.d_coff + c, *y = a.y + (long)b * HW * a.y_cs + a.y_coff + c;
+    const float *sa = a.sa + (long)b * HW, *dst = a.dstats + (long)b * HW * 2;
+    const int *amc = a.amaxc + (long)b * HW;
+    dx += (long)b * HW * dx_cs + dx_coff + c;
+    auto one = [&](int pl, const f32x4 g, const f32x4 v, float sav, float2 ds, int am) {
+        const CbamDt r = cbam_dt(g, v, sc, sh, cav, sav, ds, am, c, inv_c);
+        f32x4 dz = r.dt + kavg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (amp[e] == pl) dz[e] += kmax[e];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = A[e] * (dz[e] * r.f[e]) + Bc[e] * (v[e] - M[e]) + Cc[e];
+        return o;
+    };
+    int p = (int)(t / C4);
+    for (; p + (EW_U - 1) * pstep < HW; p += EW_U * pstep) {
+        f32x4 g[EW_U], v[EW_U];
+        float2 ds[EW_U];
+        int am[EW_U];
+        float sav[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            const int q = p + u * pstep;
+            g[u] = *reinterpret_cast<const f32x4 *>(d + (long)q * a.d_cs);
+            v[u] = *reinterpret_cast<const f32x4 *>(y + (long)q * a.y_cs);
+            ds[u] = *reinterpret_cast<const float2 *>(dst + (long)q * 2);
+            am[u] = amc[q];
+            sav[u] = sa[q];
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) *reinterpret_cast<f32x4 *>(dx + (long)(p + u * pstep) * dx_cs) = one(p + u * pstep, g[u], v[u], sav[u], ds[u], am[u]);
+    }
+    for (; p < HW; p += pstep)
+        *reinterpret_cast<f32x4 *>(dx + (long)p * dx_cs) = one(p, *reinterpret_cast<const f32x4 *>(d + (long)p * a.d_cs), *reinterpret_cast<const f32x4 *>(y + (long)p * a.y_cs),
+                                                                sa[p], *reinterpret_cast<const float2 *>(dst + (long)p * 2), amc[p]);
+}
+// defined in train_blocks.hip: out[b,c] = sum over the nchunk partial rows of image b (fp64, fixed order)
+__global__ __launch_bounds__(256) void img_partial_sum_kernel(const float *__restrict__ part, int nchunk, int C, int B, float *__restrict__ out);
+
 // pixels of one image per stage-1 workgroup of the pooled form: the batch's partial rows stay at <= 1024 like red_chunk's
 static inline int red_chunk_img(int B, int HW) {
     const int per = B >= 1024 ? 1 : 1024 / B;
@@ -729,6 +940,55 @@ extern "C" int somi_bn_act_backward_pooled_nhwc_f32(const float *dz, int dz_cs, 
         hipLaunchKernelGGL(bn_act_bwd_apply_pooled<false>, dim3(ew_grid_img(B, HW, C, WG_APPLY_RT), B), dim3(256), 0, s, dz, dz_cs, dz_coff, x, x_cs,
                            x_coff, scale, shift, mean, cA, cB, cC, act, order, dx, dx_cs, dx_coff, HW, C, davg, dmax, amaxp);
     return launch_status("somi_bn_act_backward_pooled_nhwc_f32");
+}
+
+static bool cbam_bn_args(CbamBnArgs &a, const float *d, int d_cs, int d_coff, const float *y, int y_cs, int y_coff, const float *scale, const float *shift,
+                         const float *mean, const float *ca, const float *sa, const float *dstats, const int32_t *amaxc, const int32_t *amaxp, int B, int HW,
+                         int C) {
+    if (!(slice_ok(d, d_cs, d_coff, C) && slice_ok(y, y_cs, y_coff, C) && scale && shift && mean && ca && sa && dstats && amaxc && amaxp && B > 0 &&
+          B <= 65535 && HW > 0 && (long)B * HW < (1L << 31) && C % 4 == 0 && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(ca) &&
+          aligned16(amaxp) && ((uintptr_t)dstats & 7) == 0))
+        return false;
+    a = CbamBnArgs{d, d_cs, d_coff, y, y_cs, y_coff, scale, shift, mean, ca, sa, dstats, amaxc, amaxp, HW, C};
+    return true;
+}
+
+extern "C" size_t somi_cbam_bn_bwd_workspace_floats(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return 0;
+    return (size_t)7 * somi_bn_pooled_rows(B, HW) * C + 3 * (((size_t)C + 3) / 4 * 4);
+}
+
+extern "C" int somi_cbam_bn_bwd_reduce_f32(const float *d, int d_cs, int d_coff, const float *y, int y_cs, int y_coff, const float *scale,
+                                           const float *shift, const float *mean, const float *ca, const float *sa, const float *dstats,
+                                           const int32_t *amaxc, const int32_t *amaxp, float *dca, float *workspace, int B, int HW, int C,
+                                           somi_stream_t stream) {
+    CbamBnArgs a;
+    SOMI_REQUIRE(cbam_bn_args(a, d, d_cs, d_coff, y, y_cs, y_coff, scale, shift, mean, ca, sa, dstats, amaxc, amaxp, B, HW, C) && dca && workspace,
+                 SOMI_EINVAL, "cbam bn bwd reduce: bad arguments");
+    const int chunk = red_chunk_img(B, HW), nimg = (HW + chunk - 1) / chunk;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbam_bn_bwd_reduce_kernel, dim3(nimg, B), dim3(256), 0, s, a, workspace, chunk);
+    hipLaunchKernelGGL(img_partial_sum_kernel, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, workspace, nimg, C, B, dca);
+    return launch_status("somi_cbam_bn_bwd_reduce_f32");
+}
+
+extern "C" int somi_cbam_bn_bwd_apply_f32(const float *d, int d_cs, int d_coff, const float *y, int y_cs, int y_coff, const float *scale,
+                                          const float *shift, const float *mean, const float *rstd, const float *ca, const float *sa,
+                                          const float *dstats, const int32_t *amaxc, const int32_t *amaxp, const float *davg, const float *dmax,
+                                          float *dx, int dx_cs, int dx_coff, float *dgamma, float *dbeta, float *workspace, int B, int HW, int C,
+                                          somi_stream_t stream) {
+    CbamBnArgs a;
+    SOMI_REQUIRE(cbam_bn_args(a, d, d_cs, d_coff, y, y_cs, y_coff, scale, shift, mean, ca, sa, dstats, amaxc, amaxp, B, HW, C) && rstd && davg && dmax &&
+                     aligned16(davg) && aligned16(dmax) && slice_ok(dx, dx_cs, dx_coff, C) && workspace,
+                 SOMI_EINVAL, "cbam bn bwd apply: bad arguments");
+    const int chunk = red_chunk_img(B, HW), nimg = (HW + chunk - 1) / chunk, rows = B * nimg;
+    const size_t cpad = ((size_t)C + 3) / 4 * 4;
+    float *cA = workspace + (size_t)7 * rows * C, *cB = cA + cpad, *cC = cB + cpad;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbam_bn_bwd_stage2, dim3(cdiv(C, S2_CH)), dim3(256), 0, s, workspace, rows, nimg, C, HW, davg, dmax, rstd, scale, cA, cB, cC, dgamma,
+                       dbeta);
+    hipLaunchKernelGGL(cbam_bn_bwd_apply_kernel, dim3(ew_grid_img(B, HW, C, WG_APPLY_RT), B), dim3(256), 0, s, a, cA, cB, cC, davg, dmax, dx, dx_cs, dx_coff);
+    return launch_status("somi_cbam_bn_bwd_apply_f32");
 }
 
 extern "C" int somi_bn_local_sums_f64(const float *x, int x_cs, int x_coff, long npix, int C, const float *pivot, const float *part_sum,

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SOMI_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libsomi_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 13         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
+ABI_VERSION = 14         # SOMI_ABI_VERSION of include/somi_hip.h this binding was written against
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_stream = C.c_void_p
 
@@ -119,7 +119,10 @@ SIGNATURES = {
     'somi_img_nchunk': (I, [I]),
     'somi_cbam_bwd_pixel_f32': (I, [P, I, I, P, I, I, P, P, P, P, I, I, I, S]),
     'somi_cbam_bwd_pixel_argmax_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, I, I, I, S]),
-    'somi_spatial_attn_bwd_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, S]),
+    'somi_cbam_bn_bwd_workspace_floats': (C.c_size_t, [I, I, I]),
+    'somi_cbam_bn_bwd_reduce_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, P, P, P, P, I, I, I, S]),
+    'somi_cbam_bn_bwd_apply_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, I, I, I, S]),
+    'somi_spatial_attn_bwd_f32': (I, [P, P, P, P, P, P, P, I, I, I, I, I, S]),
     'somi_cbam_bwd_chan_f32': (I, [P, I, I, P, I, I, P, P, P, P, P, P, I, I, I, S]),
     'somi_pool_argmax_nhwc_f32': (I, [P, I, I, I, I, I, P, P, S]),
     'somi_attn_mlp_bwd_workspace_floats': (Z, [I, I, I]),
@@ -173,6 +176,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                f'(or `make -C yolo-somi_amd/csrc`). There is no CPU fallback.')
+        # torch first: its wheel carries its own libamdhip64.so (SONAME libamdhip64.so.7) and asks for it by the name "libamdhip64.so".  Loaded
+        # before torch, this library would pull /opt/rocm's copy under its SONAME, torch's request would not match that name and a SECOND HIP
+        # runtime would come up in the process - whose launches then fail with "no ROCm-capable device is detected".  With torch's copy mapped
+        # first, the SONAME this library asks for resolves to it and there is one runtime.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         lax = bool(os.environ.get('SOMI_HIP_LIB')) and os.environ.get('SOMI_HIP_LIB_LAX') == '1'   # kernel A/B runs against an older build
         for name, (res, args) in SIGNATURES.items():

@@ -232,12 +232,14 @@ class Conv(_Packed):
         self.__dict__['_ctx'] = (x, y, mean, rstd, scale, shift, pk)
         return Act(out.t, out.coff, c2)
 
-    def backward(self, dz, dx_out=None, accumulate=False, need_dx=True, also_add=None, pooled=None):
+    def backward(self, dz, dx_out=None, accumulate=False, need_dx=True, also_add=None, pooled=None, cbam=None):
         """dz: gradient w.r.t. this block's output (Act).  Returns the gradient w.r.t. the input as an Act (written into
         dx_out if given, added to it if accumulate; `also_add` is a further Act added in the same pass - a shortcut's
         gradient).  Parameter gradients are accumulated into .grad (reference layout).
         pooled: (davg, dmax, amaxp) of a channel attention that pooled this block's output (ops.bn_act_backward): its gradient joins dz inside
-        the BatchNorm backward kernels."""
+        the BatchNorm backward kernels.
+        cbam: state of ops.cbam_backward(bn=...) - dz is then the gradient w.r.t. t*ca*sa of the CBAM bottleneck this conv opens, and the attention's
+        step C runs inside the BatchNorm backward kernels too (pooled = the MLP backward's (davg, dmax, amaxp) on that call's dca)."""
         x, y, mean, rstd, scale, shift, pk = self.__dict__.pop('_ctx')
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         c1, c2, cp = self.conv.in_channels, self.conv.out_channels, pad4(self.conv.out_channels)
@@ -248,7 +250,15 @@ class Conv(_Packed):
             raise NotImplementedError('training backward on a channel slice needs out_channels % 4 == 0')
         gw, gb = self.bn.weight.grad, self.bn.bias.grad
         direct = cp == c2 and gw is not None and gb is not None and gw.is_contiguous() and gb.is_contiguous() and gw.device == dev
-        if direct:                                                # the kernel accumulates straight into the gradient buffers
+        if cbam is not None:                                      # CBAM's step C + pooled gradients + BatchNorm backward in two passes over (dz, y)
+            if cw != cp or cp != c2:
+                raise NotImplementedError('fused CBAM backward works on whole, unpadded tensors')
+            dgam, dbet = (gw, gb) if direct else (torch.zeros(cp, device=dev), torch.zeros(cp, device=dev))
+            ops.cbam_bn_backward_apply(cbam, rstd, pooled[0], pooled[1], dy, dgam, dbet)
+            if not direct:
+                _acc_grad(self.bn.weight, dgam)
+                _acc_grad(self.bn.bias, dbet)
+        elif direct:                                              # the kernel accumulates straight into the gradient buffers
             ops.bn_act_backward(dz.t, dz.coff, y, 0, cw, mean, rstd, scale, shift, _act_name(self.act), 0, True, dy, 0, gw, gb, pooled=pooled)
         else:
             dgam, dbet = torch.zeros(cp, device=dev), torch.zeros(cp, device=dev)
@@ -409,17 +419,21 @@ class SpatialAttentionModule(_Packed):
         self.__dict__['_ctx'] = (x, ca, stats, sa, w)
         return Act(out, 0, x.c)
 
-    def backward(self, dt2, t_max=None):
+    def backward(self, dt2, t_max=None, bn=None):
         """dt2: gradient tensor w.r.t. x*ca*sa (whole tensor, modified in place into the x-gradient through both products and
         the spatial branch).  Returns dca (B,C) and - with t_max (B,C), the spatial maximum of x the channel attention pooled - amaxp (B,C): the
-        first pixel holding each channel's maximum (for the max-pool's gradient), else None."""
+        first pixel holding each channel's maximum (for the max-pool's gradient), else None.
+        bn = (y, scale, shift, mean) of the Conv that produced x: dt2 is left as it is and a third value - the state for that Conv's
+        backward(cbam=...) - is returned (ops.cbam_backward)."""
         x, ca, stats, sa, w = self.__dict__.pop('_ctx')
         k = self.cv1.kernel_size[0]
-        dw, db = torch.zeros_like(w), torch.zeros(1, device=w.device)
-        dca, amaxp = ops.cbam_backward(dt2, x.t, x.coff, x.c, ca, sa, stats, w, k, dw, db, t_max=t_max)
-        _acc_grad(self.cv1.weight, dw.permute(2, 0, 1).unsqueeze(0))          # [k][k][2] -> (1,2,k,k)
-        _acc_grad(self.cv1.bias, db)
-        return dca, amaxp
+        (dw, sw), (db, sb) = _grad_target(self.cv1.weight), _grad_target(self.cv1.bias)    # the kernel accumulates in nn.Conv2d's (1,2,k,k) layout
+        res = ops.cbam_backward(dt2, x.t, x.coff, x.c, ca, sa, stats, w, k, dw, db, t_max=t_max, dw_chw=True, bn=bn)
+        if sw:
+            _acc_grad(self.cv1.weight, dw)
+        if sb:
+            _acc_grad(self.cv1.bias, db)
+        return res
 
 
 class CBAMBottleneck(nn.Module):
@@ -451,11 +465,18 @@ class CBAMBottleneck(nn.Module):
         x, t = self.__dict__.pop('_ctx')
         d = self.cv2.backward(dout)                               # d(t*ca*sa)
         # d.t then holds the direct part of dt; the channel attention's pooled maximum lets the same pass find its arg-max pixels
-        dca, amaxp = self.spatial_attention.backward(d.t, t_max=self.channel_attention.__dict__['_ctx'][2] if ops.AMAX_BY_VALUE else None)
+        t_max = self.channel_attention.__dict__['_ctx'][2] if ops.AMAX_BY_VALUE else None
+        c_ = self.cv1.conv.out_channels
+        bn = None
+        if (ops.CBAM_FUSED_BN and ops.BN_POOLED and ops.SYNC_BN is None and t_max is not None and isinstance(self.cv1.act, nn.SiLU) and pad4(c_) == c_
+                and d.coff == 0 and d.t.shape[3] == c_ and t.coff == 0):
+            _, y1, mean1, _, scale1, shift1, _ = self.cv1.__dict__['_ctx']      # step C + the pooled terms + BatchNorm backward: two passes over (d, y1)
+            bn = (y1, scale1, shift1, mean1)
+        dca, amaxp, *state = self.spatial_attention.backward(d.t, t_max=t_max, bn=bn)
         pooled = self.channel_attention.backward(dca, d, amaxp, defer=True)   # the pooled paths join d inside cv1's BatchNorm backward
         c1 = self.cv1.conv.in_channels
         fuse = self.add and pad4(c1) == c1 and dout.coff % 4 == 0  # the shortcut's gradient rides the dgrad epilogue
-        self.cv1.backward(d, dx_out=dx_out, accumulate=True, also_add=dout if fuse else None, pooled=pooled)
+        self.cv1.backward(d, dx_out=dx_out, accumulate=True, also_add=dout if fuse else None, pooled=pooled, cbam=state[0] if state else None)
         if self.add and not fuse:
             ops.add_(dx_out.t, dx_out.coff, dout.t, dout.coff, x.c)
         return dx_out

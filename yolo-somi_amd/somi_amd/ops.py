@@ -26,6 +26,7 @@ CONV_PREC = 0
 PREC = {None: 0, 'f32': 0, 'bf16': 1, 'bf16x3': 2}
 FUSE_POOL = os.environ.get('SOMI_FUSE_POOL', '1') != '0'      # 0: the channel attention pools its input in a pass of its own (round-3 form; A/B runs)
 AMAX_BY_VALUE = os.environ.get('SOMI_AMAX_BY_VALUE', '1') != '0'   # 0: the max-pool's arg-max from somi_pool_argmax_nhwc_f32's own pass over the tensor
+CBAM_FUSED_BN = os.environ.get('SOMI_CBAM_FUSED_BN', '1') != '0'   # 0: CBAM's step C as a pass of its own before the BatchNorm backward (A/B runs)
 BN_POOLED = os.environ.get('SOMI_BN_POOLED', '1') != '0'    # 0: CBAM's pooled gradients are added by a pass of their own (round-3 form; A/B runs)
 
 
@@ -757,11 +758,13 @@ def add_(a, a_coff, b, b_coff, c, out=None, out_coff=None):
     return out
 
 
-def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7, t_max=None):
+def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7, t_max=None, dw_chw=False, bn=None):
     """Steps A-C of train_blocks.hip: turns d(t*ca*sa) (dt2, whole tensor, modified in place) into the part of dt that flows
     through the two multiplications and the spatial branch; returns dca (B,C) and, when t_max (B,C) - the spatial maximum of t the forward pooled -
     is given, amaxp (B,C) int32: the first pixel that holds each channel's maximum (step D, found by value inside step A's pass), else None.
-    dw7 / db7 are accumulated."""
+    dw7 / db7 are accumulated; dw7 is [k][k][2] like w7, or (dw_chw) laid out (2,k,k) like nn.Conv2d's weight.
+    bn = (y, scale, shift, mean) of the Conv -> BatchNorm -> SiLU that produced t (needs t_max): step C is NOT run as a pass of its own - dt2 is left
+    alone, dca comes from the reduction half of the fused BatchNorm backward, and a third value is returned: the state cbam_bn_backward_apply needs."""
     B, H, W, _ = t.shape
     dev = t.device
     L = _lib.lib()
@@ -776,14 +779,32 @@ def cbam_backward(dt2, t, t_coff, c, ca, sa, stats, w7, k, dw7, db7, t_max=None)
         check(L.somi_cbam_bwd_pixel_f32(_ptr(_f32c(dt2)), dt2.shape[3], 0, _ptr(_f32c(t)), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dlogit),
                                         _ptr(amaxc), B, H * W, c, _stream()), 'cbam_bwd_pixel')
     dstats = torch.empty(B, H, W, 2, device=dev, dtype=torch.float32)
-    ws = torch.empty(((B * H * W + 1023) // 1024) * (2 * k * k + 1), device=dev, dtype=torch.float32)
+    ws = torch.empty(((B * H * W + 511) // 512) * (2 * k * k + 1), device=dev, dtype=torch.float32)
     check(L.somi_spatial_attn_bwd_f32(_ptr(dlogit), _ptr(stats), _ptr(w7), _ptr(dstats), _ptr(dw7), _ptr(db7), _ptr(ws), B, H, W, k,
-                                      _stream()), 'spatial_attn_bwd')
+                                      int(dw_chw), _stream()), 'spatial_attn_bwd')
     dca = torch.empty(B, c, device=dev, dtype=torch.float32)
+    if bn is not None:
+        y, scale, shift, mean = bn
+        ws3 = torch.empty(L.somi_cbam_bn_bwd_workspace_floats(B, H * W, c), device=dev, dtype=torch.float32)
+        head = (_ptr(_f32c(dt2)), dt2.shape[3], 0, _ptr(_f32c(y)), y.shape[3], 0, _ptr(scale), _ptr(shift), _ptr(mean))
+        check(L.somi_cbam_bn_bwd_reduce_f32(*head, _ptr(ca), _ptr(sa), _ptr(dstats), _ptr(amaxc), _ptr(amaxp), _ptr(dca), _ptr(ws3), B, H * W, c,
+                                            _stream()), 'cbam_bn_bwd_reduce')
+        return dca, amaxp, (dt2, y, scale, shift, mean, ca, sa, dstats, amaxc, amaxp, ws3, c)
     ws2 = torch.empty(B * L.somi_img_nchunk(H * W) * c, device=dev, dtype=torch.float32)
     check(L.somi_cbam_bwd_chan_f32(_ptr(dt2), dt2.shape[3], 0, _ptr(t), t.shape[3], t_coff, _ptr(ca), _ptr(sa), _ptr(dstats), _ptr(amaxc),
                                    _ptr(dca), _ptr(ws2), B, H * W, c, _stream()), 'cbam_bwd_chan')
     return dca, amaxp
+
+
+def cbam_bn_backward_apply(state, rstd, davg, dmax, dx, dgamma, dbeta):
+    """Second half of the fused CBAM + BatchNorm backward (somi_cbam_bn_bwd_apply_f32): state from cbam_backward(bn=...), davg / dmax (B,C) from the
+    channel attention's MLP backward on the dca it returned; writes the gradient w.r.t. the convolution output into dx, accumulates dgamma / dbeta."""
+    d, y, scale, shift, mean, ca, sa, dstats, amaxc, amaxp, ws, c = state
+    B, H, W, _ = y.shape
+    check(_lib.lib().somi_cbam_bn_bwd_apply_f32(_ptr(d), d.shape[3], 0, _ptr(y), y.shape[3], 0, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(ca),
+                                                _ptr(sa), _ptr(dstats), _ptr(amaxc), _ptr(amaxp), _ptr(davg), _ptr(dmax), _ptr(_f32c(dx)), dx.shape[3], 0,
+                                                _ptr(dgamma), _ptr(dbeta), _ptr(ws), B, H * W, c, _stream()), 'cbam_bn_bwd_apply')
+    return dx
 
 
 def pool_argmax(x, c, x_coff=0):
