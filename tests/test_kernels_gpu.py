@@ -273,8 +273,9 @@ def test_spatial_attention_backward_against_conv2d_autograd(k, B, H, W):
         dw, db = dw0.to(d), db0.to(d)
         dstats = torch.empty(B, H, W, 2, device=d)
         ws = torch.empty(((B * H * W + 511) // 512) * (2 * k * k + 1), device=d)
-        check(L.somi_spatial_attn_bwd_f32(_ptr(dlogit.to(d)), _ptr(stats.to(d)), _ptr(w[0].permute(1, 2, 0).contiguous().to(d)), _ptr(dstats), _ptr(dw),
-                                          _ptr(db), _ptr(ws), B, H, W, k, chw, _stream()), 'spatial_attn_bwd')
+        dl_d, st_d, w_d = dlogit.to(d), stats.to(d), w[0].permute(1, 2, 0).contiguous().to(d)      # named: the pointers must outlive the call
+        check(L.somi_spatial_attn_bwd_f32(_ptr(dl_d), _ptr(st_d), _ptr(w_d), _ptr(dstats), _ptr(dw), _ptr(db), _ptr(ws), B, H, W, k, chw, _stream()),
+              'spatial_attn_bwd')
         want_dw = w64.grad[0] if chw else w64.grad[0].permute(1, 2, 0)
         rel_close(dstats, s64.grad.permute(0, 2, 3, 1), rel=1e-5, what=f'dstats k{k}')
         rel_close(dw.cpu().double() - dw0.double(), want_dw, rel=2e-5, what=f'dw k{k} chw{chw}')
