@@ -185,11 +185,11 @@ def test_c2fcbam_train_forward_backward(c1, c2, n, shortcut):
     _run_block_train(mine, ref, x, 21, 'C2fCBAM', c1)
 
 
-@pytest.mark.parametrize('c,n,B,H,W', [(64, 2, 3, 37, 29), (256, 1, 2, 20, 20), (16, 1, 5, 45, 31)])
+@pytest.mark.parametrize('c,n,B,H,W', [(64, 2, 3, 37, 29), (256, 1, 2, 20, 20), (32, 1, 5, 45, 31)])
 def test_cbam_step_c_inside_the_batchnorm_backward_equals_the_three_pass_form(c, n, B, H, W, monkeypatch):
     """somi_cbam_bn_bwd_reduce_f32 / _apply_f32 (step C of the CBAM backward rebuilt in registers inside the first conv's BatchNorm + SiLU backward)
     against the form it replaces (somi_cbam_bwd_chan_f32 writing dt, then the pooled BatchNorm backward): same block, same tensors, every parameter
-    gradient and the input gradient.  Ragged maps (chunks that end inside an image, arg-max pixels in the last chunk), hidden widths 32 / 128 / 8;
+    gradient and the input gradient.  Ragged maps (chunks that end inside an image, arg-max pixels in the last chunk), hidden widths 32 / 128 / 16;
     both forms are separately held to the oracle by test_c2fcbam_train_forward_backward."""
     from somi_amd import blocks as MB, ops
     g = torch.Generator().manual_seed(c + H)
