@@ -31,6 +31,7 @@ constexpr int NOFF = 5;
 constexpr int SLOT = 3;
 constexpr float NWD_EPS = 1e-7f, FOCAL_ALPHA = 0.25f;
 
+constexpr int LOSS_FOLD = 64;   // slot segments per level: one workgroup each, so that the finish kernel does not walk ~34000 slots per level alone
 struct LossArgs {
     somi_loss_desc d;
     int no;
@@ -45,6 +46,7 @@ struct LossArgs {
     int *head;              // [sum cells] last entry pushed onto the cell's list, -1 = none (only with gradients)
     int *next;              // [nl][na*nt*NOFF] list links
     float *partial;         // [sum nblk] obj-BCE partial sums
+    double *fold;           // [nl][LOSS_FOLD][2] box / cls sums of a level's slot segments (finish adds them in segment order)
 };
 
 // ---- forward-mode dual numbers over the 4 decoded box coordinates (px, py, pw, ph)
@@ -351,39 +353,59 @@ __global__ __launch_bounds__(256) void loss_dense_kernel(const LossArgs a, int l
 }
 
 // ------------------------------------------------------------------------------------------------ 4. finish
+// grid (LOSS_FOLD, nl): box / cls sums of one segment of a level's slots - thread-strided partial sums in double, then a tree over the 256 lanes
+// (fixed order).  Round 4: the finish kernel did this walk alone, one workgroup for every level: 227 us per step.
+__global__ __launch_bounds__(256) void loss_slots_fold_kernel(const LossArgs a) {
+    __shared__ double red[2][256];
+    const somi_loss_desc &d = a.d;
+    const int l = blockIdx.y, per_level = d.na * d.nt * NOFF;
+    const int per = (per_level + LOSS_FOLD - 1) / LOSS_FOLD, i0 = blockIdx.x * per, i1 = min(i0 + per, per_level);
+    const float *sl = a.slots + (size_t)l * per_level * SLOT;
+    double sb = 0.0, sc = 0.0;
+    for (int i = i0 + threadIdx.x; i < i1; i += 4 * 256) {
+        float vb[4], vc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = i + u * 256;
+            vb[u] = j < i1 ? sl[(size_t)j * SLOT] : -1.f;
+            vc[u] = j < i1 ? sl[(size_t)j * SLOT + 1] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (vb[u] >= 0.f) { sb += vb[u]; sc += vc[u]; }
+    }
+    red[0][threadIdx.x] = sb;
+    red[1][threadIdx.x] = sc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.fold[((size_t)l * LOSS_FOLD + blockIdx.x) * 2] = red[0][0];
+        a.fold[((size_t)l * LOSS_FOLD + blockIdx.x) * 2 + 1] = red[1][0];
+    }
+}
 __global__ __launch_bounds__(256) void loss_finish_kernel(const LossArgs a, float *out4) {
     __shared__ double red[256];
     const somi_loss_desc &d = a.d;
     double lbox = 0.0, lobj = 0.0, lcls = 0.0;
-    const int per_level = d.na * d.nt * NOFF;
     for (int l = 0; l < d.nl; ++l) {
-        // fixed-order reductions: thread-strided partial sums, then a tree over the 256 lanes
-        double sb = 0.0, sc = 0.0, so = 0.0;
-        const float *sl = a.slots + (size_t)l * per_level * SLOT;
-        for (int i = threadIdx.x; i < per_level; i += 4 * 256) {      // four slots requested per trip (one workgroup walks ~34000 of them per level)
-            float vb[4], vc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = i + u * 256;
-                vb[u] = j < per_level ? sl[(size_t)j * SLOT] : -1.f;
-                vc[u] = j < per_level ? sl[(size_t)j * SLOT + 1] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (vb[u] >= 0.f) { sb += vb[u]; sc += vc[u]; }
-        }
+        double so = 0.0;
         for (int i = threadIdx.x; i < a.nblk[l]; i += 256) so += a.partial[a.blk_off[l] + i];
-        double vals[3] = {sb, sc, so};
-        for (int q = 0; q < 3; ++q) {
-            red[threadIdx.x] = vals[q];
-            __syncthreads();
-            for (int s = 128; s > 0; s >>= 1) {
-                if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-                __syncthreads();
-            }
-            vals[q] = red[0];
+        red[threadIdx.x] = so;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
             __syncthreads();
         }
+        double vals[3] = {0.0, 0.0, red[0]};
+        __syncthreads();
+        if (d.nt > 0)
+            for (int g = 0; g < LOSS_FOLD; ++g) {                         // the segments in order; every thread computes the same sums
+                vals[0] += a.fold[((size_t)l * LOSS_FOLD + g) * 2];
+                vals[1] += a.fold[((size_t)l * LOSS_FOLD + g) * 2 + 1];
+            }
         const int n = a.nent[l];
         if (n) {
             lbox += vals[0] / n;
@@ -437,7 +459,7 @@ extern "C" size_t somi_loss_workspace_bytes(const somi_loss_desc *d) {
     const size_t slots = align_up((size_t)d->nl * d->na * (d->nt > 0 ? d->nt : 1) * NOFF * SLOT * 4, 256);
     const size_t part = align_up((size_t)(a.blk_off[d->nl - 1] + a.nblk[d->nl - 1]) * 4, 256);
     const size_t next = align_up((size_t)d->nl * d->na * (d->nt > 0 ? d->nt : 1) * NOFF * 4, 256);
-    return tobj + 256 + slots + part + tobj + next;      // + the per-cell list heads and the entry links of the gradient pass
+    return tobj + 256 + slots + part + tobj + next + 4 * LOSS_FOLD * 2 * sizeof(double);      // + the per-cell list heads, the entry links of the gradient pass, the slot-segment sums
 }
 
 extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *workspace, size_t workspace_bytes,
@@ -458,7 +480,8 @@ extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *w
     a.slots = reinterpret_cast<float *>(w); w += align_up((size_t)d.nl * d.na * (d.nt > 0 ? d.nt : 1) * NOFF * SLOT * 4, 256);
     a.partial = reinterpret_cast<float *>(w); w += align_up((size_t)(a.blk_off[d.nl - 1] + a.nblk[d.nl - 1]) * 4, 256);
     a.head = reinterpret_cast<int *>(w); w += tobj_b;
-    a.next = reinterpret_cast<int *>(w);
+    a.next = reinterpret_cast<int *>(w); w += align_up((size_t)d.nl * d.na * (d.nt > 0 ? d.nt : 1) * NOFF * 4, 256);
+    a.fold = reinterpret_cast<double *>(w);
     bool any_grad = false;
     for (int l = 0; l < d.nl; ++l) any_grad = any_grad || d.grad[l];
     (void)hipMemsetAsync(a.tobj, 0, tobj_b + 256, s);                       // target maps + entry counters
@@ -475,6 +498,7 @@ extern "C" int somi_yolo_loss_f32(const somi_loss_desc *dp, float *out4, void *w
         hipLaunchKernelGGL(loss_level_mean_kernel, dim3(d.nl), dim3(256), 0, s, a);     // no entries anywhere: every level gets the default
     }
     for (int l = 0; l < d.nl; ++l) hipLaunchKernelGGL(loss_dense_kernel, dim3(a.nblk[l]), dim3(256), 0, s, a, l);
+    if (d.nt > 0) hipLaunchKernelGGL(loss_slots_fold_kernel, dim3(LOSS_FOLD, d.nl), dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, a, out4);
     return launch_status("somi_yolo_loss_f32");
 }
