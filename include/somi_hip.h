@@ -124,11 +124,6 @@ size_t somi_conv2d_wgrad_workspace_bytes(const somi_conv_desc *fwd);
 int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float *x, int x_cs, int x_coff, const float *dy, int dy_cs,
                                int dy_coff, float *dw, const float *accumulate, void *workspace, size_t workspace_bytes,
                                somi_stream_t stream);
-/* The same with the split reduce on a second stream (ordered behind the GEMM by an event; nothing is synchronised with the host): `stream` is
- * free for the data gradient at once.  The caller keeps `workspace` alive until `reduce_stream` has run, and makes whoever reads dw wait for it. */
-int somi_conv2d_wgrad_nhwc_2s_f32(const somi_conv_desc *fwd, const float *x, int x_cs, int x_coff, const float *dy, int dy_cs,
-                                  int dy_coff, float *dw, const float *accumulate, void *workspace, size_t workspace_bytes,
-                                  somi_stream_t stream, somi_stream_t reduce_stream);
 
 /* Name of the kernel instantiation somi_conv2d_nhwc_f32 would launch for this descriptor (for profiling: matches the
  * kernel name rocprofv3 reports), or NULL for an invalid descriptor. */

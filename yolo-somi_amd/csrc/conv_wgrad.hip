@@ -396,14 +396,6 @@ extern "C" size_t somi_conv2d_wgrad_workspace_bytes(const somi_conv_desc *fwd) {
 extern "C" int somi_conv2d_wgrad_nhwc_f32(const somi_conv_desc *fwd, const float *x, int x_cs, int x_coff, const float *dy, int dy_cs,
                                           int dy_coff, float *dw, const float *accumulate, void *workspace, size_t workspace_bytes,
                                           somi_stream_t stream) {
-    return somi_conv2d_wgrad_nhwc_2s_f32(fwd, x, x_cs, x_coff, dy, dy_cs, dy_coff, dw, accumulate, workspace, workspace_bytes, stream, stream);
-}
-
-// The split reduce is off the critical path of a backward pass (dw is read by the optimizer only): with reduce_stream != stream it is enqueued
-// there behind an event recorded after the GEMM, and `stream` goes on to the data gradient without the ~14 us launch in between.
-extern "C" int somi_conv2d_wgrad_nhwc_2s_f32(const somi_conv_desc *fwd, const float *x, int x_cs, int x_coff, const float *dy, int dy_cs,
-                                             int dy_coff, float *dw, const float *accumulate, void *workspace, size_t workspace_bytes,
-                                             somi_stream_t stream, somi_stream_t reduce_stream) {
     SOMI_REQUIRE(fwd && x && dy && dw && workspace, SOMI_EINVAL, "conv wgrad: null argument");
     WgradArgs a{};
     int rc = plan(*fwd, a);
@@ -422,10 +414,8 @@ extern "C" int somi_conv2d_wgrad_nhwc_2s_f32(const somi_conv_desc *fwd, const fl
         for (int b0 = 0; b0 < a.B; b0 += bsub) {
             somi_conv_desc sub = *fwd;
             sub.B = a.B - b0 < bsub ? a.B - b0 : bsub;
-            // one stream for the slices: they share the workspace, and the last slice's reduce must not start before the others' (an event per slice
-            // would do; the case does not occur in a training step)
-            rc = somi_conv2d_wgrad_nhwc_2s_f32(&sub, x + (size_t)b0 * a.H * a.W * x_cs, x_cs, x_coff, dy + (size_t)b0 * a.Ho * a.Wo * dy_cs, dy_cs,
-                                               dy_coff, dw, b0 == 0 ? accumulate : dw, workspace, workspace_bytes, stream, stream);
+            rc = somi_conv2d_wgrad_nhwc_f32(&sub, x + (size_t)b0 * a.H * a.W * x_cs, x_cs, x_coff, dy + (size_t)b0 * a.Ho * a.Wo * dy_cs, dy_cs,
+                                            dy_coff, dw, b0 == 0 ? accumulate : dw, workspace, workspace_bytes, stream);
             if (rc) return rc;
         }
         return 0;
@@ -453,20 +443,8 @@ extern "C" int somi_conv2d_wgrad_nhwc_2s_f32(const somi_conv_desc *fwd, const fl
     if (!direct) {
         const long n = (long)sets * a.Cout * a.K;
         long g = (n / 4 + 15) / 16;
-        hipStream_t rs = static_cast<hipStream_t>(reduce_stream);
-        if (rs != s) {
-            // one event per host thread is enough: a wait captures the record that precedes it, a later record does not move it
-            static thread_local hipEvent_t ev = nullptr;
-            hipError_t e = ev ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(ev, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(rs, ev, 0);
-            if (e != hipSuccess) {
-                set_error("conv wgrad: could not order the reduce stream behind the GEMM: %s", hipGetErrorString(e));
-                return (int)e;
-            }
-        }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, rs,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, s,
                            static_cast<const float *>(workspace), a.splits, n, accumulate, dw);
     }
-    return launch_status("somi_conv2d_wgrad_nhwc_2s_f32");
+    return launch_status("somi_conv2d_wgrad_nhwc_f32");
 }

@@ -67,7 +67,6 @@ SIGNATURES = {
     'somi_conv2d_dgrad_nhwc_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, P, I, I, P, I, I, S]),
     'somi_conv2d_wgrad_workspace_bytes': (Z, [C.POINTER(ConvDesc)]),
     'somi_conv2d_wgrad_nhwc_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, I, I, P, P, P, Z, S]),
-    'somi_conv2d_wgrad_nhwc_2s_f32': (I, [C.POINTER(ConvDesc), P, I, I, P, I, I, P, P, P, Z, S, S]),
     'somi_conv2d_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'somi_dcnv3_forward_f32': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
     'somi_dcnv3_backward_workspace_bytes': (Z, [I] * 13 + [F]),

@@ -268,7 +268,7 @@ class Conv(_Packed):
         B, H, W, _ = x.shape
         if pk['gp'] is not None:                                  # accumulate into the packed gradient master
             ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp, out=pk['gp'],
-                                  accumulate=pk['gp'], side_ok=True)
+                                  accumulate=pk['gp'])
         else:
             dw = ops.conv2d_wgrad_nhwc(x.t, dy, kh=k, kw=k, stride=s, pad=p, cin=pad4(c1), x_coff=x.coff, cout=cp)
             _acc_grad(self.conv.weight, dw.view(cp, k, k, pad4(c1))[:c2, :, :, :c1].permute(0, 3, 1, 2))

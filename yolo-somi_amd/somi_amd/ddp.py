@@ -55,9 +55,6 @@ class GradBuckets:
         if self.dist is None or (self.dist.get_world_size() == 1 and not SINGLE_RANK_REHEARSAL):
             return
         view = self.flat[bi][start:end]
-        if torch.cuda.is_available():
-            from . import ops
-            ops.join_side()                                       # the span's weight gradients may still be in their side-stream reduce
         if self.use_streams:
             ev = torch.cuda.Event()
             ev.record()                                           # gradients of this bucket are final on the compute stream

@@ -267,7 +267,6 @@ class Model(nn.Module):
                     give(srcs[0], m.backward(g))
             if hook:
                 hook(m.i)
-        ops.join_side()                                          # weight-gradient reduces still on the side stream: whoever reads .grad next sees them
 
     def _forward_once(self, x, ingested=None):
         """models/yolo.py:1269-1290: walk the layers with the skip list.  ingested: an already converted (B,H,W,4) image (TTA variants)."""

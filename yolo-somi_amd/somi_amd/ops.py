@@ -26,7 +26,6 @@ CONV_PREC = 0
 PREC = {None: 0, 'f32': 0, 'bf16': 1, 'bf16x3': 2}
 FUSE_POOL = os.environ.get('SOMI_FUSE_POOL', '1') != '0'      # 0: the channel attention pools its input in a pass of its own (round-3 form; A/B runs)
 AMAX_BY_VALUE = os.environ.get('SOMI_AMAX_BY_VALUE', '1') != '0'   # 0: the max-pool's arg-max from somi_pool_argmax_nhwc_f32's own pass over the tensor
-SIDE_REDUCE = os.environ.get('SOMI_SIDE_REDUCE', '1') != '0'   # 0: the weight gradients' split reduce stays on the compute stream (A/B runs)
 CBAM_FUSED_BN = os.environ.get('SOMI_CBAM_FUSED_BN', '1') != '0'   # 0: CBAM's step C as a pass of its own before the BatchNorm backward (A/B runs)
 BN_POOLED = os.environ.get('SOMI_BN_POOLED', '1') != '0'    # 0: CBAM's pooled gradients are added by a pass of their own (round-3 form; A/B runs)
 
@@ -581,31 +580,9 @@ def conv2d_dgrad_nhwc(dy, w_dgrad, *, B, H, W, cin, kh, kw, stride=1, pad=0, cou
     return out
 
 
-_SIDE = {}          # device index -> (side stream, [pending]): work that only parameter gradients depend on
-def side_stream(dev):
-    """The per-device stream for launches that nothing on the critical path of a backward pass waits for (the split reduce of a weight gradient
-    into the optimizer's flat buffer).  Whoever reads such a gradient calls join_side() first: Model._backward_walk at its end, the DDP buckets
-    before they hand a span to the all-reduce."""
-    i = dev.index if dev.index is not None else torch.cuda.current_device()
-    ent = _SIDE.get(i)
-    if ent is None:
-        ent = _SIDE[i] = [torch.cuda.Stream(device=i), False]
-    return ent
-
-
-def join_side():
-    """The current stream of every device with pending side-stream work waits for it (a stream-side wait: the host does not block)."""
-    for i, ent in _SIDE.items():
-        if ent[1]:
-            torch.cuda.current_stream(i).wait_stream(ent[0])
-            ent[1] = False
-
-
 def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cout=None, dy_coff=0, out=None, accumulate=None,
-                      per_sample_w=False, side_ok=False):
-    """dW [Cout][kh*kw*Cin] (forward packing) of the conv x (B,H,W,cin) -> y (B,Ho,Wo,cout) from x and dy.
-    side_ok: `out` is a persistent buffer nobody reads before join_side() (the optimizer's packed gradient master): the split reduce then runs on
-    the side stream and the compute stream goes straight on to the data gradient."""
+                      per_sample_w=False):
+    """dW [Cout][kh*kw*Cin] (forward packing) of the conv x (B,H,W,cin) -> y (B,Ho,Wo,cout) from x and dy."""
     B, H, W, x_cs = x.shape
     _, Ho, Wo, dy_cs = dy.shape
     cin = x_cs - x_coff if cin is None else cin
@@ -624,15 +601,8 @@ def conv2d_wgrad_nhwc(x, dy, *, kh, kw, stride=1, pad=0, cin=None, x_coff=0, cou
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if side_ok and SIDE_REDUCE:
-        ent = side_stream(x.device)
-        check(L.somi_conv2d_wgrad_nhwc_2s_f32(C.byref(d), _ptr(_f32c(x)), x_cs, x_coff, _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(out)),
-                                              _ptr(accumulate), _ptr(ws), nbytes, _stream(), ent[0].cuda_stream), 'conv2d_wgrad_nhwc')
-        ws.record_stream(ent[0])                                  # the partials are read there: the allocator must not hand the block out before
-        ent[1] = True
-    else:
-        check(L.somi_conv2d_wgrad_nhwc_f32(C.byref(d), _ptr(_f32c(x)), x_cs, x_coff, _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(out)),
-                                           _ptr(accumulate), _ptr(ws), nbytes, _stream()), 'conv2d_wgrad_nhwc')
+    check(L.somi_conv2d_wgrad_nhwc_f32(C.byref(d), _ptr(_f32c(x)), x_cs, x_coff, _ptr(_f32c(dy)), dy_cs, dy_coff, _ptr(_f32c(out)),
+                                       _ptr(accumulate), _ptr(ws), nbytes, _stream()), 'conv2d_wgrad_nhwc')
     if prof:
         e1.record()
         bm = 64 if -(-cout // 64) * 64 < -(-cout // 128) * 128 else 128            # conv_wgrad.hip plan()
