@@ -208,6 +208,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)       # >= 20 timed iterations after >= 10 warm-ups
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--settle-max', type=int, default=30, help='un-timed steps before the warm-up until the step time is steady (0: none)')
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 32: BASELINE configs[1]; 2 for yolov5s)')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--nc', type=int, default=None, help='classes (default 10, yolov5s 80; 3 = UAVDT, BASELINE configs[3])')
@@ -324,6 +325,25 @@ def main():
     from somi_amd.dist import timed_steps, whole_job_rate
     if args.mode == 'infer':
         ops.CONV_PREC = ops.PREC[args.amp]                          # (training: TrainStep sets it around its forward + backward)
+    # settle phase, before the W warm-up steps and disclosed in the line (`settle`): un-timed steps until the step time has stopped moving (the mean of
+    # the last three within 2 % of the three before; 6 ... --settle-max steps).  One of round 4's default runs on a fresh box measured 402 ms per step
+    # where every later run on the same box measured 329: whatever ramps up on a fresh box (clocks, the host's caches) is not what a training run of
+    # thousands of steps sees.  With several ranks the decision is taken on the MAX over ranks, so every rank runs the same number of steps.
+    settle = None
+    if args.settle_max > 0:
+        hist = []
+        while len(hist) < args.settle_max:
+            torch.cuda.synchronize()
+            t0 = time.time()
+            step()
+            torch.cuda.synchronize()
+            ms = torch.tensor([(time.time() - t0) * 1e3], device=dev)
+            if world > 1:
+                dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+            hist.append(ms.item())
+            if len(hist) >= 6 and abs(sum(hist[-3:]) - sum(hist[-6:-3])) <= 0.02 * sum(hist[-6:-3]):
+                break
+        settle = {'steps': len(hist), 'first_ms': round(hist[0], 1), 'last_ms': round(hist[-1], 1)}
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -415,6 +435,7 @@ def main():
                        else f'images/sec infer ({"2 models x (forward+NMS) + WBF" if ensemble else "forward+NMS"}) @{args.size}, {shaped}, {label}'),
             'value': round(whole_job_rate(args.batch, args.steps, world, dt), 2), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'settle': settle,                                           # un-timed steps before the W warm-up steps until the step time stood still
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {None: 'f32', 'bf16': 'bf16 (conv products; fp32 accumulate, tensors, BN, loss, optimizer)',
                       'bf16x3': 'bf16x3 (conv products as 3 bf16 MFMAs on hi/lo splits; fp32 everything else)'}[args.amp], 'data': 'synthetic',

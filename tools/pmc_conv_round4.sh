@@ -20,7 +20,7 @@ run iso160_b "$PB" python3 tools/conv_probe.py 32 160 128 128 3 1 12
 run iso80_a "$PA" python3 tools/conv_probe.py 32 80 256 256 3 1 12
 run iso80_b "$PB" python3 tools/conv_probe.py 32 80 256 256 3 1 12
 # in the step: the default training bench, 1 warm-up + 2 timed steps
-T="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer"
+T="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer --settle-max 0"
 run step_a "$PA" $T
 run step_b "$PB" $T
 python3 tools/pmc_conv_summary.py $out > $out/summary.txt
