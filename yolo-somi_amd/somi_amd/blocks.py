@@ -21,10 +21,13 @@ from .pack import pack_conv_weight, pack_dgrad_weight, pad4, bn_fold
 
 class Act:
     """A channel slice [coff, coff+c) of an NHWC tensor."""
-    __slots__ = ('t', 'coff', 'c', 'up')
+    __slots__ = ('t', 'coff', 'c', 'up', 'pooled')
 
     def __init__(self, t, coff=0, c=None, up=0):
         self.t, self.coff, self.c, self.up = t, coff, (t.shape[3] - coff if c is None else c), up
+        # a GRADIENT may carry a part that is constant over an image's pixels and not yet added to the tensor: (davg, dmax, amaxp) with the meaning of
+        # ops.bn_act_backward's `pooled` (value = t + davg / HW ...).  Whoever consumes it folds it in (Conv.backward) or adds it (settle_pooled)
+        self.pooled = None
 
     @property
     def shape(self):
@@ -32,6 +35,14 @@ class Act:
 
     def slice(self, coff, c):
         return Act(self.t, self.coff + coff, c)
+
+
+def settle_pooled(a):
+    """Adds a gradient's pending pooled part (Act.pooled) to its tensor."""
+    if a is not None and a.pooled is not None:
+        ops.pool_backward_add_(a.t, a.coff, a.c, *a.pooled)
+        a.pooled = None
+    return a
 
 
 def new_act(like, H, W, c):
@@ -677,7 +688,10 @@ class ODConv_3rd(_Packed):
         self.__dict__['_ctx'] = (x, gap, fcw, zpre, st, z, attn, heads, Wk, biask, wout, y, so)
         return Act(out, 0, cout)
 
-    def backward(self, dz, need_dx=True):
+    def backward(self, dz, need_dx=True, dx_out=None, accumulate=False, defer_pool=False):
+        """dx_out / accumulate: the data gradient is written (added) into that Act (a whole tensor) by the dgrad epilogue.  defer_pool: the squeeze's
+        gradient - constant over an image's pixels - is not added here by a pass of its own but handed on as the result's `pooled` part, for the
+        producing Conv's BatchNorm backward to fold in."""
         x, gap, fcw, zpre, st, z, attn, heads, Wk, biask, wout, y, so = self.__dict__.pop('_ctx')
         cv = self.conv
         dev = y.device
@@ -697,7 +711,10 @@ class ODConv_3rd(_Packed):
         dx = None
         if need_dx:
             wt = wout.view(B, cout, kk, cin).permute(0, 3, 2, 1).contiguous().view(B, cin, kk * cout)
-            dx = ops.conv2d_dgrad_nhwc(dy, wt, B=B, H=H, W=W, cin=cin, kh=k, kw=k, stride=s, pad=p, per_sample_w=True)
+            if dx_out is not None and (dx_out.coff != 0 or dx_out.t.shape[3] != cin):
+                raise NotImplementedError('ODConv backward writes whole input-gradient tensors')
+            dx = ops.conv2d_dgrad_nhwc(dy, wt, B=B, H=H, W=W, cin=cin, kh=k, kw=k, stride=s, pad=p, per_sample_w=True,
+                                       out=None if dx_out is None else dx_out.t, accumulate=dx_out.t if (dx_out is not None and accumulate) else None)
         # synthesis backward
         dWk = torch.zeros_like(Wk)
         dbk = torch.zeros_like(biask) if biask is not None else None
@@ -725,8 +742,9 @@ class ODConv_3rd(_Packed):
         _acc_grad(cv.fc.weight, gfc.view_as(cv.fc.weight))
         if not need_dx:
             return None
-        ops.pool_backward_add_(dx, 0, cin, dgap)
-        return Act(dx, 0, cin)
+        res = Act(dx, 0, cin)
+        res.pooled = (dgap, None, None)
+        return res if defer_pool else settle_pooled(res)
 
     def _pack(self, dev):
         cv = self.conv

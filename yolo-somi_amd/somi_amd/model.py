@@ -236,7 +236,8 @@ class Model(nn.Module):
             if src not in grads:
                 grads[src] = d
             else:
-                g = grads[src]                                    # whole padded tensors add their pads too; slices add exactly c
+                g = B.settle_pooled(grads[src])                   # whole padded tensors add their pads too; slices add exactly c
+                B.settle_pooled(d)
                 whole = all(a.coff == 0 and a.t.shape[3] == B.pad4(a.c) for a in (g, d))
                 ops.add_(g.t, g.coff, d.t, d.coff, g.t.shape[3] if whole else g.c)
         det = self.model[-1]
@@ -250,21 +251,33 @@ class Model(nn.Module):
             if g is None:
                 raise RuntimeError(f'layer {m.i} ({m.type}) received no gradient')
             srcs = self._sources(m)
+            pend = None
+            if g.pooled is not None:                              # a part constant over each image's pixels, not added yet (ODConv's squeeze gradient)
+                if isinstance(m, B.Conv) and not isinstance(g, list):
+                    pend, g.pooled = g.pooled, None               # this layer's BatchNorm backward folds it in
+                else:
+                    B.settle_pooled(g)
             if isinstance(m, (B.BiFPN, B.Concat)):
                 for src, d in zip(srcs, m.backward(g)):
                     give(src, d)
             elif srcs[0] < 0:
-                m.backward(g, need_dx=False)
+                m.backward(g, need_dx=False, **({'pooled': pend} if pend is not None else {}))
             elif isinstance(m, B.DCNv3_YOLO):
                 give(srcs[0], m.backward(g))
             else:
                 have = grads.get(srcs[0])
-                if (have is not None and isinstance(m, (B.Conv, B.C2fCBAM, B.C3, B.SPPF, B.SPP)) and have.coff == 0 and
-                        have.t.shape[3] == B.pad4(have.c) and have.t.is_contiguous()):
+                kw = {'pooled': pend} if pend is not None else {}
+                if (have is not None and isinstance(m, (B.Conv, B.C2fCBAM, B.C3, B.SPPF, B.SPP, B.ODConv_3rd)) and have.coff == 0 and
+                        have.t.shape[3] == B.pad4(have.c) and have.t.is_contiguous() and have.pooled is None and
+                        (not isinstance(m, B.ODConv_3rd) or (ops.ODCONV_INPLACE and have.t.shape[3] == have.c))):
                     # the input already holds another consumer's gradient: the data-gradient epilogue adds to it in place
-                    m.backward(g, dx_out=have, accumulate=True)
+                    m.backward(g, dx_out=have, accumulate=True, **kw)
+                elif (have is None and isinstance(m, B.ODConv_3rd) and type(self.model[srcs[0]]) is B.Conv and ops.BN_POOLED and
+                      ops.SYNC_BN is None and ops.ODCONV_INPLACE):
+                    # the only consumer of a plain Conv's output (later layers have all been walked): its squeeze gradient rides that Conv's BatchNorm backward
+                    give(srcs[0], m.backward(g, defer_pool=True))
                 else:
-                    give(srcs[0], m.backward(g))
+                    give(srcs[0], m.backward(g, **kw))
             if hook:
                 hook(m.i)
 
