@@ -438,8 +438,10 @@ int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff, const floa
 
 /* Backward of the remaining layer kernels (train_blocks.hip).
  * detect: d raw (B,na,ny,nx,no) -> d box (B,ny,nx,box_cs), d cls (B,ny,nx,cls_cs) (inverse of the interleave; pads zeroed).
- * sppf:   dbuf slices 1..3 (the 5/9/13 pools) are routed to the arg-max positions and ADDED into slice 0 of dbuf (gather form,
- *         fixed summation order).
+ * sppf:   dbuf slices 1..3 (the gradients of the three chained 5x5 pools y1 = m(x), y2 = m(y1), y3 = m(y2)) are routed back through the chain - each
+ *         pool's gradient to the arg-max of its 5x5 window of the previous slice, first maximum in row-major order - and ADDED into slice 0 of dbuf
+ *         (gather form, fixed summation order).  Slices 1 and 2 of dbuf hold the chain's intermediate gradients afterwards.  SPP's parallel 5 / 9 / 13
+ *         pools (models/common.py:1806-1826) give the same values and the same routing except at exact ties inside a window.
  * bifpn:  dsrc_i = wn_i*dout (2x2 sum for an upsampled source, dsrc_i low-res); dw ACCUMULATED incl. the normalisation's chain
  *         rule.  workspace: 3*2048 floats.
  * dwconv: dx (+dx_accumulate), dw [3][3][C] and dbias ACCUMULATED.  workspace: ceil(B*H*W/512)*10*C floats.

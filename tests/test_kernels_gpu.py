@@ -212,6 +212,31 @@ def test_dwconv_sppf_bifpn():
     rel_close(got, nhwc(want), rel=1e-6, what='bifpn')
 
 
+@pytest.mark.parametrize('ties', [False, True])
+@pytest.mark.parametrize('B,C,H,W', [(2, 32, 11, 9), (1, 8, 20, 20), (3, 16, 4, 3)])
+def test_sppf_backward_follows_the_chain_of_pools(ties, B, C, H, W):
+    """somi_sppf_pool_bwd_nhwc_f32 against autograd through THREE CHAINED nn.MaxPool2d(5, 1, 2) (models/common.py:1846-1861): the gradient of each
+    pooled slice goes back through the chain to the first maximum (row-major) of each 5x5 window.  ties = True quantises the input to four values, so
+    almost every window has several maxima and the routing IS the tie rule (rounds 1-3 routed through 5 / 9 / 13 windows of slice 0: equal without
+    ties only).  Maps smaller than a window included."""
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    if ties:
+        x = torch.round(x.clamp(-1.5, 1.5))
+    xr = x.clone().double().requires_grad_(True)
+    y1 = F.max_pool2d(xr, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    dcat = torch.randn(B, 4 * C, H, W, generator=g)
+    torch.cat([xr, y1, y2, y3], 1).backward(dcat.double())
+    buf = nhwc(torch.cat([x, y1.detach().float(), y2.detach().float(), y3.detach().float()], 1)).to(d)
+    dbuf = nhwc(dcat).to(d)
+    ops.sppf_pool_backward_(buf, dbuf, C, 0)
+    rel_close(dbuf[..., :C], nhwc(xr.grad), rel=2e-6, what=f'sppf dx ties={ties}')
+
+
 def test_attention_pieces():
     from somi_amd import ops
     d = dev()

@@ -673,80 +673,73 @@ __global__ __launch_bounds__(256) void detect_raw_bwd_kernel(const float *__rest
     }
 }
 
-// ---- SPPF / SPP: the gradients of the three pooled slices (5 / 9 / 13 windows of slice 0) go to the arg-max pixel of their window.
-// Gather form, no atomics (run-to-run bit-identical): pass 1 records, per (pixel, channel, window), WHERE the maximum sits as one
-// byte (dh+6)*13 + (dw+6), first maximum in row-major order like torch's max_pool2d; pass 2 lets every slice-0 element collect, in
-// a fixed order, the gradients of the window outputs that point at it.
+// ---- SPPF / SPP: the three pooled slices are CHAINED 5x5 max-pools (models/common.py:1846-1861: y1 = m(x), y2 = m(y1), y3 = m(y2)), and autograd
+// routes each pool's gradient to the arg-max element of its 5x5 window of the PREVIOUS slice.  Gather form, no atomics (run-to-run bit-identical):
+// pass 1 records, per (element, level), where in its 5x5 window the maximum of the previous slice sits - one byte r*5 + q, first maximum in row-major
+// order like torch's max_pool2d; then level 3, 2, 1 in turn: every element of slice l-1 adds, in a fixed order, the (already complete) gradients of the
+// slice-l outputs around it whose byte points back at it.  (Rounds 1-3 treated the slices as 5 / 9 / 13 windows of slice 0 - the same values, and the
+// same routing except at exact ties - and paid 275 code checks per element in one 539 us launch, after a 276 us search over 169 taps; chained: 75 + 75.)
 __global__ __launch_bounds__(256) void sppf_pool_argmax_kernel(const float *__restrict__ buf, uint8_t *__restrict__ arg, int B, int H, int W, int C,
                                                                int cs, int x_coff) {
     const int C4 = C >> 2;                                             // 4 channels per lane: one 16-byte load per tap, one 4-byte code store
-    const long items = (long)B * H * W * C4;
-    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-        const int c = (int)(it % C4) * 4;
-        const long pix = it / C4;
-        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
-        const long b = pix / ((long)W * H);
-        const float ninf = -__builtin_huge_valf();
-        f32x4 m[3] = {{ninf, ninf, ninf, ninf}, {ninf, ninf, ninf, ninf}, {ninf, ninf, ninf, ninf}};
-        int mi[3][4];
-        for (int l = 0; l < 3; ++l)
-            for (int e = 0; e < 4; ++e) mi[l][e] = 84;                   // the centre; every window contains it
-        for (int dh = -6; dh <= 6; ++dh) {
-            const int hi = hv + dh;
-            if ((unsigned)hi >= (unsigned)H) continue;
-            const int ah = dh < 0 ? -dh : dh;
-            for (int dw = -6; dw <= 6; ++dw) {
-                const int wi = wv + dw;
-                if ((unsigned)wi >= (unsigned)W) continue;
-                const int aw = dw < 0 ? -dw : dw;
-                const int rad = ah > aw ? ah : aw;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + ((b * H + hi) * W + wi) * cs + x_coff + c);
-                const int code = (dh + 6) * 13 + (dw + 6);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (v[e] > m[2][e]) { m[2][e] = v[e]; mi[2][e] = code; }
-                    if (rad <= 4 && v[e] > m[1][e]) { m[1][e] = v[e]; mi[1][e] = code; }
-                    if (rad <= 2 && v[e] > m[0][e]) { m[0][e] = v[e]; mi[0][e] = code; }
-                }
-            }
-        }
-        for (int l = 0; l < 3; ++l)
-            *reinterpret_cast<uint32_t *>(arg + ((long)l * B * H * W + pix) * C + c) =
-                (uint32_t)mi[l][0] | ((uint32_t)mi[l][1] << 8) | ((uint32_t)mi[l][2] << 16) | ((uint32_t)mi[l][3] << 24);
-    }
-}
-
-__global__ __launch_bounds__(256) void sppf_pool_bwd_gather_kernel(const uint8_t *__restrict__ arg, float *__restrict__ dbuf, int B, int H, int W, int C,
-                                                                   int cs, int x_coff) {
-    const int C4 = C >> 2;
     const long items = (long)B * H * W * C4, plane = (long)B * H * W;
     for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
         const int c = (int)(it % C4) * 4;
         const long pix = it / C4;
         const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
         const long b = pix / ((long)W * H);
-        f32x4 acc = *reinterpret_cast<const f32x4 *>(dbuf + pix * cs + x_coff + c);
-        for (int l = 0; l < 3; ++l) {
-            const int R = 2 + 2 * l;
-            for (int dh = -R; dh <= R; ++dh) {                           // o = p + (dh, dw) points back at p when its code is (-dh, -dw)
-                const int ho = hv + dh;
-                if ((unsigned)ho >= (unsigned)H) continue;
-                for (int dw = -R; dw <= R; ++dw) {
-                    const int wo = wv + dw;
-                    if ((unsigned)wo >= (unsigned)W) continue;
-                    const long o = (b * H + ho) * W + wo;
-                    const uint32_t want = (uint32_t)((6 - dh) * 13 + (6 - dw));
-                    const uint32_t codes = *reinterpret_cast<const uint32_t *>(arg + ((long)l * plane + o) * C + c);
-                    const uint32_t x = codes ^ (want * 0x01010101u);    // a zero byte = that channel's maximum sits at p
-                    if (((x - 0x01010101u) & ~x & 0x80808080u) == 0) continue;
-                    const f32x4 d = *reinterpret_cast<const f32x4 *>(dbuf + o * cs + x_coff + (l + 1) * C + c);
+        const float ninf = -__builtin_huge_valf();
+        for (int l = 0; l < 3; ++l) {                                   // level l + 1 pools slice l
+            f32x4 m = {ninf, ninf, ninf, ninf};
+            int mi[4] = {12, 12, 12, 12};                               // the centre; every window contains it
+            for (int r = 0; r < 5; ++r) {
+                const int hi = hv + r - 2;
+                if ((unsigned)hi >= (unsigned)H) continue;
+                for (int q = 0; q < 5; ++q) {
+                    const int wi = wv + q - 2;
+                    if ((unsigned)wi >= (unsigned)W) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + ((b * H + hi) * W + wi) * cs + x_coff + l * C + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (((x >> (8 * e)) & 0xFFu) == 0) acc[e] += d[e];
+                        if (v[e] > m[e]) { m[e] = v[e]; mi[e] = r * 5 + q; }
                 }
             }
+            *reinterpret_cast<uint32_t *>(arg + ((long)l * plane + pix) * C + c) =
+                (uint32_t)mi[0] | ((uint32_t)mi[1] << 8) | ((uint32_t)mi[2] << 16) | ((uint32_t)mi[3] << 24);
         }
-        *reinterpret_cast<f32x4 *>(dbuf + pix * cs + x_coff + c) = acc;
+    }
+}
+
+// level l (2, 1, 0 in turn): slice l of dbuf += the gradients of slice l + 1 routed by the level's codes
+__global__ __launch_bounds__(256) void sppf_pool_bwd_gather_kernel(const uint8_t *__restrict__ arg, float *__restrict__ dbuf, int B, int H, int W, int C,
+                                                                   int cs, int x_coff, int l) {
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4, plane = (long)B * H * W;
+    const uint8_t *codes_l = arg + (long)l * plane * C;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        float *mine = dbuf + pix * cs + x_coff + l * C + c;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(mine);
+        for (int dh = -2; dh <= 2; ++dh) {                              // o = p + (dh, dw) points back at p when its code is (2 - dh, 2 - dw)
+            const int ho = hv + dh;
+            if ((unsigned)ho >= (unsigned)H) continue;
+            for (int dw = -2; dw <= 2; ++dw) {
+                const int wo = wv + dw;
+                if ((unsigned)wo >= (unsigned)W) continue;
+                const long o = (b * H + ho) * W + wo;
+                const uint32_t want = (uint32_t)((2 - dh) * 5 + (2 - dw));
+                const uint32_t x = *reinterpret_cast<const uint32_t *>(codes_l + o * C + c) ^ (want * 0x01010101u);   // a zero byte = that channel's maximum sits at p
+                if (((x - 0x01010101u) & ~x & 0x80808080u) == 0) continue;
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(dbuf + o * cs + x_coff + (l + 1) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((x >> (8 * e)) & 0xFFu) == 0) acc[e] += d[e];
+            }
+        }
+        *reinterpret_cast<f32x4 *>(mine) = acc;
     }
 }
 
@@ -962,7 +955,8 @@ extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, void *
     hipStream_t s = (hipStream_t)stream;
     uint8_t *arg = static_cast<uint8_t *>(workspace);                    // 3*B*H*W*C bytes
     hipLaunchKernelGGL(sppf_pool_argmax_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, buf, arg, B, H, W, C, cs, x_coff);
-    hipLaunchKernelGGL(sppf_pool_bwd_gather_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, arg, dbuf, B, H, W, C, cs, x_coff);
+    for (int l = 2; l >= 0; --l)                                         // slice 2 takes slice 3's gradients, then slice 1 takes slice 2's, then slice 0
+        hipLaunchKernelGGL(sppf_pool_bwd_gather_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, arg, dbuf, B, H, W, C, cs, x_coff, l);
     return launch_status("somi_sppf_pool_bwd_nhwc_f32");
 }
 
