@@ -240,6 +240,9 @@ int somi_dwconv3x3_nhwc_f32(const float *x, const float *w, const float *bias, c
  * max-pools (== 5x5, 9x9, 13x13 windows) to the slices at y_coff + {1,2,3}*C of the same tensor
  * (models/common.py:1856-1861).  In-place on one concat buffer: the pooled slices never alias the source slice. */
 int somi_sppf_pool_nhwc_f32(float *buf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream);
+/* The same for a training forward, level by level (three launches), leaving for every (element, level) the position r*5 + q of the first maximum
+ * (row-major) in its 5x5 window of the previous slice: `codes` = 3*B*H*W*C bytes, handed to somi_sppf_pool_bwd_nhwc_f32 as its workspace with buf = NULL. */
+int somi_sppf_pool_codes_nhwc_f32(float *buf, void *codes, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream);
 
 /* BiFPN fusion (models/common.py:3695-3704) with the preceding nn.Upsample(2,'nearest') folded in:
  * y = sum_i wn[i] * src_i, where source i is read at (h>>up[i], w>>up[i]).  wn = w / (sum swish(w) + eps) is computed
@@ -440,7 +443,8 @@ int somi_pool_bwd_add_nhwc_f32(float *dt_inout, int d_cs, int d_coff, const floa
  * detect: d raw (B,na,ny,nx,no) -> d box (B,ny,nx,box_cs), d cls (B,ny,nx,cls_cs) (inverse of the interleave; pads zeroed).
  * sppf:   dbuf slices 1..3 (the gradients of the three chained 5x5 pools y1 = m(x), y2 = m(y1), y3 = m(y2)) are routed back through the chain - each
  *         pool's gradient to the arg-max of its 5x5 window of the previous slice, first maximum in row-major order - and ADDED into slice 0 of dbuf
- *         (gather form, fixed summation order).  Slices 1 and 2 of dbuf hold the chain's intermediate gradients afterwards.  SPP's parallel 5 / 9 / 13
+ *         (gather form, fixed summation order).  Slices 1 and 2 of dbuf hold the chain's intermediate gradients afterwards.  workspace: 3*B*H*W*C bytes;
+ *         with buf = NULL it already holds the codes of somi_sppf_pool_codes_nhwc_f32 and no search runs.  SPP's parallel 5 / 9 / 13
  *         pools (models/common.py:1806-1826) give the same values and the same routing except at exact ties inside a window.
  * bifpn:  dsrc_i = wn_i*dout (2x2 sum for an upsampled source, dsrc_i low-res); dw ACCUMULATED incl. the normalisation's chain
  *         rule.  workspace: 3*2048 floats.

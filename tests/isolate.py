@@ -54,6 +54,7 @@ def hip_decisions(module):
             table[name] = t.flatten(1, 2).argmax(1).cpu()
         elif isinstance(mod, B.SPPF):                              # the concat buffer: slice 0 is what the three windows pool
             c_ = mod.cv1.conv.out_channels
+            ctx = ctx[0]                                           # (concat buffer, the kernel's per-level window codes)
             x1 = ctx.t[..., ctx.coff:ctx.coff + c_].permute(0, 3, 1, 2)
             Bn, C, H, W = x1.shape
             res = []

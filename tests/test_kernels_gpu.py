@@ -235,6 +235,15 @@ def test_sppf_backward_follows_the_chain_of_pools(ties, B, C, H, W):
     dbuf = nhwc(dcat).to(d)
     ops.sppf_pool_backward_(buf, dbuf, C, 0)
     rel_close(dbuf[..., :C], nhwc(xr.grad), rel=2e-6, what=f'sppf dx ties={ties}')
+    # the training path: the forward runs level by level and leaves the codes; the backward then searches nothing and does not read the buffer
+    buf2 = torch.zeros(B, H, W, 4 * C)
+    buf2[..., :C] = nhwc(x)
+    buf2 = buf2.to(d)
+    _, codes = ops.sppf_pool_(buf2, C, 0, codes=True)
+    assert torch.equal(buf2.cpu(), buf.cpu())
+    dbuf2 = nhwc(dcat).to(d)
+    ops.sppf_pool_backward_(None, dbuf2, C, 0, codes=codes)
+    assert torch.equal(dbuf2[..., :C].cpu(), dbuf[..., :C].cpu())
 
 
 def test_attention_pieces():

@@ -710,6 +710,38 @@ __global__ __launch_bounds__(256) void sppf_pool_argmax_kernel(const float *__re
     }
 }
 
+// training forward: ONE level of the chain - slice l + 1 = 5x5 max-pool of slice l - with the level's codes written beside it, so that the backward
+// pass needs no search of its own (three launches of 25 taps instead of a 169-tap pooling launch plus, in backward, a 75-tap search)
+__global__ __launch_bounds__(256) void sppf_pool5_codes_kernel(float *__restrict__ buf, uint8_t *__restrict__ arg, int B, int H, int W, int C, int cs,
+                                                               int x_coff, int l) {
+    const int C4 = C >> 2;
+    const long items = (long)B * H * W * C4, plane = (long)B * H * W;
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const long pix = it / C4;
+        const int wv = (int)(pix % W), hv = (int)((pix / W) % H);
+        const long b = pix / ((long)W * H);
+        const float ninf = -__builtin_huge_valf();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+        int mi[4] = {12, 12, 12, 12};
+        for (int r = 0; r < 5; ++r) {
+            const int hi = hv + r - 2;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < 5; ++q) {
+                const int wi = wv + q - 2;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + ((b * H + hi) * W + wi) * cs + x_coff + l * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > m[e]) { m[e] = v[e]; mi[e] = r * 5 + q; }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(buf + pix * cs + x_coff + (l + 1) * C + c) = m;
+        *reinterpret_cast<uint32_t *>(arg + ((long)l * plane + pix) * C + c) =
+            (uint32_t)mi[0] | ((uint32_t)mi[1] << 8) | ((uint32_t)mi[2] << 16) | ((uint32_t)mi[3] << 24);
+    }
+}
+
 // level l (2, 1, 0 in turn): slice l of dbuf += the gradients of slice l + 1 routed by the level's codes
 __global__ __launch_bounds__(256) void sppf_pool_bwd_gather_kernel(const uint8_t *__restrict__ arg, float *__restrict__ dbuf, int B, int H, int W, int C,
                                                                    int cs, int x_coff, int l) {
@@ -949,15 +981,26 @@ extern "C" int somi_detect_raw_bwd_f32(const float *draw, float *dbox, int box_c
 
 extern "C" int somi_sppf_pool_bwd_nhwc_f32(const float *buf, float *dbuf, void *workspace, int B, int H, int W, int C, int cs, int x_coff,
                                            somi_stream_t stream) {
-    SOMI_REQUIRE(buf && dbuf && workspace && B > 0 && H > 0 && W > 0 && C > 0 && x_coff + 4 * C <= cs, SOMI_EINVAL, "sppf bwd: bad arguments");
+    SOMI_REQUIRE(dbuf && workspace && B > 0 && H > 0 && W > 0 && C > 0 && x_coff + 4 * C <= cs, SOMI_EINVAL, "sppf bwd: bad arguments");
     SOMI_REQUIRE(C % 4 == 0 && cs % 4 == 0 && x_coff % 4 == 0 && aligned16(buf) && aligned16(dbuf) && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0,
                  SOMI_EINVAL, "sppf bwd: channels / strides must be multiples of 4, tensors 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     uint8_t *arg = static_cast<uint8_t *>(workspace);                    // 3*B*H*W*C bytes
-    hipLaunchKernelGGL(sppf_pool_argmax_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, buf, arg, B, H, W, C, cs, x_coff);
+    if (buf)                                                             // buf == NULL: the workspace holds the codes somi_sppf_pool_codes_nhwc_f32 left
+        hipLaunchKernelGGL(sppf_pool_argmax_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, buf, arg, B, H, W, C, cs, x_coff);
     for (int l = 2; l >= 0; --l)                                         // slice 2 takes slice 3's gradients, then slice 1 takes slice 2's, then slice 0
         hipLaunchKernelGGL(sppf_pool_bwd_gather_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, arg, dbuf, B, H, W, C, cs, x_coff, l);
     return launch_status("somi_sppf_pool_bwd_nhwc_f32");
+}
+
+extern "C" int somi_sppf_pool_codes_nhwc_f32(float *buf, void *codes, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream) {
+    SOMI_REQUIRE(buf && codes && B > 0 && H > 0 && W > 0 && C > 0 && x_coff + 4 * C <= cs, SOMI_EINVAL, "sppf (codes): bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && cs % 4 == 0 && x_coff % 4 == 0 && aligned16(buf) && (reinterpret_cast<uintptr_t>(codes) & 3u) == 0, SOMI_EINVAL,
+                 "sppf (codes): channels / strides must be multiples of 4, the tensor 16-byte aligned");
+    for (int l = 0; l < 3; ++l)
+        hipLaunchKernelGGL(sppf_pool5_codes_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, buf,
+                           static_cast<uint8_t *>(codes), B, H, W, C, cs, x_coff, l);
+    return launch_status("somi_sppf_pool_codes_nhwc_f32");
 }
 
 extern "C" int somi_bifpn_bwd_nhwc_f32(const float *const *src_host, float *const *dsrc_host, const int *up_host, const float *w_dev,

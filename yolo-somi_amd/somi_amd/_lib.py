@@ -136,6 +136,7 @@ SIGNATURES = {
     'somi_tta_resample_nhwc4_f32': (I, [P, P, I, I, I, I, I, I, I, I, F, I, S]),
     'somi_tta_descale_f32': (I, [P, C.c_long, I, F, I, F, S]),
     'somi_sppf_pool_bwd_nhwc_f32': (I, [P, P, P, I, I, I, I, I, I, S]),
+    'somi_sppf_pool_codes_nhwc_f32': (I, [P, P, I, I, I, I, I, I, S]),
     'somi_bifpn_bwd_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), P, F, I, P, P, P, I, I, I, I, S]),
     'somi_dwconv3x3_bwd_workspace_floats': (Z, [I, I, I]),
     'somi_dwconv3x3_bwd_nhwc_f32': (I, [P, P, P, P, P, P, P, P, I, I, I, I, S]),

@@ -540,16 +540,17 @@ class SPPF(nn.Module):
         B, H, W, _ = x.shape
         cat = concat_act(x.t, H, W, 4 * c_)
         self.cv1(x, out=cat.slice(0, c_))
-        ops.sppf_pool_(cat.t, c_, 0)
-        if self.training:
-            self.__dict__['_ctx'] = cat
+        if self.training:                                         # level by level, leaving each window's arg-max for the backward pass
+            self.__dict__['_ctx'] = (cat, ops.sppf_pool_(cat.t, c_, 0, codes=True)[1])
+        else:
+            ops.sppf_pool_(cat.t, c_, 0)
         return self.cv2(cat)
 
     def backward(self, dout, dx_out=None, accumulate=False):
-        cat = self.__dict__.pop('_ctx')
+        cat, codes = self.__dict__.pop('_ctx')
         c_ = self.cv1.conv.out_channels
         dcat = self.cv2.backward(dout)
-        ops.sppf_pool_backward_(cat.t, dcat.t, c_, 0)
+        ops.sppf_pool_backward_(cat.t, dcat.t, c_, 0, codes=codes)
         return self.cv1.backward(dcat.slice(0, c_), dx_out=dx_out, accumulate=accumulate)
 
 

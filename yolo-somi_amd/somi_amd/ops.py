@@ -314,8 +314,14 @@ def dwconv3x3(x, w, bias=None, post_scale=None, post_shift=None, residual=None, 
     return out
 
 
-def sppf_pool_(buf, c, x_coff=0):
+def sppf_pool_(buf, c, x_coff=0, codes=False):
+    """The three chained 5x5 pools of slice [x_coff, x_coff + c) into the next three slices of `buf`.  codes=True (training): level by level, and
+    -> (buf, codes): where each window's first maximum sits, for sppf_pool_backward_(codes=...)."""
     B, H, W, cs = buf.shape
+    if codes:
+        arg = torch.empty(3 * B * H * W * c, device=buf.device, dtype=torch.uint8)
+        check(_lib.lib().somi_sppf_pool_codes_nhwc_f32(_ptr(_f32c(buf)), _ptr(arg), B, H, W, c, cs, x_coff, _stream()), 'sppf_pool_codes')
+        return buf, arg
     check(_lib.lib().somi_sppf_pool_nhwc_f32(_ptr(_f32c(buf)), B, H, W, c, cs, x_coff, _stream()), 'sppf_pool')
     return buf
 
@@ -845,10 +851,12 @@ def detect_raw_backward(draw, box_cs, cls_cs, na, nc):
     return dbox, dcls
 
 
-def sppf_pool_backward_(buf, dbuf, c, x_coff=0):
-    B, H, W, cs = buf.shape
-    ws = torch.empty(3 * B * H * W * c, device=buf.device, dtype=torch.uint8)
-    check(_lib.lib().somi_sppf_pool_bwd_nhwc_f32(_ptr(_f32c(buf)), _ptr(_f32c(dbuf)), _ptr(ws), B, H, W, c, cs, x_coff, _stream()), 'sppf_pool_bwd')
+def sppf_pool_backward_(buf, dbuf, c, x_coff=0, codes=None):
+    """codes: what sppf_pool_(codes=True) returned (then `buf` is not read); else the windows are searched again."""
+    B, H, W, cs = dbuf.shape
+    ws = torch.empty(3 * B * H * W * c, device=dbuf.device, dtype=torch.uint8) if codes is None else codes
+    check(_lib.lib().somi_sppf_pool_bwd_nhwc_f32(_ptr(_f32c(buf)) if codes is None else None, _ptr(_f32c(dbuf)), _ptr(ws), B, H, W, c, cs, x_coff,
+                                                 _stream()), 'sppf_pool_bwd')
     return dbuf
 
 
