@@ -1,4 +1,4 @@
-# round 4, late: ODConv's input gradient added in place by the dgrad epilogue, its squeeze gradient folded into the producing Conv's BatchNorm backward.
+# round 4, late: ODConv - input gradient added in place by the dgrad epilogue, squeeze gradient folded into the producing BatchNorm backward, squeeze average taken by the producing BatchNorm + SiLU pass.
 mkdir -p gpurun_out/r4
 python -m pytest tests/test_train_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "whole_model or odconv or bit_reproducible or train_step_with_optimizer or full_width_well or accumulation" > gpurun_out/r4/t_ab7.log 2>&1 || { tail -n 30 gpurun_out/r4/t_ab7.log; exit 1; }
 tail -n 2 gpurun_out/r4/t_ab7.log

@@ -21,13 +21,14 @@ from .pack import pack_conv_weight, pack_dgrad_weight, pad4, bn_fold
 
 class Act:
     """A channel slice [coff, coff+c) of an NHWC tensor."""
-    __slots__ = ('t', 'coff', 'c', 'up', 'pooled')
+    __slots__ = ('t', 'coff', 'c', 'up', 'pooled', 'pool')
 
     def __init__(self, t, coff=0, c=None, up=0):
         self.t, self.coff, self.c, self.up = t, coff, (t.shape[3] - coff if c is None else c), up
         # a GRADIENT may carry a part that is constant over an image's pixels and not yet added to the tensor: (davg, dmax, amaxp) with the meaning of
         # ops.bn_act_backward's `pooled` (value = t + davg / HW ...).  Whoever consumes it folds it in (Conv.backward) or adds it (settle_pooled)
         self.pooled = None
+        self.pool = None          # an ACTIVATION may carry its global (average, max) per (image, channel) when the pass that wrote it took them (Conv(pool=))
 
     @property
     def shape(self):
@@ -505,7 +506,8 @@ class C2fCBAM(nn.Module):
             CBAMBottleneck(self.c, self.c, shortcut, g, k=(3, 3), e=1.0, ratio=16, kernel_size=kernel_size)
             for _ in range(n))
 
-    def forward(self, x):
+    def forward(self, x, pool=None):
+        """pool: a dict the closing conv's BatchNorm + SiLU pass fills with the output's global average / max (Conv._forward_train)."""
         c, n = self.c, len(self.m)
         if c % 4:
             raise NotImplementedError('C2fCBAM hidden width must be a multiple of 4 on the MI355X path')
@@ -514,7 +516,7 @@ class C2fCBAM(nn.Module):
         self.cv1(x, out=cat.slice(0, 2 * c))
         for i, blk in enumerate(self.m):
             blk(cat.slice((1 + i) * c, c), out=cat.slice((2 + i) * c, c))
-        return self.cv2(cat)
+        return self.cv2(cat, pool=pool)
 
     def backward(self, dout, dx_out=None, accumulate=False):
         c, n = self.c, len(self.m)
@@ -654,7 +656,7 @@ class ODConv_3rd(_Packed):
             raise NotImplementedError('ODConv training path needs whole tensors with channels % 4 == 0')
         hid = cv.fc.weight.shape[0]
         fcw = f(cv.fc.weight).flatten(1)
-        gap, _ = ops.global_pool(x.t, want_max=False)
+        gap = x.pool[0] if x.pool is not None else ops.global_pool(x.t, want_max=False)[0]    # the producer's BatchNorm + SiLU pass may have taken it
         zpre = ops.linear(gap, fcw, None, 'none')
         one, zero = torch.ones(hid, device=dev), torch.zeros(hid, device=dev)
         if B > 1:                                                 # BatchNorm over the B samples (models/common.py:4562-4563)

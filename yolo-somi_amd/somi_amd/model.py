@@ -295,7 +295,14 @@ class Model(nn.Module):
             for m in self.model:
                 if m.f != -1:
                     a = y[m.f] if isinstance(m.f, int) else [a if j == -1 else y[j] for j in m.f]
-                a = m(a)
+                nxt = self.model[m.i + 1] if m.i + 1 < len(self.model) else None
+                if (self.training and ops.FUSE_POOL and ops.ODCONV_INPLACE and type(m) in (B.Conv, B.C2fCBAM) and isinstance(nxt, B.ODConv_3rd) and nxt.f == -1):
+                    pool = {}                                     # the next layer squeezes this output: its last BatchNorm + SiLU pass takes the average
+                    a = m(a, pool=pool)
+                    if 'avg' in pool:
+                        a.pool = (pool['avg'], pool['max'])
+                else:
+                    a = m(a)
                 y.append(a if m.i in self.save else None)
         if self.training:
             # the blocks keep what backward needs on themselves (one set): a later train-mode forward overwrites it, so the
