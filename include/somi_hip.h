@@ -257,6 +257,11 @@ int somi_bifpn_nhwc_f32(const float *const *src_host, const int *up_host, const 
 int somi_pool_nchunk(int HW);
 int somi_global_pool_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, float *out_avg,
                               float *out_max, float *workspace, somi_stream_t stream);
+/* The average pool of act(x), optionally followed by a per-channel affine map: out_avg[b][c] = post_scale[c] * mean_p act(x[b,p,c]) + post_shift[c]
+ * (post_scale / post_shift NULL: the plain mean).  SEAM's squeeze (models/common.py:8483) reads BatchNorm(GELU(u)) only through its global average,
+ * which is that expression with the BatchNorm's scale / shift: the normalised tensor is never written.  Same workspace. */
+int somi_global_pool_act_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int act, const float *post_scale,
+                                  const float *post_shift, float *out_avg, float *workspace, somi_stream_t stream);
 /* z = silu(x * scale + shift) (the Conv block's BatchNorm + SiLU, as somi_chan_affine_act_nhwc_f32 with act = SILU, order = 0) AND the global
  * average / max pools of z per (image, channel) in the same pass - what a channel attention right behind the block would otherwise re-read z for
  * (models/common.py:339-358).  C / 4 must divide 256 or be a multiple of it (somi_affine_silu_pool_rows returns 0 otherwise: use the two

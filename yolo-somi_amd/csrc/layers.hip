@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void bifpn_kernel(BifpnArgs a, float *__restri
 // stage 1: grid (nchunk, B): each workgroup reduces a chunk of pixels for all channels (lane = channel quad,
 // coalesced rows); stage 2 folds the chunks.  Deterministic (no atomics).
 constexpr int POOL_CHUNK = 256;   // pixels per chunk
+template <bool ACT>                 // ACT: the pools of act(x) (SEAM's squeeze reads BatchNorm(GELU(u)) only through its average: that tensor is never written)
 __global__ __launch_bounds__(256) void global_pool_stage1(const float *__restrict__ x, int x_cs, int x_coff, int HW, int C,
                                                           float *__restrict__ part_sum, float *__restrict__ part_max,
-                                                          int nchunk) {
+                                                          int nchunk, int act) {
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int C4 = C >> 2;
     const int p0 = chunk * POOL_CHUNK, p1 = min(p0 + POOL_CHUNK, HW);
@@ -187,7 +188,11 @@ __global__ __launch_bounds__(256) void global_pool_stage1(const float *__restric
         if (rr < rows_par) {
 #pragma unroll 4
             for (int p = p0 + rr; p < p1; p += rows_par) {            // unrolled: four rows' loads in flight, sums in row order
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)b * HW + p) * x_cs + x_coff + (cq0 + cq) * 4);
+                f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)b * HW + p) * x_cs + x_coff + (cq0 + cq) * 4);
+                if (ACT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act_rt(v[e], act);
+                }
                 s += v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
@@ -215,7 +220,8 @@ __global__ __launch_bounds__(256) void global_pool_stage1(const float *__restric
 // chain of `nchunk` memory latencies); group sums combined in ascending group order
 __global__ __launch_bounds__(256) void global_pool_stage2(const float *__restrict__ part_sum, const float *__restrict__ part_max,
                                                           int nchunk, int C, int B, float inv_hw, float *__restrict__ out_avg,
-                                                          float *__restrict__ out_max) {
+                                                          float *__restrict__ out_max, const float *__restrict__ post_scale,
+                                                          const float *__restrict__ post_shift) {
     __shared__ double ls[256];
     __shared__ float lm[256];
     const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -245,7 +251,9 @@ __global__ __launch_bounds__(256) void global_pool_stage2(const float *__restric
     if (grp != 0 || i >= B * C) return;
 #pragma unroll
     for (int g = 1; g < 16; ++g) { s += ls[g * 16 + cl]; m = fmaxf(m, lm[g * 16 + cl]); }
-    out_avg[i] = (float)(s * (double)inv_hw);
+    float a = (float)(s * (double)inv_hw);
+    if (post_scale) a = a * post_scale[i % C] + post_shift[i % C];     // the mean of an affine map of the pooled values (per-channel scale / shift)
+    out_avg[i] = a;
     if (out_max) out_max[i] = m;
 }
 
@@ -787,10 +795,24 @@ extern "C" int somi_global_pool_nhwc_f32(const float *x, int x_cs, int x_coff, i
                  SOMI_EINVAL, "global pool: C,x_cs,x_coff %% 4 and alignment");
     const int nchunk = somi_pool_nchunk(HW);
     float *ps = workspace, *pm = workspace + (size_t)B * nchunk * C;
-    hipLaunchKernelGGL(global_pool_stage1, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, HW, C, ps, pm, nchunk);
+    hipLaunchKernelGGL(global_pool_stage1<false>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, HW, C, ps, pm, nchunk, 0);
     hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, (hipStream_t)stream, ps, pm, nchunk, C, B,
-                       1.0f / (float)HW, out_avg, out_max);
+                       1.0f / (float)HW, out_avg, out_max, nullptr, nullptr);
     return launch_status("somi_global_pool_nhwc_f32");
+}
+
+extern "C" int somi_global_pool_act_nhwc_f32(const float *x, int x_cs, int x_coff, int B, int HW, int C, int act, const float *post_scale,
+                                             const float *post_shift, float *out_avg, float *workspace, somi_stream_t stream) {
+    SOMI_REQUIRE(x && out_avg && workspace && B > 0 && HW > 0 && C > 0 && !post_scale == !post_shift && act >= 0 && act <= SOMI_ACT_SIGMOID,
+                 SOMI_EINVAL, "global pool (act): bad arguments");
+    SOMI_REQUIRE(C % 4 == 0 && x_cs % 4 == 0 && x_coff % 4 == 0 && x_coff + C <= x_cs && aligned16(x) && aligned16(workspace),
+                 SOMI_EINVAL, "global pool (act): C,x_cs,x_coff %% 4 and alignment");
+    const int nchunk = somi_pool_nchunk(HW);
+    float *ps = workspace, *pm = workspace + (size_t)B * nchunk * C;
+    hipLaunchKernelGGL(global_pool_stage1<true>, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_coff, HW, C, ps, pm, nchunk, act);
+    hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, (hipStream_t)stream, ps, pm, nchunk, C, B,
+                       1.0f / (float)HW, out_avg, nullptr, post_scale, post_shift);
+    return launch_status("somi_global_pool_act_nhwc_f32");
 }
 
 // workgroups per image of affine_silu_pool_kernel (0: the shape is not covered - C / 4 must divide 256 or be a multiple of it) and its partial rows
@@ -822,7 +844,7 @@ extern "C" int somi_affine_silu_pool_nhwc_f32(const float *x, int x_cs, int x_co
     float *ps = workspace, *pm = workspace + (size_t)B * rows * C;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(affine_silu_pool_kernel, dim3(gx, B), dim3(256), 0, s, x, x_cs, x_coff, scale, shift, z, z_cs, z_coff, HW, C, ps, pm, rows);
-    hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, ps, pm, rows, C, B, 1.0f / (float)HW, out_avg, out_max);
+    hipLaunchKernelGGL(global_pool_stage2, dim3(cdiv((long)B * C, 16)), dim3(256), 0, s, ps, pm, rows, C, B, 1.0f / (float)HW, out_avg, out_max, nullptr, nullptr);
     return launch_status("somi_affine_silu_pool_nhwc_f32");
 }
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     'somi_bifpn_nhwc_f32': (I, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), P, F, I, P, I, I, I, I, S]),
     'somi_pool_nchunk': (I, [I]),
     'somi_global_pool_nhwc_f32': (I, [P, I, I, I, I, I, P, P, P, S]),
+    'somi_global_pool_act_nhwc_f32': (I, [P, I, I, I, I, I, I, P, P, P, P, S]),
     'somi_affine_silu_pool_rows': (I, [I, I, I]),
     'somi_affine_silu_pool_nhwc_f32': (I, [P, I, I, P, P, P, I, I, I, I, I, P, P, P, S]),
     'somi_attn_mlp_f32': (I, [I, P, P, P, P, P, P, P, I, I, I, S]),

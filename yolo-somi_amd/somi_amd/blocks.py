@@ -871,8 +871,20 @@ class SEAM(_Packed):
         u1 = ops.dwconv3x3(y0, pk['dw1'], pk['b1'])
         y1, s1 = self._bn_train(u1, st[0].fn[2], residual=y0)    # Residual: fn(y0) + y0
         u2 = ops.conv2d_nhwc(y1, pk['pw'], pk['pb'], kh=1, kw=1)
-        y2, s2 = self._bn_train(u2, st[3])
-        avg, _ = ops.global_pool(y2, want_max=False)
+        if ops.SYNC_BN is None and ops.FUSE_POOL:
+            # BN(GELU(u2)) is read by the global average pool only, and the mean of an affine map is the affine map of the mean: the statistics pass,
+            # then ONE pass that averages gelu(u2) per image and applies scale / shift to the (B,C) result - the normalised tensor is never written
+            bn2 = st[3]
+            rm, rv = bn2.running_mean.detach().clone(), bn2.running_var.detach().clone()
+            s2 = tuple(ops.bn_stats(u2, c := u2.shape[3], 0, bn2.weight.detach(), bn2.bias.detach(), bn2.eps, bn2.momentum, rm, rv, act='gelu'))
+            with torch.no_grad():
+                bn2.running_mean.copy_(rm)
+                bn2.running_var.copy_(rv)
+                _bump_batches_tracked(bn2)
+            avg = ops.global_pool_act(u2, 'gelu', s2[2], s2[3], c=c)
+        else:
+            y2, s2 = self._bn_train(u2, st[3])
+            avg, _ = ops.global_pool(y2, want_max=False)
         sc = ops.attn_mlp(1, avg, None, pk['W1'], None, pk['W2'], None)
         self.__dict__['_ctx'] = (x, u0, s0, y0, u1, s1, y1, u2, s2, avg, sc, pk)
         return Act(ops.scale_channels(x.t, sc), 0, x.c)

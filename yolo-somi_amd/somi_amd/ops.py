@@ -350,6 +350,19 @@ def global_pool(x, c=None, x_coff=0, want_max=True):
     return avg, mx
 
 
+def global_pool_act(x, act, post_scale=None, post_shift=None, c=None, x_coff=0):
+    """(B, c): post_scale * mean over pixels of act(x) + post_shift - the global average of an activation + per-channel affine map of x without
+    writing that tensor (somi_global_pool_act_nhwc_f32)."""
+    B, H, W, cs = x.shape
+    c = cs - x_coff if c is None else c
+    L = _lib.lib()
+    ws = torch.empty(2 * B * L.somi_pool_nchunk(H * W) * c, device=x.device, dtype=torch.float32)
+    avg = torch.empty(B, c, device=x.device, dtype=torch.float32)
+    check(L.somi_global_pool_act_nhwc_f32(_ptr(_f32c(x)), cs, x_coff, B, H * W, c, ACT[act], _ptr(post_scale), _ptr(post_shift), _ptr(avg), _ptr(ws),
+                                          _stream()), 'global_pool_act')
+    return avg
+
+
 def affine_silu_pool(x, c, x_coff, scale, shift, out, out_coff=0):
     """out = silu(x * scale + shift) and the global average / max pools of it per (image, channel) in one pass; -> (avg, max) (B, c), or None when
     the kernel does not cover the width (c / 4 must divide 256 or be a multiple of it) - the caller then runs the two separate passes."""
