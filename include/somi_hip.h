@@ -200,6 +200,10 @@ int somi_dcnv3_backward_f64(const double *input, const double *offset, const dou
  *  centre-feature-scale blend y = x*(1-s) + xproj*s with s = sigmoid(logit[p*logit_cs + g]). */
 int somi_layernorm_act_nhwc_f32(const float *x, const float *gamma, const float *beta, float eps, int act, float *y,
                                 long npix, int C, somi_stream_t stream);
+/* depthwise 3x3 conv (+bias) -> LayerNorm over C -> activation in ONE pass (the DCNv3 block's dw_conv chain, modules/dcnv3.py:283-291), C == 256:
+ * u = the conv output (the LayerNorm backward reads it), y = act(LN(u)); bit-identical to somi_dwconv3x3_nhwc_f32 + somi_layernorm_act_nhwc_f32. */
+int somi_dwconv3x3_ln_nhwc_f32(const float *x, const float *w, const float *bias, const float *gamma, const float *beta, float eps, int act,
+                               float *u, float *y, int B, int H, int W, int C, somi_stream_t stream);
 int somi_group_softmax_f32(const float *x, float *y, long n_groups, int K, somi_stream_t stream);
 /* group g of pixel p at x + p*x_stride + g*K (y likewise); x == y allowed */
 int somi_group_softmax_strided_f32(const float *x, long x_stride, float *y, long y_stride, long npix, int G, int K, somi_stream_t stream);

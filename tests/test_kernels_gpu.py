@@ -246,6 +246,30 @@ def test_sppf_backward_follows_the_chain_of_pools(ties, B, C, H, W):
     assert torch.equal(dbuf2[..., :C].cpu(), dbuf[..., :C].cpu())
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 11, 9), (1, 70, 5), (3, 8, 33)])
+def test_dwconv_layernorm_gelu_in_one_pass(B, H, W):
+    """somi_dwconv3x3_ln_nhwc_f32 (the DCNv3 block's depthwise conv -> LayerNorm -> GELU chain, 256 channels) against the two separate passes and
+    against torch: the conv output u is the same tensor bit for bit, y within one rounding of the separate LayerNorm kernel's (same formulas)."""
+    from somi_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(H)
+    C = 256
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.4
+    b = torch.randn(C, generator=g) * 0.2
+    lw, lb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    wp = w[:, 0].permute(1, 2, 0).reshape(9, C).contiguous().to(d)
+    xd = nhwc(x).to(d)
+    u, y = ops.dwconv3x3_ln(xd, wp, b.to(d), lw.to(d), lb.to(d), 1e-6, 'gelu')
+    u2 = ops.dwconv3x3(xd, wp, b.to(d))
+    y2 = ops.layernorm_act(u2, lw.to(d), lb.to(d), 1e-6, 'gelu')
+    assert torch.equal(u, u2)
+    rel_close(y, y2, rel=1e-6, what='fused vs separate LayerNorm + GELU')
+    want_u = F.conv2d(x.double(), w.double(), b.double(), 1, 1, groups=C)
+    want = F.gelu(F.layer_norm(want_u.permute(0, 2, 3, 1), (C,), lw.double(), lb.double(), 1e-6))
+    rel_close(y, want, rel=1e-5, what='dwconv + LayerNorm + GELU')
+
+
 def test_attention_pieces():
     from somi_amd import ops
     d = dev()

@@ -90,6 +90,72 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float *__restrict_
     }
 }
 
+// The DCNv3 block's depthwise conv -> LayerNorm -> GELU chain (modules/dcnv3.py:283-291) in one pass, for C == 256: the lanes of a wave hold the 64
+// channel quads of ONE image column, so each output row's LayerNorm statistics are two wave reductions of values already in registers.  Writes u
+// (the conv output: the LayerNorm backward reads it) and y = act(LN(u)); the separate LayerNorm pass's read of u is gone.  Same arithmetic and
+// summation order as dwconv3x3_kernel<false> + layernorm_act_kernel (bit-identical results).
+__global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int act,
+                                                           float *__restrict__ u, float *__restrict__ y, int B, int H, int W, int SEG) {
+    constexpr int C = 256, C4 = 64;
+    const int nseg = (H + SEG - 1) / SEG;
+    const long items = (long)B * nseg * W * C4;                         // a multiple of 64: whole waves enter or leave the loop
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const int c = (int)(it % C4) * 4;
+        const int wv = (int)((it / C4) % W);
+        const int seg = (int)((it / ((long)C4 * W)) % nseg);
+        const long b = it / ((long)C4 * W * nseg);
+        f32x4 wk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const f32x4 *>(w + k * C + c);
+        const f32x4 bv = bias ? *reinterpret_cast<const f32x4 *>(bias + c) : zero;
+        const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + c), bt = *reinterpret_cast<const f32x4 *>(beta + c);
+        const bool wl = wv > 0, wr = wv + 1 < W;
+        const float *xb = x + (b * H * W + wv) * C + c;
+        auto load_row = [&](int h, f32x4 (&row)[3]) {
+            if ((unsigned)h < (unsigned)H) {
+                const float *pr = xb + (long)h * W * C;
+                row[0] = wl ? *reinterpret_cast<const f32x4 *>(pr - C) : zero;
+                row[1] = *reinterpret_cast<const f32x4 *>(pr);
+                row[2] = wr ? *reinterpret_cast<const f32x4 *>(pr + C) : zero;
+            } else {
+                row[0] = row[1] = row[2] = zero;
+            }
+        };
+        const int h_lo = seg * SEG, h_hi = min(H, h_lo + SEG);
+        f32x4 top[3], mid[3], bot[3];
+        load_row(h_lo - 1, top);
+        load_row(h_lo, mid);
+        for (int h = h_lo; h < h_hi; ++h) {
+            load_row(h + 1, bot);
+            f32x4 acc = bv;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc += top[q] * wk[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc += mid[q] * wk[3 + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc += bot[q] * wk[6 + q];
+            const long o = ((b * H + h) * W + wv) * C + c;
+            *reinterpret_cast<f32x4 *>(u + o) = acc;
+            float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+            const float mean = s / (float)C;
+            const f32x4 d = acc - mean;
+            float q2 = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            for (int sh = 32; sh > 0; sh >>= 1) q2 += __shfl_xor(q2, sh);
+            const float rstd = rsqrtf(q2 / (float)C + eps);
+            f32x4 v = d * rstd;
+            v = v * gm + bt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_rt(v[e], act);
+            *reinterpret_cast<f32x4 *>(y + o) = v;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { top[q] = mid[q]; mid[q] = bot[q]; }
+        }
+    }
+}
+
 void launch_dwconv3x3(bool flip, const float *x, const float *w, const float *bias, const float *ps, const float *pt, const float *res,
                       float *y, int B, int H, int W, int C, int act, hipStream_t s) {
     const int seg = H >= 64 ? 16 : 8;
@@ -755,6 +821,18 @@ extern "C" int somi_dwconv3x3_nhwc_f32(const float *x, const float *w, const flo
     SOMI_REQUIRE(!post_scale == !post_shift, SOMI_EINVAL, "dwconv: post_scale and post_shift go together");
     somi::launch_dwconv3x3(false, x, w, bias, post_scale, post_shift, residual, y, B, H, W, C, act, (hipStream_t)stream);
     return launch_status("somi_dwconv3x3_nhwc_f32");
+}
+
+extern "C" int somi_dwconv3x3_ln_nhwc_f32(const float *x, const float *w, const float *bias, const float *gamma, const float *beta, float eps,
+                                          int act, float *u, float *y, int B, int H, int W, int C, somi_stream_t stream) {
+    SOMI_REQUIRE(x && w && gamma && beta && u && y && B > 0 && H > 0 && W > 0, SOMI_EINVAL, "dwconv + layernorm: bad arguments");
+    SOMI_REQUIRE(C == 256, SOMI_ENOTIMPL, "dwconv + layernorm: 256 channels only (one wave per pixel); run the two passes for other widths");
+    SOMI_REQUIRE(aligned16(x) && aligned16(w) && aligned16(u) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!bias || aligned16(bias)),
+                 SOMI_EINVAL, "dwconv + layernorm: 16 B alignment");
+    const int seg = H >= 64 ? 16 : 8;
+    hipLaunchKernelGGL(dwconv3x3_ln_kernel, dim3(ew_grid((long)B * cdiv(H, seg) * W * 64)), dim3(256), 0, (hipStream_t)stream, x, w, bias, gamma, beta,
+                       eps, act, u, y, B, H, W, seg);
+    return launch_status("somi_dwconv3x3_ln_nhwc_f32");
 }
 
 extern "C" int somi_sppf_pool_nhwc_f32(float *buf, int B, int H, int W, int C, int cs, int x_coff, somi_stream_t stream) {

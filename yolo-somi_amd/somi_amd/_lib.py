@@ -78,6 +78,7 @@ SIGNATURES = {
     'somi_dcnv3_forward_f64': (I, [P, P, P, P] + [I] * 13 + [F, I, S]),
     'somi_dcnv3_backward_f64': (I, [P, P, P, P, P, P, P] + [I] * 13 + [F, I, P, Z, S]),
     'somi_layernorm_act_nhwc_f32': (I, [P, P, P, F, I, P, C.c_long, I, S]),
+    'somi_dwconv3x3_ln_nhwc_f32': (I, [P, P, P, P, P, F, I, P, P, I, I, I, I, S]),
     'somi_group_softmax_f32': (I, [P, P, C.c_long, I, S]),
     'somi_group_softmax_strided_f32': (I, [P, C.c_long, P, C.c_long, C.c_long, I, I, S]),
     'somi_group_softmax_bwd_strided_f32': (I, [P, C.c_long, P, P, C.c_long, C.c_long, I, I, S]),

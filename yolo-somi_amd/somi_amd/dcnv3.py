@@ -161,8 +161,12 @@ class DCNv3(nn.Module):
         dw = self.dw_conv[0]
         ln = self.dw_conv[1][1]
         wdw = dw.weight.detach().float()[:, 0].permute(1, 2, 0).reshape(9, C).contiguous()
-        u = ops.dwconv3x3(input, wdw, dw.bias.detach().float().contiguous())
-        x1 = ops.layernorm_act(u, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
+        if C == 256 and ops.FUSE_POOL:                           # one pass: a wave owns a pixel's 256 channels, the row statistics are wave reductions
+            u, x1 = ops.dwconv3x3_ln(input, wdw, dw.bias.detach().float().contiguous(), ln.weight.detach().float().contiguous(),
+                                     ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
+        else:
+            u = ops.dwconv3x3(input, wdw, dw.bias.detach().float().contiguous())
+            x1 = ops.layernorm_act(u, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
         K = self.kernel_size * self.kernel_size
         GK = self.group * K
         cfg = (self.kernel_size, self.kernel_size, self.stride, self.stride, self.pad, self.pad, self.dilation, self.dilation, self.group,

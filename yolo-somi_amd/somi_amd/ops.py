@@ -314,6 +314,15 @@ def dwconv3x3(x, w, bias=None, post_scale=None, post_shift=None, residual=None, 
     return out
 
 
+def dwconv3x3_ln(x, w, bias, gamma, beta, eps, act='gelu'):
+    """(u, y): u = depthwise 3x3 conv of x (+bias), y = act(LayerNorm_C(u)) - one pass (256 channels; somi_dwconv3x3_ln_nhwc_f32)."""
+    B, H, W, Cc = x.shape
+    u, y = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.lib().somi_dwconv3x3_ln_nhwc_f32(_ptr(_f32c(x)), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), float(eps), ACT[act], _ptr(u), _ptr(y),
+                                                B, H, W, Cc, _stream()), 'dwconv3x3_ln')
+    return u, y
+
+
 def sppf_pool_(buf, c, x_coff=0, codes=False):
     """The three chained 5x5 pools of slice [x_coff, x_coff + c) into the next three slices of `buf`.  codes=True (training): level by level, and
     -> (buf, codes): where each window's first maximum sits, for sppf_pool_backward_(codes=...)."""
