@@ -86,7 +86,7 @@ def _ddp_worker(rank, world, port, q):
     gb.broadcast_buffers(stats)                               # DDP's broadcast_buffers (train.py:208-209): rank 0's overwrite everyone's
     assert torch.equal(stats, torch.arange(6, dtype=torch.float32)), stats
     gb.broadcast_buffers(torch.empty(0))                      # a graph without buffers: no collective, no hang
-    res = (rank, order, list(gb.launched), g0.clone(), g1.clone())
+    res = (rank, order, list(gb.launched), g0.tolist(), g1.tolist())   # plain lists: a tensor in the queue is fetched from THIS process, which may have exited by then
     secs, nbytes = gb.measure_exchange(iters=2)              # what bench.py reports as `allreduce` at N > 1 (collective)
     assert secs > 0 and nbytes == 1010 * 4 and float(g0.abs().sum()) == 0.0 and gb.launched == []
     q.put(res)
@@ -106,8 +106,8 @@ def test_gradient_buckets_all_reduce_sum_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     for rank, order, launched, g0, g1 in res:
-        assert torch.equal(g0, torch.arange(1000, dtype=torch.float32) * 3)      # (1 + 2) x the base gradient on every rank
-        assert torch.equal(g1, torch.ones(10) * 3)
+        assert g0 == (torch.arange(1000, dtype=torch.float32) * 3).tolist()      # (1 + 2) x the base gradient on every rank
+        assert g1 == [3.0] * 10
         # buffer 0 buckets from the end: [744,1000) after layer 2; [488,744) after layer 1 (>= 300); [232,488) and [0,232) after layer 0
         b0 = [(s, e) for bi, s, e in launched if bi == 0]
         assert b0 == [(744, 1000), (488, 744), (232, 488), (0, 232)]

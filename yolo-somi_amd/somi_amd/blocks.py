@@ -518,9 +518,10 @@ class C2fCBAM(nn.Module):
             blk(cat.slice((1 + i) * c, c), out=cat.slice((2 + i) * c, c))
         return self.cv2(cat, pool=pool)
 
-    def backward(self, dout, dx_out=None, accumulate=False):
+    def backward(self, dout, dx_out=None, accumulate=False, pooled=None):
+        """pooled: a pending part of dout that is constant over each image's pixels (Act.pooled): the closing conv's BatchNorm backward folds it in."""
         c, n = self.c, len(self.m)
-        dcat = self.cv2.backward(dout)                            # gradient of every piece through the 1x1 mix
+        dcat = self.cv2.backward(dout, pooled=pooled)             # gradient of every piece through the 1x1 mix
         for i in reversed(range(n)):
             self.m[i].backward(dcat.slice((2 + i) * c, c), dcat.slice((1 + i) * c, c))
         return self.cv1.backward(dcat.slice(0, 2 * c), dx_out=dx_out, accumulate=accumulate)

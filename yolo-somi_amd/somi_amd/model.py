@@ -253,8 +253,8 @@ class Model(nn.Module):
             srcs = self._sources(m)
             pend = None
             if g.pooled is not None:                              # a part constant over each image's pixels, not added yet (ODConv's squeeze gradient)
-                if isinstance(m, B.Conv) and not isinstance(g, list):
-                    pend, g.pooled = g.pooled, None               # this layer's BatchNorm backward folds it in
+                if type(m) in (B.Conv, B.C2fCBAM):
+                    pend, g.pooled = g.pooled, None               # this layer's (closing conv's) BatchNorm backward folds it in
                 else:
                     B.settle_pooled(g)
             if isinstance(m, (B.BiFPN, B.Concat)):
@@ -271,8 +271,11 @@ class Model(nn.Module):
                         have.t.shape[3] == B.pad4(have.c) and have.t.is_contiguous() and have.pooled is None and
                         (not isinstance(m, B.ODConv_3rd) or (ops.ODCONV_INPLACE and have.t.shape[3] == have.c))):
                     # the input already holds another consumer's gradient: the data-gradient epilogue adds to it in place
-                    m.backward(g, dx_out=have, accumulate=True, **kw)
-                elif (have is None and isinstance(m, B.ODConv_3rd) and type(self.model[srcs[0]]) is B.Conv and ops.BN_POOLED and
+                    if (isinstance(m, B.ODConv_3rd) and type(self.model[srcs[0]]) in (B.Conv, B.C2fCBAM) and ops.BN_POOLED and ops.SYNC_BN is None):
+                        have.pooled = m.backward(g, dx_out=have, accumulate=True, defer_pool=True).pooled    # the last consumer to arrive: see below
+                    else:
+                        m.backward(g, dx_out=have, accumulate=True, **kw)
+                elif (have is None and isinstance(m, B.ODConv_3rd) and type(self.model[srcs[0]]) in (B.Conv, B.C2fCBAM) and ops.BN_POOLED and
                       ops.SYNC_BN is None and ops.ODCONV_INPLACE):
                     # the only consumer of a plain Conv's output (later layers have all been walked): its squeeze gradient rides that Conv's BatchNorm backward
                     give(srcs[0], m.backward(g, defer_pool=True))
