@@ -471,10 +471,19 @@ def main():
             out['allreduce'] = exchange
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model, args.mode, args.size, nc, wbf=ensemble)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(out) + '\n').encode())
     if dist:
         dist.destroy_process_group()
 
 
+_REAL_STDOUT = None
+
+
 if __name__ == '__main__':
+    # ONE JSON line on stdout, nothing else: libraries print there too (RCCL writes its version banner to stdout when the first communicator comes up),
+    # so everything but the final line goes to stderr - file descriptor 1 points at stderr for the run, the line is written to the real stdout.
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     main()
