@@ -103,6 +103,17 @@ def _grad_target(param):
     return torch.zeros_like(param, dtype=torch.float32), True
 
 
+def _grad_targets(*params):
+    """_grad_target for several parameters -> (buffers, finish): the kernels accumulate into `buffers`, finish() adds the scratch ones (if any) to .grad."""
+    tg = [_grad_target(p_) for p_ in params]
+
+    def finish():
+        for p_, (buf, scratch) in zip(params, tg):
+            if scratch:
+                _acc_grad(p_, buf)
+    return [t[0] for t in tg], finish
+
+
 _NBT_PENDING = None      # Model.forward collects the BatchNorm step counters here and bumps them with one multi-tensor add
 
 
@@ -704,10 +715,9 @@ class ODConv_3rd(_Packed):
         cin, cout, kk, K = cv.in_channels, cv.out_channels, k * k, cv.K
         hid = fcw.shape[0]
         f = lambda t: t.detach().float().contiguous()            # noqa: E731
-        dg, db = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+        (dg, db), fin = _grad_targets(self.bn.weight, self.bn.bias)      # the kernel accumulates straight into .grad when it can
         dy = ops.bn_act_backward(dz.t, dz.coff, y, 0, cout, *so, _act_name(self.act), 0, True, torch.empty_like(y), 0, dg, db)
-        _acc_grad(self.bn.weight, dg)
-        _acc_grad(self.bn.bias, db)
+        fin()
         # per-sample conv: bias, weight and data gradients
         dbias_b, _ = ops.global_pool(dy, want_max=False)
         dbias_b = dbias_b * float(dy.shape[1] * dy.shape[2])                  # sum over pixels = mean * HoWo
@@ -734,12 +744,13 @@ class ODConv_3rd(_Packed):
             _acc_grad(lin.weight, gW)
             _acc_grad(lin.bias, gb)
         # relu + BatchNorm over the batch (or plain relu for one sample)
-        g2, b2 = torch.zeros(hid, device=dev), torch.zeros(hid, device=dev)
+        if B > 1:
+            (g2, b2), fin = _grad_targets(cv.bn.weight, cv.bn.bias)
+        else:                                                     # one sample: no BatchNorm in the forward (models/common.py:4562), nothing for its parameters
+            g2, b2, fin = torch.zeros(hid, device=dev), torch.zeros(hid, device=dev), lambda: None
         dzpre = ops.bn_act_backward(dzv.view(B, 1, 1, hid), 0, zpre.view(B, 1, 1, hid), 0, hid, *st, 'relu', 0, B > 1,
                                     torch.empty(B, 1, 1, hid, device=dev), 0, g2, b2).view(B, hid)
-        if B > 1:
-            _acc_grad(cv.bn.weight, g2)
-            _acc_grad(cv.bn.bias, b2)
+        fin()
         gfc = torch.zeros_like(fcw)
         dgap = torch.empty_like(gap) if need_dx else None
         ops.linear_backward(gap, fcw, dzpre, dzpre, 0, 'none', gfc, None, dgap)
@@ -857,10 +868,9 @@ class SEAM(_Packed):
     def _bn_backward(self, dz, u, st, bn, pooled=None):
         """gradient w.r.t. u of BN_batch(GELU(u)) (order 1), parameter gradients accumulated.  pooled: ops.bn_act_backward (dz may then be None)."""
         c = u.shape[3]
-        dg, db = torch.zeros(c, device=u.device), torch.zeros(c, device=u.device)
+        (dg, db), fin = _grad_targets(bn.weight, bn.bias)
         du = ops.bn_act_backward(dz, 0, u, 0, c, *st, 'gelu', 1, True, torch.empty_like(u), 0, dg, db, pooled=pooled)
-        _acc_grad(bn.weight, dg)
-        _acc_grad(bn.bias, db)
+        fin()
         return du
 
     def _forward_train(self, x):
@@ -896,18 +906,17 @@ class SEAM(_Packed):
         c = x.c
         dev = x.t.device
         dx, dsc = ops.scale_channels_backward(dout.t, x.t, sc)
-        gW1, gW2 = torch.zeros_like(pk['W1']), torch.zeros_like(pk['W2'])
+        (gW1, gW2), fin = _grad_targets(self.fc[0].weight, self.fc[2].weight)
         davg, _ = ops.attn_mlp_backward(1, dsc, sc, avg, None, pk['W1'], None, pk['W2'], gW1, None, gW2, None)
-        _acc_grad(self.fc[0].weight, gW1)
-        _acc_grad(self.fc[2].weight, gW2)
+        fin()
         # y2 is read by the global average pool only: its gradient is davg / HW at every pixel - handed to the BatchNorm backward as such
         # (no zero tensor filled, added to and read twice)
         du2 = self._bn_backward(None, u2, s2, st[3], pooled=(davg, None, None))
         dwp = ops.conv2d_wgrad_nhwc(y1, du2, kh=1, kw=1)
         _acc_grad(st[1].weight, dwp.view(c, c, 1, 1))
-        dbp = torch.zeros(c, device=dev)
+        (dbp,), fin = _grad_targets(st[1].bias)
         ops.chan_sum_(du2, c, 0, dbp)
-        _acc_grad(st[1].bias, dbp)
+        fin()
         dy1 = ops.conv2d_dgrad_nhwc(du2, pk['pwt'], B=x.shape[0], H=x.shape[1], W=x.shape[2], cin=c, kh=1, kw=1)
         du1 = self._bn_backward(dy1, u1, s1, st[0].fn[2])
         gw, gb = torch.zeros_like(pk['dw1']), torch.zeros(c, device=dev)
@@ -1264,10 +1273,9 @@ class DCNv3_YOLO(_Packed):
     def backward(self, dz, need_dx=True):
         u, st, saved = self.__dict__.pop('_ctx')
         c, dev = self.bn.num_features, u.device
-        dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+        (dg, db), fin = _grad_targets(self.bn.weight, self.bn.bias)
         du = ops.bn_act_backward(dz.t, dz.coff, u, 0, c, *st, _act_name(self.act), 0, True, torch.empty_like(u), 0, dg, db)
-        _acc_grad(self.bn.weight, dg)
-        _acc_grad(self.bn.bias, db)
+        fin()
         dinput, grads = self.dcnv3._backward_impl(saved, du)
         for p_, g_ in zip(self.dcnv3._params(), grads):
             _acc_grad(p_, g_.view_as(p_) if g_.numel() == p_.numel() else g_[:p_.shape[0]])
