@@ -275,6 +275,7 @@ def test_bench_refuses_a_mislaunch():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], capture_output=True, text=True,
                        timeout=300, env=env, cwd=root)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout) and '{' not in r.stdout
+    assert r.stdout == ''        # stdout is reserved for the one JSON line (file descriptor 1 points at stderr for the run)
 
 
 def test_custom_ops_are_registered_device_only():
