@@ -161,7 +161,7 @@ class DCNv3(nn.Module):
         dw = self.dw_conv[0]
         ln = self.dw_conv[1][1]
         wdw = dw.weight.detach().float()[:, 0].permute(1, 2, 0).reshape(9, C).contiguous()
-        if C == 256 and ops.FUSE_POOL:                           # one pass: a wave owns a pixel's 256 channels, the row statistics are wave reductions
+        if C == 256 and ops.FUSE_DWLN:                           # one pass: a wave owns a pixel's 256 channels, the row statistics are wave reductions
             u, x1 = ops.dwconv3x3_ln(input, wdw, dw.bias.detach().float().contiguous(), ln.weight.detach().float().contiguous(),
                                      ln.bias.detach().float().contiguous(), ln.eps, 'gelu')
         else:

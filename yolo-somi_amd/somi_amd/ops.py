@@ -27,6 +27,7 @@ PREC = {None: 0, 'f32': 0, 'bf16': 1, 'bf16x3': 2}
 FUSE_POOL = os.environ.get('SOMI_FUSE_POOL', '1') != '0'      # 0: the channel attention pools its input in a pass of its own (round-3 form; A/B runs)
 AMAX_BY_VALUE = os.environ.get('SOMI_AMAX_BY_VALUE', '1') != '0'   # 0: the max-pool's arg-max from somi_pool_argmax_nhwc_f32's own pass over the tensor
 ODCONV_INPLACE = os.environ.get('SOMI_ODCONV_INPLACE', '1') != '0'   # 0: ODConv's squeeze pools its input itself; its input gradient goes through a tensor of its own + add passes (A/B runs)
+FUSE_DWLN = os.environ.get('SOMI_FUSE_DWLN', '1') != '0'    # 0: the DCNv3 block's depthwise conv and LayerNorm + GELU as two passes (A/B runs)
 CBAM_FUSED_BN = os.environ.get('SOMI_CBAM_FUSED_BN', '1') != '0'   # 0: CBAM's step C as a pass of its own before the BatchNorm backward (A/B runs)
 BN_POOLED = os.environ.get('SOMI_BN_POOLED', '1') != '0'    # 0: CBAM's pooled gradients are added by a pass of their own (round-3 form; A/B runs)
 
